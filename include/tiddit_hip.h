@@ -1,0 +1,113 @@
+/*
+ * tiddit_hip.h — C ABI of libtiddit_hip.so, the MI355X (gfx950) implementation of TIDDIT's
+ * signal-aggregation and clustering hot path.
+ *
+ * The reference (SciLifeLab/TIDDIT v3.9.5) has no FFI: its boundary for this path is the Python
+ * module-function level.  Each entry point below names the reference interface
+ * it replaces (file:line under tiddit/); the tiddit_amd python modules bind them with ctypes and re-exports the
+ * reference's own function names/signatures (see INTEGRATION.md for the binding a maintainer adds).
+ *
+ * Conventions
+ *   - plain C: opaque handles, pointers + sizes, no C++/torch types.
+ *   - every function returns 0 (TDT_OK) or a negative TDT_E_* code; tdt_last_error() gives the
+ *     message of the last failure on the calling thread.
+ *   - `h_*` / unprefixed pointers are caller-owned HOST memory; `d_*` pointers are caller-owned
+ *     DEVICE memory on the context's GPU.  Calls taking only d_* pointers are asynchronous on the
+ *     context stream (tdt_ctx_stream); calls that return results to host memory synchronise.
+ *   - coordinates are 0-based; `end` is exclusive (htslib bam_endpos / pysam reference_end).
+ *   - there is NO CPU fallback: without a usable GPU tdt_ctx_create fails.
+ */
+#ifndef TIDDIT_HIP_H
+#define TIDDIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDT_OK 0
+#define TDT_E_ARG (-1)      /* bad argument (null pointer, bin_size <= 0, m < 2, ...)              */
+#define TDT_E_HIP (-2)      /* a HIP runtime call failed (message in tdt_last_error)               */
+#define TDT_E_RANGE (-3)    /* a read indexes a bin outside its contig (reference: IndexError)     */
+#define TDT_E_INEXACT (-4)  /* a bin left the exact-arithmetic domain (|acc| >= 2^53)              */
+#define TDT_E_NOMEM (-5)
+#define TDT_E_UNSUPPORTED (-6) /* input outside the device path's domain (e.g. coordinate span >= 2^32) */
+
+typedef struct tdt_ctx tdt_ctx;
+typedef struct tdt_cov tdt_cov;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int tdt_version(void);
+const char *tdt_last_error(void);
+int tdt_device_count(int *count);
+int tdt_ctx_create(int device, tdt_ctx **out);
+void tdt_ctx_destroy(tdt_ctx *ctx);
+int tdt_ctx_sync(tdt_ctx *ctx);
+/* The hipStream_t all asynchronous work of this context is enqueued on (as void*). */
+void *tdt_ctx_stream(tdt_ctx *ctx);
+/* Enqueue work on an externally owned hipStream_t (e.g. torch's current stream); 0 restores the
+ * context's own stream. */
+int tdt_ctx_set_stream(tdt_ctx *ctx, void *hip_stream);
+
+/* ---- binned read-depth histogram ---------------------------------------------------------- *
+ * Replaces tiddit_coverage.create_coverage (tiddit_coverage.pyx:10-21), the per-read
+ * update_coverage calls (tiddit_coverage.pyx:48-74) driven by __main__.py:229-242 (--cov) and
+ * tiddit_signal.pyx:169-182 (--sv), including their read filter
+ *     keep iff !(flag & 0x4) && !(flag & 0x400) && mapq >= min_q .
+ * Bins are bit-identical to the reference's float64 arrays: every per-read contribution
+ * float32(bases)/float32(den) is added as an exact 2^-S fixed-point int64 (S from tdt_cov_scale_bits). */
+int tdt_cov_create(tdt_ctx *ctx, const int64_t *contig_len, int n_contigs, int bin_size, tdt_cov **out);
+void tdt_cov_destroy(tdt_cov *cov);
+/* bins = ceil(LN/bin_size); end_bin_size = LN - (bins-1)*bin_size      (tiddit_coverage.pyx:15-17) */
+int tdt_cov_nbins(tdt_cov *cov, int tid, int64_t *nbins, int *end_bin_size);
+int tdt_cov_scale_bits(tdt_cov *cov);
+/* zero all accumulators (a fresh create_coverage) */
+int tdt_cov_reset(tdt_cov *cov);
+/* Add n alignment records of contig `tid`.  Host arrays are staged through pinned memory and copied
+ * with hipMemcpyAsync (double-buffered), the kernel applies the read filter on device. */
+int tdt_cov_push(tdt_cov *cov, int tid, const int32_t *start, const int32_t *end, const uint8_t *mapq,
+                 const uint16_t *flag, size_t n, int min_q);
+/* Same with device-resident arrays (asynchronous). */
+int tdt_cov_push_device(tdt_cov *cov, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq,
+                        const uint16_t *d_flag, size_t n, int min_q);
+/* Convert contig tid's accumulators to float64 bins (exact), copy to host / leave on device.
+ * Returns TDT_E_RANGE / TDT_E_INEXACT if any pushed read / bin violated the domain. */
+int tdt_cov_finish(tdt_cov *cov, int tid, double *out_bins);
+int tdt_cov_finish_device(tdt_cov *cov, int tid, double *d_out_bins);
+/* Number of reads that passed the filter so far (all contigs); synchronises. */
+int tdt_cov_kept(tdt_cov *cov, int64_t *kept);
+
+/* ---- binned GC / N-mask histogram ---------------------------------------------------------- *
+ * Replaces tiddit_gc.binned_gc's per-character loop (tiddit_gc.pyx:14-31): out[bin] = -1 if
+ * n/bin_size > n_cutoff else round_half_even(100*gc/chars); chars = bytes actually in the bin. */
+int tdt_gc_bins(tdt_ctx *ctx, const uint8_t *seq, int64_t len, int bin_size, double n_cutoff, int8_t *out);
+/* d_seq must be 16-byte aligned; asynchronous. */
+int tdt_gc_bins_device(tdt_ctx *ctx, const uint8_t *d_seq, int64_t len, int bin_size, double n_cutoff, int8_t *d_out);
+
+/* ---- signal clustering ("DBSCAN") ----------------------------------------------------------- *
+ * Replaces DBSCAN.x_coordinate_clustering (DBSCAN.py:33-64), y_coordinate_clustering (:66-123) and
+ * main (:125-129).  `data` is the reference's row-major int64 [n, stride] array (column 0 = posA,
+ * column 1 = posB) in the order the caller would hand to DBSCAN.main; labels come back as float64
+ * in that same order, exactly as the reference returns them.  eps is compared like numpy compares
+ * an int64 distance with the Python number: d < eps.
+ *   mode 0: main (x then y);  mode 1: x pass only.  *last_id receives the final cluster_id. */
+int tdt_dbscan(tdt_ctx *ctx, const int64_t *data, size_t n, size_t stride, double eps, int m, int mode,
+               double *labels, int64_t *last_id);
+/* Device-resident batch: nb independent buckets ((chrA,chrB) pairs), bucket b owning points
+ * [bucket_off[b], bucket_off[b+1]) of d_x/d_y (uint32 coordinates, each bucket in DBSCAN.main input
+ * order).  bucket_off is a HOST array of nb+1 offsets.  Labels (float64, ids restart per bucket)
+ * are written to d_labels; per-bucket final cluster_id to d_last_id (int64[nb], may be NULL).
+ * Asynchronous unless large x-clusters need the segmented sort (one 8-byte readback). */
+int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, size_t n, const int64_t *bucket_off,
+                      int nb, uint64_t eps, int m, int mode, double *d_labels, int64_t *d_last_id);
+/* tiddit_cluster.pyx:152-154 in one call: stable sort of each bucket by posA, then DBSCAN.main.
+ * perm_out[i] = index (within the whole input) of the point at sorted position i. */
+int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
+                    double eps, int m, uint32_t *perm_out, double *labels_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIDDIT_HIP_H */

@@ -1,0 +1,389 @@
+"""GPU parity tests: the HIP path (through the C ABI of libtiddit_hip.so) against the CPU oracle and
+the golden vectors captured from the real reference.  Bit-exact everywhere (integer / exact-float
+work).  Run on the MI355X box: python -m pytest tests -m gpu"""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tiddit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from tiddit_amd import _native
+    _native.load()
+    return _native
+
+
+@pytest.fixture(scope="module")
+def ctx(nat):
+    return nat.default_context(0)
+
+
+@pytest.fixture(scope="module")
+def cov(ctx):
+    from tiddit_amd import tiddit_coverage
+    return tiddit_coverage
+
+
+@pytest.fixture(scope="module")
+def gcmod(ctx):
+    from tiddit_amd import tiddit_gc
+    return tiddit_gc
+
+
+@pytest.fixture(scope="module")
+def db(ctx):
+    from tiddit_amd import DBSCAN
+    return DBSCAN
+
+
+# ------------------------------------------------------------------------------------ coverage
+def test_native_library_is_loaded(nat):
+    assert nat.load().tdt_version() >= 100
+    maps = open("/proc/self/maps").read()
+    assert "libtiddit_hip.so" in maps
+
+
+def test_coverage_kat(cov, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "coverage.json")))
+    for k in g["kat"]:
+        arr, ebs = cov.create_coverage({"SQ": [{"SN": "c", "LN": k["LN"]}]}, k["bin"], "c")
+        r = cov.update_coverage(k["s"], k["e"], k["bin"], arr, ebs)
+        assert r is arr
+        assert arr.tolist() == k["bins"], k
+    for s in g["shapes"]:
+        d, eb = cov.create_coverage({"SQ": [{"SN": "a", "LN": s["LN"]}, {"SN": "b", "LN": 77}]}, s["bin"])
+        assert (len(d["a"]), eb["a"], len(d["b"]), eb["b"]) == (s["nbins"], s["end_bin_size"], s["nbins_b"], s["end_bin_size_b"])
+        h = cov.CoverageHistogram([("a", s["LN"]), ("b", 77)], s["bin"])
+        assert h.nbins("a") == (s["nbins"], s["end_bin_size"]) and h.nbins("b") == (s["nbins_b"], s["end_bin_size_b"])
+        h.close()
+
+
+def test_coverage_random_golden(cov, golden_dir):
+    z = np.load(os.path.join(golden_dir, "coverage_random.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    for c in range(n):
+        LN, b = z["c%d_meta" % c].tolist()
+        s, e = z["c%d_start" % c], z["c%d_end" % c]
+        h = cov.CoverageHistogram([("c", LN)], b)
+        h.push("c", s, e, np.full(len(s), 60, np.uint8), np.zeros(len(s), np.uint16), 0)
+        got = h.finish("c")
+        assert h.kept() == len(s)
+        h.close()
+        assert np.array_equal(got, z["c%d_bins" % c]), (c, LN, b)
+
+
+@pytest.mark.parametrize("tag", ["cov", "sv"])
+def test_coverage_config1_stream(cov, golden_dir, tag):
+    g = json.load(open(os.path.join(golden_dir, "coverage.json")))["config1"][tag]
+    start, end, mapq, flag = synth.gen_reads(1_000_000, 10)
+    h = cov.CoverageHistogram([("chrS", 1_000_000)], g["bin"])
+    h.push("chrS", start, end, mapq, flag, g["q"])
+    bins = h.finish("chrS")
+    assert h.kept() == g["kept"]
+    assert sha(bins.astype("<f8")) == g["bins_sha256"]
+    assert np.array_equal(bins, np.load(os.path.join(golden_dir, "config1_bins_%s.npy" % tag)))
+    # pushing in two halves, out of order, gives the same bins (exact integer accumulation)
+    h.reset()
+    half = len(start) // 2 + 3
+    h.push("chrS", start[half:], end[half:], mapq[half:], flag[half:], g["q"])
+    h.push("chrS", start[:half], end[:half], mapq[:half], flag[:half], g["q"])
+    assert np.array_equal(h.finish("chrS"), bins)
+    h.close()
+
+
+def test_coverage_print_matches_golden(cov, golden_dir, tmp_path):
+    g = json.load(open(os.path.join(golden_dir, "coverage.json")))["config1"]["cov"]
+    start, end, mapq, flag = synth.gen_reads(1_000_000, 10)
+    hdr = {"SQ": [{"SN": "chrS", "LN": 1_000_000}]}
+    d, eb = cov.create_coverage(hdr, 500)
+    d["chrS"] = cov.update_coverage_batch(start, end, mapq, flag, 20, 500, d["chrS"], eb["chrS"])
+    for ft in ("bed", "wig"):
+        p = str(tmp_path / ("o." + ft))
+        cov.print_coverage(d, hdr, 500, ft, p)
+        assert hashlib.sha256(open(p, "rb").read()).hexdigest() == g[ft + "_sha256"]
+
+
+@pytest.mark.parametrize("LN,z,depth,seed", [(3_000_000, 500, 30, 1), (3_000_000, 50, 30, 2), (1_000_003, 333, 60, 3),
+                                              (5_000_000, 1000, 8, 4), (200_000, 1, 3, 5), (700_001, 4096, 40, 6)])
+def test_coverage_stream_vs_oracle(cov, LN, z, depth, seed):
+    start, end, mapq, flag = synth.gen_reads(LN, depth, seed=seed)
+    want, kept = oracle.coverage_stream(start, end, mapq, flag, LN, z, 5)
+    h = cov.CoverageHistogram([("c", LN)], z)
+    h.push("c", start, end, mapq, flag, 5)
+    got = h.finish("c")
+    assert h.kept() == kept
+    h.close()
+    assert np.array_equal(got, want)
+
+
+def test_coverage_long_and_unsorted_reads(cov):
+    rng = np.random.default_rng(9)
+    LN, z, n = 2_000_000, 50, 200_000
+    start = rng.integers(0, LN - 1, n)                      # NOT sorted
+    span = np.where(rng.random(n) < 0.05, rng.integers(1, 60_000, n), rng.integers(1, 400, n))  # ONT-like tails
+    end = np.minimum(start + span, LN)
+    mapq = rng.integers(0, 61, n).astype(np.uint8)
+    flag = np.where(rng.random(n) < 0.1, 0x400, 0).astype(np.uint16)
+    want, kept = oracle.coverage_stream(start, end, mapq, flag, LN, z, 20)
+    h = cov.CoverageHistogram([("c", LN)], z)
+    h.push("c", start, end, mapq, flag, 20)
+    got = h.finish("c")
+    assert h.kept() == kept
+    assert np.array_equal(got, want)
+    h.close()
+
+
+def test_coverage_multi_contig_and_last_bin(cov):
+    rng = np.random.default_rng(10)
+    contigs = [("a", 1137), ("b", 100_000), ("c", 99_999), ("d", 1), ("e", 50_000)]
+    h = cov.CoverageHistogram(contigs, 500)
+    want = {}
+    for name, LN in contigs:
+        n = 4000
+        start = np.sort(rng.integers(0, LN, n))
+        end = np.minimum(start + rng.integers(1, 700, n), LN)      # many reads end exactly at LN
+        mapq = np.full(n, 30, np.uint8)
+        flag = np.zeros(n, np.uint16)
+        want[name], _ = oracle.coverage_stream(start, end, mapq, flag, LN, 500, 20)
+        h.push(name, start, end, mapq, flag, 20)
+    for name, LN in contigs:
+        assert np.array_equal(h.finish(name), want[name]), name
+    h.close()
+
+
+def test_coverage_out_of_range_raises(cov, nat):
+    arr, ebs = cov.create_coverage({"SQ": [{"SN": "c", "LN": 1000}]}, 500, "c")
+    with pytest.raises(IndexError):
+        cov.update_coverage(900, 1200, 500, arr, ebs)
+    h = cov.CoverageHistogram([("c", 1000)], 500)
+    h.push("c", [10], [5], [60], [0], 0)   # end <= start
+    with pytest.raises(nat.TdtError):
+        h.finish("c")
+    h.close()
+
+
+def test_coverage_device_pointers_and_misalignment(cov, ctx):
+    torch = pytest.importorskip("torch")
+    LN, z = 4_000_000, 500
+    start, end, mapq, flag = synth.gen_reads(LN, 20, seed=77)
+    want, _ = oracle.coverage_stream(start[3:], end[3:], mapq[3:], flag[3:], LN, z, 20)
+    dev = torch.device("cuda:0")
+    ts = torch.from_numpy(start.astype(np.int32)).to(dev)
+    te = torch.from_numpy(end.astype(np.int32)).to(dev)
+    tm = torch.from_numpy(mapq).to(dev)
+    tf = torch.from_numpy(flag.view(np.int16)).to(dev)
+    out = torch.empty(len(want), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    h = cov.CoverageHistogram([("c", LN)], z)
+    # offset by 3 elements: none of the arrays is vector-load aligned any more
+    n = len(start) - 3
+    h.push_device("c", ts.data_ptr() + 12, te.data_ptr() + 12, tm.data_ptr() + 3, tf.data_ptr() + 6, n, 20)
+    h.finish_device("c", out.data_ptr())
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), want)
+    h.reset()
+    want0, _ = oracle.coverage_stream(start, end, mapq, flag, LN, z, 20)
+    h.push_device("c", ts.data_ptr(), te.data_ptr(), tm.data_ptr(), tf.data_ptr(), len(start), 20)
+    h.finish_device("c", out.data_ptr())
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), want0)
+    h.close()
+
+
+# ------------------------------------------------------------------------------------------ gc
+def test_gc_kat(gcmod, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "gc.json")))
+    for k in g["kat"]:
+        out = gcmod.binned_gc_array(k["seq"].encode(), k["bin"], k["n_cutoff"])
+        assert out.dtype == np.int8 and out.tolist() == k["out"], k
+
+
+def test_gc_random_golden(gcmod, golden_dir):
+    z = np.load(os.path.join(golden_dir, "gc_random.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    for c in range(n):
+        L, b, seed = z["c%d_meta" % c].tolist()
+        seq = synth.gen_sequence(L, seed=seed, n_frac=0.08)
+        out = gcmod.binned_gc_array(seq, b, float(z["c%d_cut" % c][0]))
+        assert np.array_equal(out, z["c%d_out" % c]), (c, L, b)
+
+
+@pytest.mark.parametrize("L,b,cut", [(10_000_019, 50, 0.5), (3_000_001, 500, 0.5), (2_000_000, 64, 0.1), (1_000_000, 2048, 0.5),
+                                     (1_000_000, 2049, 0.5), (5_000_000, 100_000, 0.3), (999_983, 13, 0.0), (64, 50, 0.5),
+                                     (1_000_000, 1_000_000, 0.5), (1_000_001, 1_000_000, 1.0)])
+def test_gc_vs_oracle(gcmod, L, b, cut):
+    seq = synth.gen_sequence(L, seed=L % 97, n_frac=0.1)
+    assert np.array_equal(gcmod.binned_gc_array(seq, b, cut), oracle.binned_gc(seq, b, cut))
+
+
+def test_gc_fasta_entry_points(gcmod, tmp_path):
+    fa = tmp_path / "ref.fa"
+    seqs = {"chrA": synth.gen_sequence(12_345, seed=1), "chrB": synth.gen_sequence(700, seed=2), "chrC": synth.gen_sequence(61, seed=3)}
+    with open(fa, "w") as f:
+        for name, s in seqs.items():
+            f.write(">%s some description\n" % name)
+            t = s.tobytes().decode()
+            for i in range(0, len(t), 60):
+                f.write(t[i:i + 60] + "\n")
+    r = gcmod.binned_gc(str(fa), "chrB", 50, 0.5)
+    assert r[0] == "chrB" and np.array_equal(r[1], oracle.binned_gc(seqs["chrB"], 50, 0.5))
+    d = gcmod.main(str(fa), list(seqs), 4, 50, 0.5)
+    for name, s in seqs.items():
+        assert np.array_equal(d[name], oracle.binned_gc(s, 50, 0.5)), name
+
+
+# -------------------------------------------------------------------------------------- dbscan
+def test_dbscan_kat(db, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "dbscan.json")))
+    for k in g["kat"]:
+        data = np.array(k["data"], dtype=np.int64)
+        xl, xid = db.x_coordinate_clustering(data, k["eps"], k["m"])
+        assert xl.tolist() == k["x"] and xid == k["x_id"], k
+        yl, yid = db.y_coordinate_clustering(data, k["eps"], k["m"], xid, xl.copy())
+        assert yl.tolist() == k["y"] and yid == k["y_id"], k
+        assert db.main(data, k["eps"], k["m"]).tolist() == k["y"]
+    # the reference's own commented toy (DBSCAN.py:132-133) given as a list of lists
+    assert db.main([[1, 2], [1, 2], [1, 2], [10, 11]], 0.1, 2).tolist() == [0.0, 0.0, -1.0, -1.0]
+
+
+def test_dbscan_random_golden(db, golden_dir):
+    z = np.load(os.path.join(golden_dir, "dbscan_random.npz"))
+    n = len([k for k in z.files if k.endswith("_par")])
+    for c in range(n):
+        data = z["r%d_data" % c]
+        eps, m, xid, yid = z["r%d_par" % c].tolist()
+        xl, got_xid = db.x_coordinate_clustering(data, eps, m)
+        assert np.array_equal(xl, z["r%d_x" % c]) and got_xid == xid, c
+        assert np.array_equal(db.main(data, eps, m), z["r%d_y" % c]), c
+
+
+def test_dbscan_unsorted_x_golden(db, golden_dir):
+    z = np.load(os.path.join(golden_dir, "dbscan_unsorted_x.npz"))
+    n = len([k for k in z.files if k.endswith("_par")])
+    for c in range(n):
+        eps, m, xid = z["u%d_par" % c].tolist()
+        xl, got = db.x_coordinate_clustering(z["u%d_data" % c], eps, m)
+        assert np.array_equal(xl, z["u%d_x" % c]) and got == xid, c
+
+
+def test_dbscan_gen_golden(db, golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "dbscan_gen.json")))
+    for n in ("100000", "1000000"):
+        if n not in g:
+            continue
+        lab = db.main(synth.gen_points(int(n)), g[n]["eps"], g[n]["m"])
+        assert sha(lab.astype("<f8")) == g[n]["labels_sha256"], n
+        assert int(lab.max()) == g[n]["final_max_id"] and int((lab == -1).sum()) == g[n]["n_noise"]
+
+
+@pytest.mark.parametrize("n,span,eps,m,seed", [(200_000, 2_000_000, 500, 3, 1),      # dense: x-clusters of thousands of points
+                                               (300_000, 100_000, 50, 3, 2),          # one giant x-cluster
+                                               (150_000, 50_000_000, 500, 4, 3), (100_000, 5_000_000, 175, 2, 4),
+                                               (50_000, 1_000, 5, 3, 5), (257, 300, 500, 3, 6), (100_000, 3_000_000, 300, 9, 7)])
+def test_dbscan_dense_vs_oracle(db, n, span, eps, m, seed):
+    rng = np.random.default_rng(seed)
+    x = np.sort(rng.integers(0, span, n))
+    y = np.where(rng.random(n) < 0.5, x + rng.integers(0, 4 * eps, n), rng.integers(0, span, n))
+    data = np.stack([x, y, np.arange(n)], 1).astype(np.int64)
+    want = oracle.dbscan_main(data, eps, m)
+    got = db.main(data, eps, m)
+    assert np.array_equal(got, want)
+    xl, xid = db.x_coordinate_clustering(data, eps, m)
+    wl, wid = oracle.x_coordinate_clustering(data, eps, m)
+    assert xid == wid and np.array_equal(xl, wl)
+
+
+def test_dbscan_config3_sha(db):
+    # BASELINE configs[2]: 5M points, e=500 l=3 — closed-form prediction recorded in SURVEY.md §8(d)
+    pts = synth.gen_points(5_000_000)
+    lab = db.main(pts, 500, 3)
+    assert int(lab.max()) == 517346 and int((lab == -1).sum()) == 2283962
+    assert sha(lab.astype("<f8")) == "2f3d430450eb79949107dae67154e5c6060e715e260e3547c537347ca1d0f45f"
+    assert np.array_equal(lab, oracle.dbscan_main(pts, 500, 3))
+
+
+def test_dbscan_negative_and_offset_coordinates(db):
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.integers(-50_000, 50_000, 5000)) + (1 << 40)
+    y = rng.integers(-1000, 1000, 5000) - (1 << 35)
+    data = np.stack([x, y], 1).astype(np.int64)
+    assert np.array_equal(db.main(data, 40, 3), oracle.dbscan_main(data, 40, 3))
+    assert np.array_equal(db.main(data, 39.5, 3), oracle.dbscan_main(data, 39.5, 3))
+
+
+def _bucketed_case(rng, nb):
+    sizes = rng.choice([0, 0, 1, 2, 3, 5, 40, 300, 5000], nb)
+    xs, ys, want, lastid = [], [], [], []
+    for s in sizes:
+        x = np.sort(rng.integers(0, max(10, s * 40), s))
+        y = np.where(rng.random(s) < 0.6, x + rng.integers(0, 900, s), rng.integers(0, max(10, s * 40), s))
+        xs.append(x)
+        ys.append(y)
+        if s:
+            d = np.stack([x, y], 1).astype(np.int64)
+            xl, xid = oracle.x_coordinate_clustering(d, 300, 3)
+            yl, yid = oracle.y_coordinate_clustering(d, 300, 3, xid, xl)
+            want.append(yl)
+            lastid.append(yid)
+        else:
+            want.append(np.zeros(0))
+            lastid.append(-1)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    return np.concatenate(xs), np.concatenate(ys), off, np.concatenate(want), np.array(lastid)
+
+
+def test_dbscan_device_buckets(ctx, nat):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(21)
+    for nb in (1, 7, 300):
+        x, y, off, want, lastid = _bucketed_case(rng, nb)
+        dev = torch.device("cuda:0")
+        tx = torch.from_numpy(x.astype(np.int64).astype(np.uint32).view(np.int32)).to(dev)
+        ty = torch.from_numpy(y.astype(np.int64).astype(np.uint32).view(np.int32)).to(dev)
+        tl = torch.empty(max(1, len(x)), dtype=torch.float64, device=dev)
+        tid = torch.empty(nb, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        nat.check(ctx.lib.tdt_dbscan_device(ctx.handle, tx.data_ptr(), ty.data_ptr(), len(x), nat.ptr(off), nb, 300, 3, 0,
+                                            tl.data_ptr(), tid.data_ptr()))
+        ctx.sync()
+        assert np.array_equal(tl.cpu().numpy()[:len(x)], want), nb
+        assert np.array_equal(tid.cpu().numpy(), lastid), nb
+
+
+def test_sort_dbscan(ctx, nat):
+    rng = np.random.default_rng(22)
+    nb = 40
+    x, y, off, _, _ = _bucketed_case(rng, nb)
+    # scramble inside every bucket; duplicates in posA exercise the stable tie order
+    x = (x // 7) * 7
+    for b in range(nb):
+        p = rng.permutation(off[b + 1] - off[b])
+        x[off[b]:off[b + 1]] = x[off[b]:off[b + 1]][p]
+        y[off[b]:off[b + 1]] = y[off[b]:off[b + 1]][p]
+    n = len(x)
+    perm = np.empty(n, dtype=np.uint32)
+    lab = np.empty(n, dtype=np.float64)
+    xa = x.astype(np.int64)
+    ya = y.astype(np.int64)
+    nat.check(ctx.lib.tdt_sort_dbscan(ctx.handle, nat.ptr(xa), nat.ptr(ya), n, nat.ptr(off), nb, 300.0, 3, nat.ptr(perm), nat.ptr(lab)))
+    for b in range(nb):
+        lo, hi = int(off[b]), int(off[b + 1])
+        if lo == hi:
+            continue
+        order = np.argsort(xa[lo:hi], kind="stable")                     # sorted(..., key=posA)  tiddit_cluster.pyx:152
+        assert np.array_equal(perm[lo:hi], lo + order), b
+        d = np.stack([xa[lo:hi][order], ya[lo:hi][order]], 1)
+        assert np.array_equal(lab[lo:hi], oracle.dbscan_main(d, 300, 3)), b

@@ -1,0 +1,120 @@
+"""ctypes binding of libtiddit_hip.so (include/tiddit_hip.h).  No CPU fallback: a missing library
+or a missing GPU raises."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libtiddit_hip.so")
+
+TDT_OK = 0
+ERRORS = {-1: "TDT_E_ARG", -2: "TDT_E_HIP", -3: "TDT_E_RANGE", -4: "TDT_E_INEXACT", -5: "TDT_E_NOMEM",
+          -6: "TDT_E_UNSUPPORTED"}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class TdtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERRORS.get(code, code), msg))
+        self.code = code
+
+
+# every symbol include/tiddit_hip.h declares: name -> (restype, argtypes)
+_i, _i64, _sz, _dbl, _P = ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_double, ctypes.c_void_p
+_PP = ctypes.POINTER(ctypes.c_void_p)
+SYMBOLS = {
+    "tdt_version": (_i, []),
+    "tdt_last_error": (ctypes.c_char_p, []),
+    "tdt_device_count": (_i, [ctypes.POINTER(_i)]),
+    "tdt_ctx_create": (_i, [_i, _PP]),
+    "tdt_ctx_destroy": (None, [_P]),
+    "tdt_ctx_sync": (_i, [_P]),
+    "tdt_ctx_stream": (_P, [_P]),
+    "tdt_ctx_set_stream": (_i, [_P, _P]),
+    "tdt_cov_create": (_i, [_P, _P, _i, _i, _PP]),
+    "tdt_cov_destroy": (None, [_P]),
+    "tdt_cov_nbins": (_i, [_P, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i)]),
+    "tdt_cov_scale_bits": (_i, [_P]),
+    "tdt_cov_reset": (_i, [_P]),
+    "tdt_cov_push": (_i, [_P, _i, _P, _P, _P, _P, _sz, _i]),
+    "tdt_cov_push_device": (_i, [_P, _i, _P, _P, _P, _P, _sz, _i]),
+    "tdt_cov_finish": (_i, [_P, _i, _P]),
+    "tdt_cov_finish_device": (_i, [_P, _i, _P]),
+    "tdt_cov_kept": (_i, [_P, ctypes.POINTER(_i64)]),
+    "tdt_gc_bins": (_i, [_P, _P, _i64, _i, _dbl, _P]),
+    "tdt_gc_bins_device": (_i, [_P, _P, _i64, _i, _dbl, _P]),
+    "tdt_dbscan": (_i, [_P, _P, _sz, _sz, _dbl, _i, _i, _P, ctypes.POINTER(_i64)]),
+    "tdt_dbscan_device": (_i, [_P, _P, _P, _sz, _P, _i, ctypes.c_uint64, _i, _i, _P, _P]),
+    "tdt_sort_dbscan": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P]),
+}
+
+
+def load():
+    """dlopen libtiddit_hip.so and type every entry point (no GPU needed for this step)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(SO_PATH):
+                raise ImportError("libtiddit_hip.so is not built (run `python -m tiddit_amd.build`); "
+                                  "tiddit_amd has no CPU fallback")
+            L = ctypes.CDLL(SO_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                f = getattr(L, name)
+                f.restype = res
+                f.argtypes = args
+            _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != TDT_OK:
+        raise TdtError(rc, load().tdt_last_error().decode(errors="replace"))
+
+
+def ptr(a):
+    """host numpy array -> void*"""
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Context:
+    """One tdt_ctx (device + stream + scratch).  Contexts are per process; use default_context()."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = ctypes.c_void_p()
+        check(self.lib.tdt_ctx_create(device, ctypes.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def sync(self):
+        check(self.lib.tdt_ctx_sync(self.handle))
+
+    def set_stream(self, hip_stream):
+        check(self.lib.tdt_ctx_set_stream(self.handle, ctypes.c_void_p(hip_stream)))
+
+    def close(self):
+        if self.handle:
+            self.lib.tdt_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = int(os.environ.get("TIDDIT_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    key = (os.getpid(), device)
+    if key not in _default:
+        _default[key] = Context(device)
+    return _default[key]

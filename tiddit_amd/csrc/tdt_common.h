@@ -1,0 +1,54 @@
+// Internal shared definitions for libtiddit_hip.so (gfx950 only; no portability layer).
+#pragma once
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/tiddit_hip.h"
+
+#define TDT_WAVE 64
+
+void tdt_set_error(const char *fmt, ...);
+
+#define TDT_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            tdt_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return TDT_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define TDT_CHECK_LAUNCH() TDT_HIP(hipGetLastError())
+
+// Grow-only device / pinned-host scratch buffers owned by a context.
+struct tdt_buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum { TDT_NSCRATCH = 24, TDT_NPINNED = 4 };
+
+struct tdt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;    // stream in use (own_stream or an adopted one)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int num_cu = 256;
+    tdt_buf scratch[TDT_NSCRATCH];
+    tdt_buf pinned[TDT_NPINNED];
+};
+
+int tdt_scratch(tdt_ctx *ctx, int slot, size_t bytes, void **out);
+int tdt_pinned(tdt_ctx *ctx, int slot, size_t bytes, void **out);
+
+static inline int tdt_ceil_log2_u64(uint64_t v) {
+    int l = 0;
+    while ((1ull << l) < v) l++;
+    return l;
+}

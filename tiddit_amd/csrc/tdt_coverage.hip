@@ -1,0 +1,527 @@
+// Binned read-depth histogram for gfx950 (MI355X).
+//
+// Replaces the per-read update_coverage loop of the reference (tiddit_coverage.pyx:48-74 driven by
+// __main__.py:229-242 and tiddit_signal.pyx:169-182).  Bit-exactness: every contribution of the
+// reference is double(float32(bases)/float32(den)); those quotients are taken from host-built
+// IEEE float32 tables and added as exact 2^-S fixed-point int64, so the sum is order independent
+// and equals the reference's float64 sum bit for bit.
+//
+// Kernel shape (HBM-bound streaming, 11 B/read, no MFMA):
+//   * one workgroup = 4 waves walks a contiguous chunk of COV_READS_PER_BLOCK coordinate-sorted
+//     reads, 4 reads per lane per step (16-byte coalesced loads of start/end, 4 B of mapq, 8 B of flag);
+//   * each lane folds its reads' contributions into two registers (bin K and K+1, K = first bin of
+//     its first read); a wavefront segmented reduction over runs of equal K (sorted input => long
+//     runs) merges the 64 lanes, so only run-tail lanes touch memory;
+//   * those few partial sums go to an LDS-staged per-workgroup window of int64 bins (ds_add_u64),
+//     anything outside the window (unsorted input, very long reads) straight to HBM atomics;
+//   * the window is spilled once with coalesced 64-bit global atomics, zero bins skipped.
+// A final elementwise pass turns int64 accumulators into the float64 bins.
+#include "tdt_common.h"
+
+#define COV_THREADS 256
+#define COV_RPL 4                                  // reads per lane per step
+#define COV_TILE (COV_THREADS * COV_RPL)           // 1024 reads per workgroup step
+#define COV_STEPS 8
+#define COV_READS_PER_BLOCK (COV_TILE * COV_STEPS) // 8192
+#define COV_WIN 2048                               // LDS window, int64 bins (16 KiB)
+#define COV_LUT_LDS_MAX 1024                       // LUT entries kept in LDS (bin_size < 1024)
+#define COV_PUSH_CHUNK (4u << 20)                  // reads per staged host chunk
+
+struct CovParams {
+    const int32_t *start;
+    const int32_t *end;
+    const uint8_t *mapq;
+    const uint16_t *flag;
+    unsigned long long n;
+    unsigned long long *acc;  // this contig's accumulators
+    int nbins;
+    int bin_size;
+    unsigned magic;           // floor(x / bin_size) = mulhi(x, magic) >> shift for 0 <= x < 2^31
+    int shift;                // -1: bin_size == 1
+    int min_q;
+    const unsigned long long *lut_main;  // [bin_size+1] fixed-point float32(b)/float32(bin_size)
+    const unsigned long long *lut_end;   // [bin_size+1] fixed-point float32(b)/float32(end_bin_size)
+    unsigned long long one;              // 1.0 in fixed point
+    int *status;                         // [0] |= 1 on range error
+    unsigned long long *kept;
+    int aligned;                         // all four arrays vector-load aligned
+};
+
+__device__ __forceinline__ int cov_div(int x, unsigned magic, int shift) {
+    return shift < 0 ? x : (int)(__umulhi((unsigned)x, magic) >> shift);
+}
+
+template <bool LDS_LUT>
+__global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
+    // everything lives in the dynamic region (a static __shared__ in front of it would shift its
+    // base off 16-byte alignment): [0] window base bin, [2..) window, then the two LUTs
+    int *s_base = reinterpret_cast<int *>(smem);
+    unsigned long long *win = smem + 2;
+    unsigned long long *lutM = win + COV_WIN;
+    unsigned long long *lutE = lutM + (LDS_LUT ? (P.bin_size + 1) : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const unsigned long long r0 = (unsigned long long)blockIdx.x * COV_READS_PER_BLOCK;
+    const unsigned long long r1 = min(P.n, r0 + COV_READS_PER_BLOCK);
+
+    for (int i = tid; i < COV_WIN; i += COV_THREADS) win[i] = 0;
+    if (LDS_LUT) {
+        for (int i = tid; i <= P.bin_size; i += COV_THREADS) {
+            lutM[i] = P.lut_main[i];
+            lutE[i] = P.lut_end[i];
+        }
+    }
+    if (tid == 0) {
+        int s = P.start[r0];
+        s = s < 0 ? 0 : s;
+        int b = cov_div(s, P.magic, P.shift);
+        *s_base = b < P.nbins ? b : P.nbins - 1;
+    }
+    __syncthreads();
+    const int base = *s_base;
+    const unsigned long long *LM = LDS_LUT ? lutM : P.lut_main;
+    const unsigned long long *LE = LDS_LUT ? lutE : P.lut_end;
+    const int z = P.bin_size;
+    const int last_bin = P.nbins - 1;
+
+    auto contribute = [&](int bin, unsigned long long v) {
+        unsigned off = (unsigned)(bin - base);
+        if (off < COV_WIN) atomicAdd(&win[off], v);
+        else atomicAdd(&P.acc[bin], v);
+    };
+
+    unsigned nkept = 0;
+    bool bad = false;
+
+    for (unsigned long long t0 = r0; t0 < r1; t0 += COV_TILE) {
+        const unsigned long long idx = t0 + (unsigned long long)tid * COV_RPL;
+        int sv[COV_RPL], ev[COV_RPL];
+        unsigned mq[COV_RPL], fl[COV_RPL];
+        if (P.aligned && idx + COV_RPL <= r1) {
+            const int4 s4 = *reinterpret_cast<const int4 *>(P.start + idx);
+            const int4 e4 = *reinterpret_cast<const int4 *>(P.end + idx);
+            const unsigned m4 = *reinterpret_cast<const unsigned *>(P.mapq + idx);
+            const uint2 f4 = *reinterpret_cast<const uint2 *>(P.flag + idx);
+            sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
+            ev[0] = e4.x; ev[1] = e4.y; ev[2] = e4.z; ev[3] = e4.w;
+            mq[0] = m4 & 0xff; mq[1] = (m4 >> 8) & 0xff; mq[2] = (m4 >> 16) & 0xff; mq[3] = m4 >> 24;
+            fl[0] = f4.x & 0xffff; fl[1] = f4.x >> 16; fl[2] = f4.y & 0xffff; fl[3] = f4.y >> 16;
+        } else {
+#pragma unroll
+            for (int j = 0; j < COV_RPL; j++) {
+                const bool ok = idx + j < r1;
+                sv[j] = ok ? P.start[idx + j] : 0;
+                ev[j] = ok ? P.end[idx + j] : 1;
+                mq[j] = ok ? P.mapq[idx + j] : 0;
+                fl[j] = ok ? P.flag[idx + j] : 0x4;  // padding lanes look unmapped
+            }
+        }
+
+        // lane key: first bin of the lane's first read (any value is correct; sorted input makes
+        // it non-decreasing across lanes so equal keys form runs)
+        int K;
+        {
+            int s = sv[0] < 0 ? 0 : sv[0];
+            K = cov_div(s, P.magic, P.shift);
+        }
+        unsigned long long vA = 0, vB = 0;
+        auto add = [&](int bin, unsigned long long v) {
+            if (bin == K) vA += v;
+            else if (bin == K + 1) vB += v;
+            else if (v) contribute(bin, v);
+        };
+
+#pragma unroll
+        for (int j = 0; j < COV_RPL; j++) {
+            int s = sv[j], e = ev[j];
+            bool keep = !(fl[j] & 0x404u) && (int)mq[j] >= P.min_q;
+            int fb = 0, eb = 0;
+            if (keep) {
+                if (s < 0 || e <= s) { bad = true; keep = false; }
+            }
+            if (keep) {
+                fb = cov_div(s, P.magic, P.shift);
+                eb = cov_div(e - 1, P.magic, P.shift);
+                if (eb > last_bin) { bad = true; keep = false; }
+            }
+            if (keep) {
+                nkept++;
+                if (fb == eb) {
+                    add(fb, LM[e - s]);                                  // tiddit_coverage.pyx:55-57
+                } else {
+                    add(fb, LM[(unsigned)(fb + 1) * (unsigned)z - (unsigned)s]);                     // :61-62
+                    const int bl = (int)((unsigned)(e - 1) - (unsigned)eb * (unsigned)z);                   // :63 (one short of the true overlap)
+                    add(eb, eb < last_bin ? LM[bl] : LE[bl]);            // :66-69
+                    for (int b = fb + 1; b < eb; b++) add(b, P.one);     // :71-72
+                }
+            }
+        }
+
+        // wavefront segmented reduction of (vA, vB) over runs of equal K
+        const int Kprev = __shfl_up(K, 1);
+        const bool head = (lane == 0) || (Kprev != K);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long below = heads & ((2ull << lane) - 1ull);  // heads at lanes <= lane
+        const int run_start = 63 - __clzll((long long)below);
+        const int dist = lane - run_start;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long a = __shfl_up(vA, d);
+            const unsigned long long b = __shfl_up(vB, d);
+            if (dist >= d) { vA += a; vB += b; }
+        }
+        const bool tail = (lane == 63) || ((heads >> lane >> 1) & 1ull);
+        if (tail) {
+            if (vA) contribute(K, vA);
+            if (vB) contribute(K + 1, vB);
+        }
+    }
+
+    // kept-read count: one atomic per wave
+    for (int d = 32; d > 0; d >>= 1) nkept += __shfl_down(nkept, d);
+    if (lane == 0 && nkept) atomicAdd(P.kept, (unsigned long long)nkept);
+    if (bad) atomicOr(P.status, 1);
+
+    __syncthreads();
+    // coalesced spill of the LDS window
+    for (int i = tid; i < COV_WIN; i += COV_THREADS) {
+        const unsigned long long v = win[i];
+        if (v) atomicAdd(&P.acc[base + i], v);
+    }
+}
+
+__global__ void cov_finalize(const long long *__restrict__ acc, double *__restrict__ out, long long n, double inv_scale,
+                             int *status) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    bool inexact = false;
+    for (; i < n; i += stride) {
+        const long long a = acc[i];
+        if (a >= (1ll << 53) || a < 0) inexact = true;
+        out[i] = (double)a * inv_scale;
+    }
+    if (inexact) atomicOr(status, 2);
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct tdt_cov {
+    tdt_ctx *ctx = nullptr;
+    int n_contigs = 0;
+    int bin_size = 0;
+    int S = 0;  // fixed-point fraction bits
+    unsigned magic = 0;
+    int shift = 0;
+    std::vector<int64_t> len, nbins, off;  // off: accumulator offset of each contig
+    std::vector<int> end_bin_size;
+    int64_t total_bins = 0;
+    unsigned long long *d_acc = nullptr;
+    unsigned long long *d_lut_main = nullptr;
+    unsigned long long *d_lut_end = nullptr;  // [n_contigs][bin_size+1]
+    int *d_status = nullptr;                  // [0] status bits, (8 B further) kept counter
+    unsigned long long *d_kept = nullptr;
+    // staging slots for host pushes
+    void *d_stage[2] = {nullptr, nullptr};
+    void *h_stage[2] = {nullptr, nullptr};
+    hipEvent_t slot_ev[2] = {nullptr, nullptr};
+    int slot_used[2] = {0, 0};
+    int next_slot = 0;
+};
+
+static bool build_lut(std::vector<unsigned long long> &lut, int bin_size, int den, int S) {
+    const double scale = ldexp(1.0, S);
+    for (int b = 0; b <= bin_size; b++) {
+        // exactly what Cython emits: (float)bases / (float)den, widened to double
+        volatile float q = (float)b / (float)den;
+        double f = (double)q * scale;
+        unsigned long long fx = (unsigned long long)f;
+        if ((double)fx != f) return false;  // not representable at S bits: S too small
+        lut[b] = fx;
+    }
+    return true;
+}
+
+extern "C" int tdt_cov_create(tdt_ctx *ctx, const int64_t *contig_len, int n_contigs, int bin_size, tdt_cov **out) {
+    if (!ctx || !contig_len || !out || n_contigs <= 0) {
+        tdt_set_error("tdt_cov_create: bad argument");
+        return TDT_E_ARG;
+    }
+    *out = nullptr;
+    if (bin_size <= 0 || bin_size > (1 << 24)) {
+        tdt_set_error("tdt_cov_create: bin_size %d outside [1, 2^24] (reference: float32 bases are exact only there)",
+                      bin_size);
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(ctx->device));
+    tdt_cov *c = new tdt_cov();
+    c->ctx = ctx;
+    c->n_contigs = n_contigs;
+    c->bin_size = bin_size;
+    const int L = tdt_ceil_log2_u64((uint64_t)bin_size);
+    c->S = 23 + L + 1;
+    if (L == 0) {
+        c->shift = -1;
+        c->magic = 0;
+    } else {
+        // m = ceil(2^(31+L) / d): floor(x/d) == (x*m) >> (31+L) for all 0 <= x < 2^31
+        const unsigned __int128 num = (unsigned __int128)1 << (31 + L);
+        const unsigned __int128 m = (num + (unsigned)bin_size - 1) / (unsigned)bin_size;
+        c->magic = (unsigned)m;
+        c->shift = L - 1;
+        const int probes[] = {0, 1, bin_size - 1, bin_size, bin_size + 1, 2 * bin_size - 1, 2 * bin_size, 1000003,
+                              0x3fffffff, 0x7ffffffe, 0x7fffffff};
+        for (int x : probes) {
+            if (x < 0) continue;
+            const int q = (int)(((unsigned long long)(unsigned)x * c->magic) >> 32 >> c->shift);
+            if (q != x / bin_size) {
+                tdt_set_error("internal: magic division self-check failed for d=%d x=%d", bin_size, x);
+                delete c;
+                return TDT_E_ARG;
+            }
+        }
+    }
+    c->len.assign(contig_len, contig_len + n_contigs);
+    c->nbins.resize(n_contigs);
+    c->off.resize(n_contigs);
+    c->end_bin_size.resize(n_contigs);
+    int64_t total = 0;
+    for (int i = 0; i < n_contigs; i++) {
+        const int64_t LN = contig_len[i];
+        if (LN < 0 || LN > 0x7fffffffll) {
+            tdt_set_error("tdt_cov_create: contig %d length %lld outside [0, 2^31)", i, (long long)LN);
+            delete c;
+            return TDT_E_ARG;
+        }
+        const int64_t bins = (LN + bin_size - 1) / bin_size;  // == int(ceil(LN/float(bin_size))) for LN < 2^53
+        c->nbins[i] = bins;
+        c->end_bin_size[i] = (int)(LN - (bins - 1) * bin_size);
+        c->off[i] = total;
+        total += bins;
+        // keep every contig's accumulators 16-byte aligned
+        total = (total + 1) & ~1ll;
+    }
+    c->total_bins = total;
+    const size_t lut_n = (size_t)bin_size + 1;
+    std::vector<unsigned long long> lut(lut_n), lute((size_t)n_contigs * lut_n);
+    if (!build_lut(lut, bin_size, bin_size, c->S)) {
+        tdt_set_error("internal: fixed-point scale 2^-%d cannot represent float32(b)/float32(%d)", c->S, bin_size);
+        delete c;
+        return TDT_E_ARG;
+    }
+    for (int i = 0; i < n_contigs; i++) {
+        std::vector<unsigned long long> t(lut_n);
+        const int ebs = c->end_bin_size[i] > 0 ? c->end_bin_size[i] : bin_size;
+        // b/ebs >= b/bin_size, so the quotient never needs more fraction bits than the main table.
+        // Entries with b >= ebs are only read for reads overhanging the contig end inside its last
+        // bin (the reference then really divides by end_bin_size, :69); they are exact too.
+        const double scale = ldexp(1.0, c->S);
+        for (size_t b = 0; b < lut_n; b++) {
+            volatile float q = (float)b / (float)ebs;
+            double f = (double)q * scale;
+            unsigned long long fx = (f < 1.8e19) ? (unsigned long long)f : 0ull;
+            t[b] = ((double)fx == f) ? fx : 0ull;
+        }
+        memcpy(&lute[(size_t)i * lut_n], t.data(), lut_n * sizeof(unsigned long long));
+    }
+    hipError_t e;
+    auto fail = [&](const char *what) {
+        tdt_set_error("tdt_cov_create: %s failed: %s", what, hipGetErrorString(e));
+        tdt_cov_destroy(c);
+        return TDT_E_HIP;
+    };
+    if ((e = hipMalloc((void **)&c->d_acc, (size_t)(total > 0 ? total : 1) * 8)) != hipSuccess) return fail("hipMalloc(acc)");
+    if ((e = hipMalloc((void **)&c->d_lut_main, lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut)");
+    if ((e = hipMalloc((void **)&c->d_lut_end, (size_t)n_contigs * lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut_end)");
+    if ((e = hipMalloc((void **)&c->d_status, 16)) != hipSuccess) return fail("hipMalloc(status)");
+    c->d_kept = (unsigned long long *)((char *)c->d_status + 8);
+    if ((e = hipMemcpy(c->d_lut_main, lut.data(), lut_n * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(lut)");
+    if ((e = hipMemcpy(c->d_lut_end, lute.data(), (size_t)n_contigs * lut_n * 8, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail("hipMemcpy(lut_end)");
+    if ((e = hipMemset(c->d_acc, 0, (size_t)(total > 0 ? total : 1) * 8)) != hipSuccess) return fail("hipMemset(acc)");
+    if ((e = hipMemset(c->d_status, 0, 16)) != hipSuccess) return fail("hipMemset(status)");
+    for (int i = 0; i < 2; i++)
+        if ((e = hipEventCreateWithFlags(&c->slot_ev[i], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate");
+    *out = c;
+    return TDT_OK;
+}
+
+extern "C" void tdt_cov_destroy(tdt_cov *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->d_acc) (void)hipFree(c->d_acc);
+    if (c->d_lut_main) (void)hipFree(c->d_lut_main);
+    if (c->d_lut_end) (void)hipFree(c->d_lut_end);
+    if (c->d_status) (void)hipFree(c->d_status);
+    for (int i = 0; i < 2; i++) {
+        if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+        if (c->slot_ev[i]) (void)hipEventDestroy(c->slot_ev[i]);
+    }
+    delete c;
+}
+
+extern "C" int tdt_cov_nbins(tdt_cov *c, int tid, int64_t *nbins, int *end_bin_size) {
+    if (!c || tid < 0 || tid >= c->n_contigs) {
+        tdt_set_error("tdt_cov_nbins: bad contig id");
+        return TDT_E_ARG;
+    }
+    if (nbins) *nbins = c->nbins[tid];
+    if (end_bin_size) *end_bin_size = c->end_bin_size[tid];
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_scale_bits(tdt_cov *c) { return c ? c->S : TDT_E_ARG; }
+
+extern "C" int tdt_cov_reset(tdt_cov *c) {
+    if (!c) return TDT_E_ARG;
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    TDT_HIP(hipMemsetAsync(c->d_acc, 0, (size_t)(c->total_bins > 0 ? c->total_bins : 1) * 8, c->ctx->stream));
+    TDT_HIP(hipMemsetAsync(c->d_status, 0, 16, c->ctx->stream));
+    return TDT_OK;
+}
+
+static int cov_launch(tdt_cov *c, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq,
+                      const uint16_t *d_flag, size_t n, int min_q) {
+    if (n == 0 || c->nbins[tid] == 0) return TDT_OK;
+    CovParams P;
+    P.start = d_start;
+    P.end = d_end;
+    P.mapq = d_mapq;
+    P.flag = d_flag;
+    P.n = n;
+    P.acc = c->d_acc + c->off[tid];
+    P.nbins = (int)c->nbins[tid];
+    P.bin_size = c->bin_size;
+    P.magic = c->magic;
+    P.shift = c->shift;
+    P.min_q = min_q;
+    P.lut_main = c->d_lut_main;
+    P.lut_end = c->d_lut_end + (size_t)tid * ((size_t)c->bin_size + 1);
+    P.one = 1ull << c->S;
+    P.status = c->d_status;
+    P.kept = c->d_kept;
+    P.aligned = (((uintptr_t)d_start | (uintptr_t)d_end) & 15) == 0 && ((uintptr_t)d_mapq & 3) == 0 &&
+                ((uintptr_t)d_flag & 7) == 0;
+    const unsigned grid = (unsigned)((n + COV_READS_PER_BLOCK - 1) / COV_READS_PER_BLOCK);
+    const bool lds_lut = c->bin_size + 1 <= COV_LUT_LDS_MAX;
+    const size_t lds = 16 + (size_t)COV_WIN * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0);
+    if (lds_lut)
+        hipLaunchKernelGGL(cov_accumulate<true>, dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else
+        hipLaunchKernelGGL(cov_accumulate<false>, dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_push_device(tdt_cov *c, int tid, const int32_t *d_start, const int32_t *d_end,
+                                   const uint8_t *d_mapq, const uint16_t *d_flag, size_t n, int min_q) {
+    if (!c || tid < 0 || tid >= c->n_contigs || (n && (!d_start || !d_end || !d_mapq || !d_flag))) {
+        tdt_set_error("tdt_cov_push_device: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    return cov_launch(c, tid, d_start, d_end, d_mapq, d_flag, n, min_q);
+}
+
+extern "C" int tdt_cov_push(tdt_cov *c, int tid, const int32_t *start, const int32_t *end, const uint8_t *mapq,
+                            const uint16_t *flag, size_t n, int min_q) {
+    if (!c || tid < 0 || tid >= c->n_contigs || (n && (!start || !end || !mapq || !flag))) {
+        tdt_set_error("tdt_cov_push: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    const size_t chunk = COV_PUSH_CHUNK;
+    const size_t slot_bytes = chunk * 12;  // 4+4+2+1 B/read, each array 16-byte aligned (chunk % 16 == 0) -> 11 B + slack
+    for (size_t o = 0; o < n; o += chunk) {
+        const size_t m = n - o < chunk ? n - o : chunk;
+        const int s = c->next_slot;
+        c->next_slot ^= 1;
+        if (!c->h_stage[s]) {
+            TDT_HIP(hipHostMalloc(&c->h_stage[s], slot_bytes, hipHostMallocDefault));
+            TDT_HIP(hipMalloc(&c->d_stage[s], slot_bytes));
+        }
+        if (c->slot_used[s]) TDT_HIP(hipEventSynchronize(c->slot_ev[s]));
+        char *h = (char *)c->h_stage[s];
+        char *d = (char *)c->d_stage[s];
+        const size_t o_end = chunk * 4, o_flag = chunk * 8, o_mapq = chunk * 10;
+        memcpy(h, start + o, m * 4);
+        memcpy(h + o_end, end + o, m * 4);
+        memcpy(h + o_flag, flag + o, m * 2);
+        memcpy(h + o_mapq, mapq + o, m);
+        if (m == chunk) {
+            TDT_HIP(hipMemcpyAsync(d, h, chunk * 11, hipMemcpyHostToDevice, c->ctx->stream));
+        } else {
+            TDT_HIP(hipMemcpyAsync(d, h, m * 4, hipMemcpyHostToDevice, c->ctx->stream));
+            TDT_HIP(hipMemcpyAsync(d + o_end, h + o_end, m * 4, hipMemcpyHostToDevice, c->ctx->stream));
+            TDT_HIP(hipMemcpyAsync(d + o_flag, h + o_flag, m * 2, hipMemcpyHostToDevice, c->ctx->stream));
+            TDT_HIP(hipMemcpyAsync(d + o_mapq, h + o_mapq, m, hipMemcpyHostToDevice, c->ctx->stream));
+        }
+        int rc = cov_launch(c, tid, (const int32_t *)d, (const int32_t *)(d + o_end), (const uint8_t *)(d + o_mapq),
+                            (const uint16_t *)(d + o_flag), m, min_q);
+        if (rc) return rc;
+        TDT_HIP(hipEventRecord(c->slot_ev[s], c->ctx->stream));
+        c->slot_used[s] = 1;
+    }
+    return TDT_OK;
+}
+
+static int cov_status(tdt_cov *c) {
+    int st[4];
+    TDT_HIP(hipMemcpyAsync(st, c->d_status, 16, hipMemcpyDeviceToHost, c->ctx->stream));
+    TDT_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (st[0] & 1) {
+        tdt_set_error("coverage: a read maps outside its contig's bins (reference raises IndexError) or has end <= start");
+        return TDT_E_RANGE;
+    }
+    if (st[0] & 2) {
+        tdt_set_error("coverage: a bin exceeded 2^53 fixed-point units; the float64 sum is no longer exact");
+        return TDT_E_INEXACT;
+    }
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_finish_device(tdt_cov *c, int tid, double *d_out) {
+    if (!c || tid < 0 || tid >= c->n_contigs || (!d_out && c->nbins[tid])) {
+        tdt_set_error("tdt_cov_finish_device: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    const long long nb = c->nbins[tid];
+    if (nb) {
+        const int threads = 256;
+        long long blocks = (nb + threads - 1) / threads;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(cov_finalize, dim3((unsigned)blocks), dim3(threads), 0, c->ctx->stream,
+                           (const long long *)(c->d_acc + c->off[tid]), d_out, nb, ldexp(1.0, -c->S), c->d_status);
+        TDT_CHECK_LAUNCH();
+    }
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_finish(tdt_cov *c, int tid, double *out) {
+    if (!c || tid < 0 || tid >= c->n_contigs || (!out && c->nbins[tid])) {
+        tdt_set_error("tdt_cov_finish: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    const size_t nb = (size_t)c->nbins[tid];
+    void *d_out = nullptr;
+    int rc = tdt_scratch(c->ctx, 0, (nb ? nb : 1) * 8, &d_out);
+    if (rc) return rc;
+    rc = tdt_cov_finish_device(c, tid, (double *)d_out);
+    if (rc) return rc;
+    if (nb) TDT_HIP(hipMemcpyAsync(out, d_out, nb * 8, hipMemcpyDeviceToHost, c->ctx->stream));
+    return cov_status(c);
+}
+
+extern "C" int tdt_cov_kept(tdt_cov *c, int64_t *kept) {
+    if (!c || !kept) return TDT_E_ARG;
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    unsigned long long k = 0;
+    TDT_HIP(hipMemcpyAsync(&k, c->d_kept, 8, hipMemcpyDeviceToHost, c->ctx->stream));
+    TDT_HIP(hipStreamSynchronize(c->ctx->stream));
+    *kept = (int64_t)k;
+    return TDT_OK;
+}

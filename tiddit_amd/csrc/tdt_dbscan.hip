@@ -1,0 +1,606 @@
+// Signal clustering ("DBSCAN") for gfx950 (MI355X).
+//
+// The reference's DBSCAN.py is two 1-D sliding-window passes driven by a sequential run-labelling
+// state machine (x_coordinate_clustering DBSCAN.py:33-64, y_coordinate_clustering :66-123).  Its
+// closed form is data parallel:
+//   x pass   p[i]  = (i <= n-m) && max_{j in (i, min(i+m,n-1)]} |x_j - x_i| < eps
+//            runs  = maximal stretches of consecutive true p, numbered 0,1,.. (an inclusive scan of run starts)
+//            lab[k]= id of the run holding j* = the largest j <= k with p[j], if k - j* <= m-1, else -1
+//   y pass   every x-cluster is a contiguous index range; its members are stably sorted by y, the
+//            same run labelling is applied with window m-1, sub-run 1 keeps the x id and sub-run
+//            s > 1 becomes (R-1) + #extra sub-runs of earlier x-clusters + (s-1).
+// All of it is integer compares, prefix sums and a segmented sort: HBM/latency-bound, no MFMA.
+// Several independent (chrA,chrB) buckets are processed by the same launches (ids restart per bucket).
+#include "tdt_common.h"
+
+#include <algorithm>
+#include <cmath>
+
+#define DB_THREADS 256
+#define DB_ITEMS 4
+#define DB_TILE (DB_THREADS * DB_ITEMS)
+#define DB_SMALL 128  // x-clusters up to this many members are y-sorted by in-kernel rank counting
+
+int tdt_segsort_u64(tdt_ctx *ctx, int slot, const unsigned long long *d_in, unsigned long long *d_out, size_t n,
+                    unsigned nseg, const unsigned *d_begin, const unsigned *d_end);
+
+// largest b in [0, nb) with boff[b] <= i
+__device__ __forceinline__ int db_bucket(const int *__restrict__ boff, int nb, int i) {
+    if (nb == 1) return 0;
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (boff[mid] <= i) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ unsigned db_absdiff(unsigned a, unsigned b) { return a > b ? a - b : b - a; }
+
+// ---------------------------------------------------------------------------------------- scan
+// In-place inclusive scan of a u32 array: reduce tiles -> scan the tile sums (one block) -> apply.
+__global__ __launch_bounds__(DB_THREADS) void scan_reduce(const unsigned *__restrict__ v, int n, unsigned *__restrict__ tsum) {
+    __shared__ unsigned red[DB_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.x * DB_TILE + tid * DB_ITEMS;
+    unsigned s = 0;
+    if (i0 + DB_ITEMS <= n) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(v + i0);
+        s = q.x + q.y + q.z + q.w;
+    } else {
+        for (int j = 0; j < DB_ITEMS; j++)
+            if (i0 + j < n) s += v[i0 + j];
+    }
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) tsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of tsum[0..nt) in place, single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void scan_tiles(unsigned *tsum, int nt) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nt; base += 1024) {
+        const int i = base + tid;
+        const unsigned v = i < nt ? tsum[i] : 0;
+        unsigned s = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(s, d);
+            if (lane >= d) s += t;
+        }
+        if (lane == 63) wsum[wave] = s;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const unsigned carry = carry_s;
+        if (i < nt) tsum[i] = carry + woff + s - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + s;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(DB_THREADS) void scan_apply(unsigned *__restrict__ v, int n, const unsigned *__restrict__ tsum) {
+    __shared__ unsigned wsum[DB_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * DB_TILE + tid * DB_ITEMS;
+    unsigned a[DB_ITEMS];
+    const bool full = i0 + DB_ITEMS <= n;
+    if (full) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(v + i0);
+        a[0] = q.x; a[1] = q.y; a[2] = q.z; a[3] = q.w;
+    } else {
+        for (int j = 0; j < DB_ITEMS; j++) a[j] = i0 + j < n ? v[i0 + j] : 0;
+    }
+    a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
+    unsigned s = a[3];
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(s, d);
+        if (lane >= d) s += t;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    unsigned off = tsum[blockIdx.x] + s - a[3];
+    for (int w = 0; w < wave; w++) off += wsum[w];
+    if (full) {
+        *reinterpret_cast<uint4 *>(v + i0) = make_uint4(a[0] + off, a[1] + off, a[2] + off, a[3] + off);
+    } else {
+        for (int j = 0; j < DB_ITEMS; j++)
+            if (i0 + j < n) v[i0 + j] = a[j] + off;
+    }
+}
+
+// -------------------------------------------------------------------------------------- x pass
+// p[i] (DBSCAN.py:41-51) and run-start flags (the `cluster` boolean of :52-62)
+__global__ __launch_bounds__(DB_THREADS) void dbx_flags(const unsigned *__restrict__ x, int n, const int *__restrict__ boff,
+                                                        int nb, unsigned long long eps, int m,
+                                                        unsigned char *__restrict__ px, unsigned *__restrict__ sx) {
+    const int i0 = (blockIdx.x * DB_THREADS + threadIdx.x) * DB_ITEMS;
+    if (i0 >= n) return;
+    int b = db_bucket(boff, nb, i0 > 0 ? i0 - 1 : 0);
+    bool prev = false;
+    for (int i = (i0 > 0 ? i0 - 1 : 0); i < i0 + DB_ITEMS && i < n; i++) {
+        while (i >= boff[b + 1]) b++;
+        const int bend = boff[b + 1];
+        bool p = false;
+        if (i + m <= bend) {  // the loop `for i in range(0, len(data)-m+1)` (:39)
+            const int hi = min(i + m, bend - 1);  // data[i+1:i+m+1] truncates at the array end (:43)
+            const unsigned xi = x[i];
+            unsigned maxd = 0;
+            for (int j = i + 1; j <= hi; j++) maxd = max(maxd, db_absdiff(x[j], xi));
+            p = (unsigned long long)maxd < eps;
+        }
+        if (i >= i0) {
+            px[i] = p;
+            sx[i] = (p && !prev) ? 1u : 0u;
+        }
+        prev = p;
+    }
+}
+
+// lab[k] = (scan of run starts at j*) - 1; also the number of runs before every bucket
+__global__ __launch_bounds__(DB_THREADS) void dbx_labels(const unsigned char *__restrict__ px, const unsigned *__restrict__ sx_incl,
+                                                         int n, int m, const int *__restrict__ boff, int nb,
+                                                         int *__restrict__ xlab, unsigned *__restrict__ runbase) {
+    const int k = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (k >= n) return;
+    int lab = -1;
+    for (int j = k; j >= 0 && j > k - m; j--) {
+        if (px[j]) {
+            lab = (int)sx_incl[j] - 1;
+            break;
+        }
+    }
+    xlab[k] = lab;
+    const int b = db_bucket(boff, nb, k);
+    if (k + 1 == boff[b + 1]) {
+        const unsigned s = sx_incl[k];
+        for (int bb = b + 1; bb <= nb && boff[bb] == k + 1; bb++) runbase[bb] = s;
+    }
+}
+
+__global__ __launch_bounds__(DB_THREADS) void db_segments(const int *__restrict__ xlab, int n, int *__restrict__ seg_start,
+                                                          int *__restrict__ seg_end) {
+    const int k = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (k >= n) return;
+    const int l = xlab[k];
+    if (l < 0) return;
+    if (k == 0 || xlab[k - 1] != l) seg_start[l] = k;
+    if (k == n - 1 || xlab[k + 1] != l) seg_end[l] = k + 1;
+}
+
+// x-only result (x_coordinate_clustering's return value)
+__global__ __launch_bounds__(DB_THREADS) void dbx_final(const int *__restrict__ xlab, int n, const int *__restrict__ boff, int nb,
+                                                        const unsigned *__restrict__ runbase, double *__restrict__ labels,
+                                                        long long *__restrict__ last_id) {
+    const int k = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (k < nb && last_id) last_id[k] = (long long)(runbase[k + 1] - runbase[k]) - 1;
+    if (k >= n) return;
+    const int l = xlab[k];
+    labels[k] = l < 0 ? -1.0 : (double)(l - (int)runbase[db_bucket(boff, nb, k)]);
+}
+
+// -------------------------------------------------------------------------------------- y pass
+// stable sort by y inside every x-cluster (DBSCAN.py:76-81): rank counting for small clusters,
+// unique 64-bit keys (y << 32 | index) handed to the segmented radix sort for large ones
+__global__ __launch_bounds__(DB_THREADS) void dby_rank(const int *__restrict__ xlab, const unsigned *__restrict__ y, int n,
+                                                       const int *__restrict__ seg_start, const int *__restrict__ seg_end,
+                                                       unsigned *__restrict__ ys, unsigned *__restrict__ ord,
+                                                       unsigned long long *__restrict__ key64, unsigned *__restrict__ lbeg,
+                                                       unsigned *__restrict__ lend, unsigned *__restrict__ nlarge) {
+    const int k = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (k >= n) return;
+    const int l = xlab[k];
+    if (l < 0) {
+        ys[k] = 0;
+        ord[k] = k;
+        return;
+    }
+    const int s0 = seg_start[l], s1 = seg_end[l];
+    const unsigned yk = y[k];
+    if (s1 - s0 <= DB_SMALL) {
+        int rank = 0;
+        for (int j = s0; j < s1; j++) {
+            const unsigned yj = y[j];
+            rank += (yj < yk) || (yj == yk && j < k);
+        }
+        ys[s0 + rank] = yk;
+        ord[s0 + rank] = k;
+    } else {
+        key64[k] = ((unsigned long long)yk << 32) | (unsigned)k;
+        if (k == s0) {
+            const unsigned idx = atomicAdd(nlarge, 1u);
+            lbeg[idx] = s0;
+            lend[idx] = s1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(DB_THREADS) void dby_unpack_large(const int *__restrict__ xlab, int n, const int *__restrict__ seg_start,
+                                                               const int *__restrict__ seg_end,
+                                                               const unsigned long long *__restrict__ ksorted,
+                                                               unsigned *__restrict__ ys, unsigned *__restrict__ ord) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int l = xlab[i];
+    if (l < 0) return;
+    if (seg_end[l] - seg_start[l] <= DB_SMALL) return;
+    const unsigned long long key = ksorted[i];
+    ys[i] = (unsigned)(key >> 32);
+    ord[i] = (unsigned)key;
+}
+
+// window test on the sorted y of each x-cluster (DBSCAN.py:90-99) and sub-run starts (:101-110)
+__global__ __launch_bounds__(DB_THREADS) void dby_flags(const int *__restrict__ xlab, int n, const int *__restrict__ seg_start,
+                                                        const int *__restrict__ seg_end, const unsigned *__restrict__ ys,
+                                                        unsigned long long eps, int m, unsigned char *__restrict__ py,
+                                                        unsigned *__restrict__ sy) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int l = xlab[i];
+    bool p = false, prev = false;
+    if (l >= 0) {
+        const int s0 = seg_start[l], s1 = seg_end[l];
+        if (i + m <= s1) p = (unsigned long long)(ys[i + m - 1] - ys[i]) < eps;  // next = y[i+1:i+m], sorted => max is the last
+        if (i > s0 && (i - 1) + m <= s1) prev = (unsigned long long)(ys[i + m - 2] - ys[i - 1]) < eps;
+    }
+    py[i] = p;
+    sy[i] = (p && !prev) ? 1u : 0u;
+}
+
+// extra sub-runs of every x-cluster, stored at the cluster's first position (`cluster_id += sub_cluster_id-1`, :121-122)
+__global__ __launch_bounds__(DB_THREADS) void dby_extras(const int *__restrict__ xlab, int n, const int *__restrict__ seg_start,
+                                                         const int *__restrict__ seg_end, const unsigned *__restrict__ sy_incl,
+                                                         unsigned *__restrict__ ex) {
+    const int k = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (k >= n) return;
+    const int l = xlab[k];
+    unsigned e = 0;
+    if (l >= 0 && seg_start[l] == k) {
+        const unsigned sr = sy_incl[seg_end[l] - 1] - (k > 0 ? sy_incl[k - 1] : 0u);
+        e = sr > 1 ? sr - 1 : 0;
+    }
+    ex[k] = e;
+}
+
+// relabel (DBSCAN.py:112-119) and scatter back to the input order
+__global__ __launch_bounds__(DB_THREADS) void dby_final(const int *__restrict__ xlab, int n, int m, const int *__restrict__ seg_start,
+                                                        const unsigned char *__restrict__ py, const unsigned *__restrict__ sy_incl,
+                                                        const unsigned *__restrict__ ex_incl, const unsigned *__restrict__ ord,
+                                                        const int *__restrict__ boff, int nb, const unsigned *__restrict__ runbase,
+                                                        double *__restrict__ labels, long long *__restrict__ last_id) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i < nb && last_id) {
+        const int b0 = boff[i], b1 = boff[i + 1];
+        const long long extras = (long long)(b1 > 0 ? ex_incl[b1 - 1] : 0u) - (long long)(b0 > 0 ? ex_incl[b0 - 1] : 0u);
+        last_id[i] = (long long)(runbase[i + 1] - runbase[i]) - 1 + extras;
+    }
+    if (i >= n) return;
+    const int l = xlab[i];
+    if (l < 0) {
+        labels[i] = -1.0;  // ord[i] == i for noise
+        return;
+    }
+    double lab = -1.0;
+    for (int j = i; j >= 0 && j > i - m; j--) {
+        if (py[j]) {
+            const int s0 = seg_start[l];
+            const unsigned s = sy_incl[j] - (s0 > 0 ? sy_incl[s0 - 1] : 0u);
+            const int b = db_bucket(boff, nb, i);
+            const unsigned rb = runbase[b];
+            if (s == 1) {
+                lab = (double)((unsigned)l - rb);
+            } else {
+                const int b0 = boff[b];
+                const unsigned xoff = (s0 > 0 ? ex_incl[s0 - 1] : 0u) - (b0 > 0 ? ex_incl[b0 - 1] : 0u);
+                lab = (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)xoff + (long long)(s - 1));
+            }
+            break;
+        }
+    }
+    labels[ord[i]] = lab;
+}
+
+// ------------------------------------------------------------------------------------------ host
+static inline size_t db_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int db_scan_inplace(tdt_ctx *ctx, unsigned *d_v, int n, unsigned *d_tsum) {
+    const int nt = (n + DB_TILE - 1) / DB_TILE;
+    hipLaunchKernelGGL(scan_reduce, dim3(nt), dim3(DB_THREADS), 0, ctx->stream, (const unsigned *)d_v, n, d_tsum);
+    hipLaunchKernelGGL(scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, d_tsum, nt);
+    hipLaunchKernelGGL(scan_apply, dim3(nt), dim3(DB_THREADS), 0, ctx->stream, d_v, n, (const unsigned *)d_tsum);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
+extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, size_t n_, const int64_t *bucket_off,
+                                 int nb, uint64_t eps, int m, int mode, double *d_labels, int64_t *d_last_id) {
+    if (!ctx || nb < 1 || !bucket_off || m < 2 || (mode != 0 && mode != 1)) {
+        tdt_set_error("tdt_dbscan_device: bad argument (m must be >= 2: the reference's max() of an empty window raises)");
+        return TDT_E_ARG;
+    }
+    if (n_ >= 0x7fffffffull) {
+        tdt_set_error("tdt_dbscan_device: n too large");
+        return TDT_E_UNSUPPORTED;
+    }
+    const int n = (int)n_;
+    if (bucket_off[0] != 0 || bucket_off[nb] != (int64_t)n) {
+        tdt_set_error("tdt_dbscan_device: bucket_off must start at 0 and end at n");
+        return TDT_E_ARG;
+    }
+    for (int b = 0; b < nb; b++)
+        if (bucket_off[b + 1] < bucket_off[b]) {
+            tdt_set_error("tdt_dbscan_device: bucket_off must be non-decreasing");
+            return TDT_E_ARG;
+        }
+    TDT_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // small control block first (needed even for n == 0)
+    const size_t sz_boff = db_align((size_t)(nb + 1) * 4);
+    const size_t sz_rb = db_align((size_t)(nb + 1) * 4);
+    const int nt = n ? (n + DB_TILE - 1) / DB_TILE : 1;
+    const size_t N = (size_t)(n ? n : 1);
+    const size_t nlarge_cap = N / DB_SMALL + 1;
+    size_t total = sz_boff + sz_rb + db_align(256) /*counters*/ + db_align((size_t)nt * 4) +
+                   2 * db_align(N) /*px,py*/ + 3 * db_align(N * 4) /*sx,sy,ex*/ + 3 * db_align(N * 4) /*xlab,seg_start,seg_end*/ +
+                   2 * db_align(N * 4) /*ys,ord*/ + 2 * db_align(N * 8) /*key64 in/out*/ + 2 * db_align(nlarge_cap * 4);
+    void *base = nullptr;
+    int rc = tdt_scratch(ctx, 3, total, &base);
+    if (rc) return rc;
+    char *p = (char *)base;
+    auto carve = [&](size_t bytes) {
+        void *r = p;
+        p += db_align(bytes);
+        return r;
+    };
+    int *d_boff = (int *)carve((size_t)(nb + 1) * 4);
+    unsigned *d_runbase = (unsigned *)carve((size_t)(nb + 1) * 4);
+    unsigned *d_cnt = (unsigned *)carve(256);
+    unsigned *d_tsum = (unsigned *)carve((size_t)nt * 4);
+    unsigned char *d_px = (unsigned char *)carve(N);
+    unsigned char *d_py = (unsigned char *)carve(N);
+    unsigned *d_sx = (unsigned *)carve(N * 4);
+    unsigned *d_sy = (unsigned *)carve(N * 4);
+    unsigned *d_ex = (unsigned *)carve(N * 4);
+    int *d_xlab = (int *)carve(N * 4);
+    int *d_seg0 = (int *)carve(N * 4);
+    int *d_seg1 = (int *)carve(N * 4);
+    unsigned *d_ys = (unsigned *)carve(N * 4);
+    unsigned *d_ord = (unsigned *)carve(N * 4);
+    unsigned long long *d_key = (unsigned long long *)carve(N * 8);
+    unsigned long long *d_ksorted = (unsigned long long *)carve(N * 8);
+    unsigned *d_lbeg = (unsigned *)carve(nlarge_cap * 4);
+    unsigned *d_lend = (unsigned *)carve(nlarge_cap * 4);
+
+    // bucket offsets: stage through pinned memory so the copy is truly asynchronous
+    void *h_stage = nullptr;
+    rc = tdt_pinned(ctx, 0, (size_t)(nb + 1) * 4 + 64, &h_stage);
+    if (rc) return rc;
+    TDT_HIP(hipStreamSynchronize(st));  // previous call may still be reading the pinned block
+    int *h_boff = (int *)h_stage;
+    for (int b = 0; b <= nb; b++) h_boff[b] = (int)bucket_off[b];
+    TDT_HIP(hipMemcpyAsync(d_boff, h_boff, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
+    TDT_HIP(hipMemsetAsync(d_runbase, 0, (size_t)(nb + 1) * 4, st));
+    TDT_HIP(hipMemsetAsync(d_cnt, 0, 256, st));
+
+    const int blocks1 = n ? (n + DB_THREADS - 1) / DB_THREADS : 1;
+    const int blocks4 = n ? (n + DB_TILE - 1) / DB_TILE : 1;
+    const int blocks_nb = (std::max(n, nb) + DB_THREADS - 1) / DB_THREADS;
+    if (n == 0) {
+        // empty input: every bucket reports cluster_id -1
+        hipLaunchKernelGGL(dbx_final, dim3(blocks_nb), dim3(DB_THREADS), 0, st, (const int *)d_xlab, 0, (const int *)d_boff, nb,
+                           (const unsigned *)d_runbase, d_labels, (long long *)d_last_id);
+        TDT_CHECK_LAUNCH();
+        return TDT_OK;
+    }
+    hipLaunchKernelGGL(dbx_flags, dim3(blocks4), dim3(DB_THREADS), 0, st, d_x, n, (const int *)d_boff, nb,
+                       (unsigned long long)eps, m, d_px, d_sx);
+    TDT_CHECK_LAUNCH();
+    rc = db_scan_inplace(ctx, d_sx, n, d_tsum);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dbx_labels, dim3(blocks1), dim3(DB_THREADS), 0, st, (const unsigned char *)d_px, (const unsigned *)d_sx, n, m,
+                       (const int *)d_boff, nb, d_xlab, d_runbase);
+    TDT_CHECK_LAUNCH();
+    if (mode == 1) {
+        hipLaunchKernelGGL(dbx_final, dim3(blocks_nb), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_boff, nb,
+                           (const unsigned *)d_runbase, d_labels, (long long *)d_last_id);
+        TDT_CHECK_LAUNCH();
+        return TDT_OK;
+    }
+    hipLaunchKernelGGL(db_segments, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, d_seg0, d_seg1);
+    hipLaunchKernelGGL(dby_rank, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, d_y, n, (const int *)d_seg0,
+                       (const int *)d_seg1, d_ys, d_ord, d_key, d_lbeg, d_lend, d_cnt);
+    TDT_CHECK_LAUNCH();
+    // x-clusters larger than DB_SMALL: one 4-byte readback decides whether the segmented sort runs
+    unsigned nlarge = 0;
+    TDT_HIP(hipMemcpyAsync(&nlarge, d_cnt, 4, hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipStreamSynchronize(st));
+    if (nlarge) {
+        rc = tdt_segsort_u64(ctx, 4, d_key, d_ksorted, (size_t)n, nlarge, d_lbeg, d_lend);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dby_unpack_large, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
+                           (const int *)d_seg1, (const unsigned long long *)d_ksorted, d_ys, d_ord);
+        TDT_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(dby_flags, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
+                       (const int *)d_seg1, (const unsigned *)d_ys, (unsigned long long)eps, m, d_py, d_sy);
+    TDT_CHECK_LAUNCH();
+    rc = db_scan_inplace(ctx, d_sy, n, d_tsum);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dby_extras, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
+                       (const int *)d_seg1, (const unsigned *)d_sy, d_ex);
+    TDT_CHECK_LAUNCH();
+    rc = db_scan_inplace(ctx, d_ex, n, d_tsum);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dby_final, dim3(blocks_nb), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, m, (const int *)d_seg0,
+                       (const unsigned char *)d_py, (const unsigned *)d_sy, (const unsigned *)d_ex, (const unsigned *)d_ord,
+                       (const int *)d_boff, nb, (const unsigned *)d_runbase, d_labels, (long long *)d_last_id);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
+static uint64_t db_eps_u64(double eps) {
+    // numpy: int64 distance < python number  <=>  d < ceil(eps) for integer d >= 0
+    if (!(eps > 0)) return 0;  // also NaN: nothing is ever < NaN
+    if (eps >= 8589934592.0) return 1ull << 33;
+    return (uint64_t)ceil(eps);
+}
+
+extern "C" int tdt_dbscan(tdt_ctx *ctx, const int64_t *data, size_t n, size_t stride, double eps, int m, int mode,
+                          double *labels, int64_t *last_id) {
+    if (!ctx || (n && (!data || !labels)) || stride < 1 || (mode == 0 && stride < 2)) {
+        tdt_set_error("tdt_dbscan: bad argument");
+        return TDT_E_ARG;
+    }
+    if (m < 2) {
+        tdt_set_error("tdt_dbscan: m must be >= 2 (the reference raises ValueError: max() arg is an empty sequence)");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(ctx->device));
+    if (n == 0) {
+        if (last_id) *last_id = -1;
+        return TDT_OK;
+    }
+    // device coordinates are uint32 offsets from the column minimum
+    int64_t xmin = data[0], xmax = data[0], ymin = 0, ymax = 0;
+    if (stride >= 2) ymin = ymax = data[1];
+    for (size_t i = 0; i < n; i++) {
+        const int64_t xv = data[i * stride];
+        xmin = xv < xmin ? xv : xmin;
+        xmax = xv > xmax ? xv : xmax;
+        if (stride >= 2) {
+            const int64_t yv = data[i * stride + 1];
+            ymin = yv < ymin ? yv : ymin;
+            ymax = yv > ymax ? yv : ymax;
+        }
+    }
+    if ((unsigned __int128)((__int128)xmax - xmin) > 0xfffffffeull || (unsigned __int128)((__int128)ymax - ymin) > 0xfffffffeull) {
+        tdt_set_error("tdt_dbscan: coordinate span >= 2^32 is outside the device path's domain");
+        return TDT_E_UNSUPPORTED;
+    }
+    void *h = nullptr, *d = nullptr;
+    int rc = tdt_pinned(ctx, 1, n * 8 + n * 8 + 64, &h);
+    if (rc) return rc;
+    rc = tdt_scratch(ctx, 5, n * 8 + n * 8 + 64, &d);
+    if (rc) return rc;
+    uint32_t *hx = (uint32_t *)h, *hy = hx + n;
+    for (size_t i = 0; i < n; i++) {
+        hx[i] = (uint32_t)(data[i * stride] - xmin);
+        hy[i] = stride >= 2 ? (uint32_t)(data[i * stride + 1] - ymin) : 0u;
+    }
+    uint32_t *dx = (uint32_t *)d, *dy = dx + n;
+    TDT_HIP(hipMemcpyAsync(dx, hx, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int64_t boff[2] = {0, (int64_t)n};
+    void *dlast = nullptr;
+    rc = tdt_scratch(ctx, 6, n * 8 + 64, &dlast);
+    if (rc) return rc;
+    double *dl = (double *)dlast;
+    long long *dlid = (long long *)((char *)dlast + n * 8);
+    rc = tdt_dbscan_device(ctx, dx, dy, n, boff, 1, db_eps_u64(eps), m, mode, dl, (int64_t *)dlid);
+    if (rc) return rc;
+    TDT_HIP(hipStreamSynchronize(ctx->stream));
+    long long lid = -1;
+    TDT_HIP(hipMemcpy(labels, dl, n * 8, hipMemcpyDeviceToHost));
+    TDT_HIP(hipMemcpy(&lid, dlid, 8, hipMemcpyDeviceToHost));
+    if (last_id) *last_id = lid;
+    return TDT_OK;
+}
+
+// -------------------------------------------------------------------- sort + cluster in one call
+__global__ __launch_bounds__(DB_THREADS) void sd_make_keys(const unsigned *__restrict__ x, int n, const int *__restrict__ boff, int nb,
+                                                           unsigned long long *__restrict__ key) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int b = db_bucket(boff, nb, i);
+    key[i] = ((unsigned long long)x[i] << 32) | (unsigned)(i - boff[b]);  // unique inside the bucket => stable order
+}
+
+__global__ __launch_bounds__(DB_THREADS) void sd_unpack(const unsigned long long *__restrict__ ksorted, const unsigned *__restrict__ y,
+                                                        int n, const int *__restrict__ boff, int nb, unsigned *__restrict__ xs,
+                                                        unsigned *__restrict__ ysrt, unsigned *__restrict__ perm) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const int b = db_bucket(boff, nb, i);
+    const unsigned long long k = ksorted[i];
+    const unsigned src = (unsigned)boff[b] + (unsigned)k;
+    xs[i] = (unsigned)(k >> 32);
+    ysrt[i] = y[src];
+    perm[i] = src;
+}
+
+extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
+                               double eps, int m, uint32_t *perm_out, double *labels_out) {
+    if (!ctx || nb < 1 || !bucket_off || (n && (!posA || !posB || !perm_out || !labels_out))) {
+        tdt_set_error("tdt_sort_dbscan: bad argument");
+        return TDT_E_ARG;
+    }
+    if (m < 2) {
+        tdt_set_error("tdt_sort_dbscan: m must be >= 2");
+        return TDT_E_ARG;
+    }
+    if (n >= 0x7fffffffull || bucket_off[0] != 0 || bucket_off[nb] != (int64_t)n) {
+        tdt_set_error("tdt_sort_dbscan: bad bucket offsets / n");
+        return TDT_E_ARG;
+    }
+    if (n == 0) return TDT_OK;
+    TDT_HIP(hipSetDevice(ctx->device));
+    int64_t amin = posA[0], amax = posA[0], bmin = posB[0], bmax = posB[0];
+    for (size_t i = 0; i < n; i++) {
+        amin = std::min(amin, posA[i]);
+        amax = std::max(amax, posA[i]);
+        bmin = std::min(bmin, posB[i]);
+        bmax = std::max(bmax, posB[i]);
+    }
+    if ((unsigned __int128)((__int128)amax - amin) > 0xfffffffeull || (unsigned __int128)((__int128)bmax - bmin) > 0xfffffffeull) {
+        tdt_set_error("tdt_sort_dbscan: coordinate span >= 2^32 is outside the device path's domain");
+        return TDT_E_UNSUPPORTED;
+    }
+    hipStream_t st = ctx->stream;
+    void *h = nullptr, *d = nullptr;
+    const size_t hb = n * 8 + (size_t)(nb + 1) * 4 + 64;
+    int rc = tdt_pinned(ctx, 1, hb, &h);
+    if (rc) return rc;
+    // device: x,y (in), xs,ys (sorted), perm, keys in/out, labels, boff
+    const size_t szN4 = db_align(n * 4), szN8 = db_align(n * 8);
+    rc = tdt_scratch(ctx, 5, 5 * szN4 + 3 * szN8 + db_align((size_t)(nb + 1) * 4) + 256, &d);
+    if (rc) return rc;
+    char *p = (char *)d;
+    unsigned *dx = (unsigned *)p; p += szN4;
+    unsigned *dy = (unsigned *)p; p += szN4;
+    unsigned *dxs = (unsigned *)p; p += szN4;
+    unsigned *dys = (unsigned *)p; p += szN4;
+    unsigned *dperm = (unsigned *)p; p += szN4;
+    unsigned long long *dk = (unsigned long long *)p; p += szN8;
+    unsigned long long *dks = (unsigned long long *)p; p += szN8;
+    double *dlab = (double *)p; p += szN8;
+    int *dboff = (int *)p;
+    uint32_t *hx = (uint32_t *)h, *hy = hx + n;
+    int *hboff = (int *)(hy + n);
+    for (size_t i = 0; i < n; i++) {
+        hx[i] = (uint32_t)(posA[i] - amin);
+        hy[i] = (uint32_t)(posB[i] - bmin);
+    }
+    for (int b = 0; b <= nb; b++) hboff[b] = (int)bucket_off[b];
+    TDT_HIP(hipMemcpyAsync(dx, hx, n * 4, hipMemcpyHostToDevice, st));
+    TDT_HIP(hipMemcpyAsync(dy, hy, n * 4, hipMemcpyHostToDevice, st));
+    TDT_HIP(hipMemcpyAsync(dboff, hboff, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
+    const int blocks = ((int)n + DB_THREADS - 1) / DB_THREADS;
+    hipLaunchKernelGGL(sd_make_keys, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned *)dx, (int)n, (const int *)dboff, nb, dk);
+    TDT_CHECK_LAUNCH();
+    rc = tdt_segsort_u64(ctx, 4, dk, dks, n, (unsigned)nb, (const unsigned *)dboff, (const unsigned *)dboff + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sd_unpack, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned long long *)dks, (const unsigned *)dy, (int)n,
+                       (const int *)dboff, nb, dxs, dys, dperm);
+    TDT_CHECK_LAUNCH();
+    rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, nullptr);
+    if (rc) return rc;
+    TDT_HIP(hipStreamSynchronize(st));
+    TDT_HIP(hipMemcpy(perm_out, dperm, n * 4, hipMemcpyDeviceToHost));
+    TDT_HIP(hipMemcpy(labels_out, dlab, n * 8, hipMemcpyDeviceToHost));
+    return TDT_OK;
+}

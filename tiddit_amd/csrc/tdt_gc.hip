@@ -1,0 +1,214 @@
+// Binned GC / N-mask histogram for gfx950 (MI355X).
+//
+// Replaces the per-character Python loop of tiddit_gc.binned_gc (tiddit_gc.pyx:14-31):
+//   n = #{N,n}, gc = #{C,c,G,g}, chars = bytes in the bin (the contig's last bin may be short)
+//   out = -1 if n/bin_size > n_cutoff else round_half_even(100*gc/chars)
+// HBM-bound byte stream (1 B/base in, 1 B/bin out).  Small bins (the reference always uses 50):
+//   phase 1  every lane loads 16 coalesced bytes, classifies them with SWAR compares into a 16-bit
+//            GC mask and a 16-bit N mask and drops both into LDS bit arrays (one bit per base);
+//   phase 2  every lane owns one bin = one bit range of the LDS arrays and popcounts it (<= 3 words
+//            for 50-bp bins), then rounds in integers and stores one int8.
+// Bins wider than GC_SMALL_MAX use one workgroup per bin with a wavefront/LDS reduction.
+#include "tdt_common.h"
+
+#define GC_THREADS 256
+#define GC_SMALL_MAX 2048
+
+// 0x80 in every byte of x that is zero (exact, no cross-byte borrow)
+__device__ __forceinline__ unsigned gc_zero_bytes(unsigned x) {
+    return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+}
+// gather the four 0x80 flags of a word into 4 bits (bit i = byte i)
+__device__ __forceinline__ unsigned gc_nibble(unsigned flags) { return (flags * 0x00204081u) >> 28; }
+
+__device__ __forceinline__ void gc_classify_word(unsigned w, unsigned &gc4, unsigned &n4) {
+    const unsigned u = w | 0x20202020u;  // fold case: only 'C'/'c' map to 0x63, 'G'/'g' to 0x67, 'N'/'n' to 0x6e
+    gc4 = gc_nibble(gc_zero_bytes(u ^ 0x63636363u) | gc_zero_bytes(u ^ 0x67676767u));
+    n4 = gc_nibble(gc_zero_bytes(u ^ 0x6e6e6e6eu));
+}
+
+__device__ __forceinline__ void gc_classify16(const uint4 v, unsigned &gc16, unsigned &n16) {
+    unsigned g0, g1, g2, g3, n0, n1, n2, n3;
+    gc_classify_word(v.x, g0, n0);
+    gc_classify_word(v.y, g1, n1);
+    gc_classify_word(v.z, g2, n2);
+    gc_classify_word(v.w, g3, n3);
+    gc16 = g0 | (g1 << 4) | (g2 << 8) | (g3 << 12);
+    n16 = n0 | (n1 << 4) | (n2 << 8) | (n3 << 12);
+}
+
+// 16 bytes at byte offset g (16-aligned); bytes at or beyond len read as 0
+__device__ __forceinline__ uint4 gc_load16(const uint8_t *seq, long long g, long long len) {
+    if (g + 16 <= len) return *reinterpret_cast<const uint4 *>(seq + g);
+    unsigned w[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++)
+        if (g + i < len) w[i >> 2] |= (unsigned)seq[g + i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ signed char gc_result(unsigned long long gc, unsigned long long n, unsigned long long chars,
+                                                 unsigned long long n_min) {
+    if (n >= n_min) return -1;                       // n/bin_size > n_cutoff   (tiddit_gc.pyx:27)
+    const unsigned long long a = 100ull * gc;        // round(100*gc/chars), Python half-to-even (:30)
+    unsigned long long q = a / chars;
+    const unsigned long long r2 = 2ull * (a - q * chars);
+    if (r2 > chars || (r2 == chars && (q & 1ull))) q++;
+    return (signed char)q;
+}
+
+__global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__restrict__ seq, long long len, int bin_size,
+                                                            int tile_bins, long long nbins, unsigned long long n_min,
+                                                            signed char *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned gc_smem[];
+    const int tile_bytes = tile_bins * bin_size;  // multiple of 16
+    const int chunks = tile_bytes >> 4;
+    const int words = (chunks + 1) >> 1;          // u32 words per bit array
+    unsigned *gbits = gc_smem;
+    unsigned *nbits = gc_smem + words;
+    unsigned short *g16 = reinterpret_cast<unsigned short *>(gbits);
+    unsigned short *n16 = reinterpret_cast<unsigned short *>(nbits);
+    const int tid = threadIdx.x;
+
+    for (long long tile = blockIdx.x; tile * tile_bins < nbins; tile += gridDim.x) {
+        const long long T0 = tile * (long long)tile_bytes;
+        for (int c = tid; c < chunks; c += GC_THREADS) {
+            unsigned gm, nm;
+            gc_classify16(gc_load16(seq, T0 + 16ll * c, len), gm, nm);
+            g16[c] = (unsigned short)gm;
+            n16[c] = (unsigned short)nm;
+        }
+        if (tid == 0 && (chunks & 1)) {  // zero the unused upper half of the last word
+            g16[chunks] = 0;
+            n16[chunks] = 0;
+        }
+        __syncthreads();
+        for (int j = tid; j < tile_bins; j += GC_THREADS) {
+            const long long bin = tile * tile_bins + j;
+            if (bin >= nbins) break;
+            const int lo = j * bin_size;
+            long long rem = len - (T0 + lo);
+            const int chars = rem < bin_size ? (int)rem : bin_size;
+            const int hi = lo + chars - 1;  // inclusive last bit
+            const int w0 = lo >> 5, w1 = hi >> 5;
+            unsigned gcnt = 0, ncnt = 0;
+            for (int w = w0; w <= w1; w++) {
+                unsigned m = 0xffffffffu;
+                if (w == w0) m &= 0xffffffffu << (lo & 31);
+                if (w == w1) m &= 0xffffffffu >> (31 - (hi & 31));
+                gcnt += __popc(gbits[w] & m);
+                ncnt += __popc(nbits[w] & m);
+            }
+            out[bin] = gc_result(gcnt, ncnt, (unsigned long long)chars, n_min);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(GC_THREADS) void gc_large_bins(const uint8_t *__restrict__ seq, long long len,
+                                                            long long bin_size, long long nbins, unsigned long long n_min,
+                                                            signed char *__restrict__ out) {
+    __shared__ unsigned long long red[2 * (GC_THREADS / 64)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (long long bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
+        const long long lo = bin * bin_size;
+        const long long hi = min(len, lo + bin_size);  // exclusive
+        const long long a0 = lo & ~15ll;
+        unsigned long long gcnt = 0, ncnt = 0;
+        for (long long g = a0 + 16ll * tid; g < hi; g += 16ll * GC_THREADS) {
+            unsigned gm, nm;
+            gc_classify16(gc_load16(seq, g, len), gm, nm);
+            unsigned valid = 0xffffu;
+            if (g < lo) valid &= 0xffffu << (lo - g);
+            if (g + 16 > hi) valid &= 0xffffu >> (g + 16 - hi);
+            gcnt += __popc(gm & valid);
+            ncnt += __popc(nm & valid);
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            gcnt += __shfl_down(gcnt, d);
+            ncnt += __shfl_down(ncnt, d);
+        }
+        if (lane == 0) {
+            red[2 * wave] = gcnt;
+            red[2 * wave + 1] = ncnt;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long G = 0, N = 0;
+            for (int w = 0; w < GC_THREADS / 64; w++) {
+                G += red[2 * w];
+                N += red[2 * w + 1];
+            }
+            out[bin] = gc_result(G, N, (unsigned long long)(hi - lo), n_min);
+        }
+        __syncthreads();
+    }
+}
+
+// smallest n with (double)n/(double)bin_size > n_cutoff (Python: n/bin_size > n_cutoff, true division)
+static unsigned long long gc_n_min(long long bin_size, double n_cutoff) {
+    long long lo = 0, hi = bin_size + 1;  // answer in [0, bin_size+1]; bin_size+1 == never masked
+    while (lo < hi) {
+        const long long mid = lo + (hi - lo) / 2;
+        if ((double)mid / (double)bin_size > n_cutoff) hi = mid;
+        else lo = mid + 1;
+    }
+    return (unsigned long long)lo;
+}
+
+extern "C" int tdt_gc_bins_device(tdt_ctx *ctx, const uint8_t *d_seq, int64_t len, int bin_size, double n_cutoff,
+                                  int8_t *d_out) {
+    if (!ctx || len < 0 || bin_size <= 0 || (len > 0 && (!d_seq || !d_out))) {
+        tdt_set_error("tdt_gc_bins_device: bad argument");
+        return TDT_E_ARG;
+    }
+    if (((uintptr_t)d_seq & 15) != 0) {
+        tdt_set_error("tdt_gc_bins_device: d_seq must be 16-byte aligned");
+        return TDT_E_ARG;
+    }
+    if (len == 0) return TDT_OK;
+    TDT_HIP(hipSetDevice(ctx->device));
+    const long long nbins = (len + bin_size - 1) / bin_size;
+    const unsigned long long n_min = gc_n_min(bin_size, n_cutoff);
+    if (bin_size <= GC_SMALL_MAX) {
+        int m = 1024 / bin_size;
+        if (m < 1) m = 1;
+        const int tile_bins = 16 * m;
+        const long long tiles = (nbins + tile_bins - 1) / tile_bins;
+        const int chunks = (tile_bins * bin_size) >> 4;
+        const size_t lds = (size_t)((chunks + 1) / 2) * 2 * sizeof(unsigned);
+        long long grid = tiles;
+        const long long cap = (long long)ctx->num_cu * 16;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(gc_small_bins, dim3((unsigned)grid), dim3(GC_THREADS), lds, ctx->stream, d_seq, (long long)len,
+                           bin_size, tile_bins, nbins, n_min, (signed char *)d_out);
+    } else {
+        long long grid = nbins;
+        const long long cap = (long long)ctx->num_cu * 16;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(gc_large_bins, dim3((unsigned)grid), dim3(GC_THREADS), 0, ctx->stream, d_seq, (long long)len,
+                           (long long)bin_size, nbins, n_min, (signed char *)d_out);
+    }
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
+extern "C" int tdt_gc_bins(tdt_ctx *ctx, const uint8_t *seq, int64_t len, int bin_size, double n_cutoff, int8_t *out) {
+    if (!ctx || len < 0 || bin_size <= 0 || (len > 0 && (!seq || !out))) {
+        tdt_set_error("tdt_gc_bins: bad argument");
+        return TDT_E_ARG;
+    }
+    if (len == 0) return TDT_OK;
+    TDT_HIP(hipSetDevice(ctx->device));
+    const size_t nbins = (size_t)((len + bin_size - 1) / bin_size);
+    void *d_seq = nullptr, *d_out = nullptr;
+    int rc = tdt_scratch(ctx, 1, (size_t)len + 16, &d_seq);
+    if (rc) return rc;
+    rc = tdt_scratch(ctx, 2, nbins, &d_out);
+    if (rc) return rc;
+    TDT_HIP(hipMemcpyAsync(d_seq, seq, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    rc = tdt_gc_bins_device(ctx, (const uint8_t *)d_seq, len, bin_size, n_cutoff, (int8_t *)d_out);
+    if (rc) return rc;
+    TDT_HIP(hipMemcpyAsync(out, d_out, nbins, hipMemcpyDeviceToHost, ctx->stream));
+    TDT_HIP(hipStreamSynchronize(ctx->stream));
+    return TDT_OK;
+}

@@ -1,0 +1,72 @@
+"""Minimal indexed FASTA access (the reference uses pysam.FastaFile, tiddit_gc.pyx:7-15).
+
+Reads a whole contig as a uint8 numpy array (newlines stripped with one reshape) from a ``.fai``
+index; builds the index when it is missing (what ``pysam.faidx`` does at __main__.py:95-97)."""
+import os
+
+import numpy as np
+
+
+def build_fai(path):
+    entries = []
+    with open(path, "rb") as f:
+        name = None
+        length = offset = linebases = linewidth = 0
+        pos = 0
+        for line in f:
+            ln = len(line)
+            if line.startswith(b">"):
+                if name is not None:
+                    entries.append((name, length, offset, linebases, linewidth))
+                name = line[1:].split()[0].decode()
+                length = 0
+                offset = pos + ln
+                linebases = linewidth = 0
+            elif name is not None:
+                bases = len(line.rstrip(b"\r\n"))
+                if linebases == 0 and bases:
+                    linebases, linewidth = bases, ln
+                length += bases
+            pos += ln
+        if name is not None:
+            entries.append((name, length, offset, linebases, linewidth))
+    with open(path + ".fai", "w") as out:
+        for e in entries:
+            out.write("%s\t%d\t%d\t%d\t%d\n" % e)
+    return entries
+
+
+class FastaFile:
+    def __init__(self, path):
+        self.path = path
+        if not os.path.isfile(path + ".fai"):
+            build_fai(path)
+        self.index = {}
+        self.references = []
+        for line in open(path + ".fai"):
+            c = line.rstrip("\n").split("\t")
+            self.index[c[0]] = tuple(int(v) for v in c[1:5])
+            self.references.append(c[0])
+
+    def get_reference_length(self, contig):
+        return self.index[contig][0]
+
+    def fetch_array(self, contig):
+        """whole contig -> uint8[length] (bases exactly as in the file, case preserved)"""
+        length, offset, linebases, linewidth = self.index[contig]
+        if length == 0:
+            return np.zeros(0, dtype=np.uint8)
+        nfull = length // linebases
+        tail = length - nfull * linebases
+        nbytes = nfull * linewidth + tail
+        with open(self.path, "rb") as f:
+            f.seek(offset)
+            raw = np.frombuffer(f.read(nbytes), dtype=np.uint8)
+        if linewidth == linebases:
+            return raw[:length].copy()
+        body = raw[:nfull * linewidth].reshape(nfull, linewidth)[:, :linebases].reshape(-1)
+        return np.concatenate([body, raw[nfull * linewidth:nfull * linewidth + tail]])
+
+    def fetch(self, contig, start=0, end=None):
+        a = self.fetch_array(contig)
+        return a[start:end].tobytes().decode()

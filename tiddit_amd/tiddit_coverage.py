@@ -1,0 +1,162 @@
+"""Drop-in for ``tiddit.tiddit_coverage`` (tiddit_coverage.pyx) on the MI355X.
+
+Same entry points as the reference — ``create_coverage`` (:10-21), ``update_coverage`` (:48-74),
+``print_coverage`` (:22-45) — plus the batch forms the per-read loops of ``__main__.py:229-242`` and
+``tiddit_signal.pyx:169-182`` are rewritten onto: ``update_coverage_batch`` and ``CoverageHistogram``.
+Bins are bit-identical to the reference's float64 arrays (see csrc/tdt_coverage.hip).
+"""
+import ctypes
+import math
+
+import numpy
+
+from . import _native
+
+
+def create_coverage(bam_header, bin_size, c="all"):
+    """tiddit_coverage.pyx:10-21 — zeroed float64 bins per contig + the size of each last bin."""
+    coverage_data = {}
+    end_bin_size = {}
+    for contig in bam_header["SQ"]:
+        if c == "all" or contig["SN"] == c:
+            bins = int(math.ceil(contig["LN"] / float(bin_size)))
+            coverage_data[contig["SN"]] = numpy.zeros(bins)
+            end_bin_size[contig["SN"]] = contig["LN"] - (bins - 1) * bin_size
+            if c != "all":
+                return (coverage_data[contig["SN"]], end_bin_size[contig["SN"]])
+    return (coverage_data, end_bin_size)
+
+
+def print_coverage(coverage_data, bam_header, bin_size, file_type, outfile):
+    """tiddit_coverage.pyx:22-45 — bed (note the reference's `+1` bin end and LN on the last row)
+    or fixedStep wig; values are formatted exactly like ``"{}".format(numpy.float64)``."""
+    f = open(outfile, "w", buffering=819200)
+    if file_type == "bed":
+        f.write("#chromosome\tstart\tend\tcoverage\n")
+    elif file_type == "wig":
+        f.write("track type=wiggle_0 name=\"Coverage\" description=\"Per bin average coverage\"\n")
+    for contig in bam_header["SQ"]:
+        name = contig["SN"]
+        values = coverage_data[name]
+        n = len(values)
+        if file_type == "wig":
+            f.write("fixedStep chrom={} start=1 step={}\n".format(name, bin_size))
+            f.write("".join("{}\n".format(v) for v in values))
+        elif file_type == "bed":
+            rows = []
+            for i in range(0, n):
+                bin_end = (i + 1) * bin_size + 1
+                if i == n - 1:
+                    bin_end = contig["LN"]
+                rows.append("{}\t{}\t{}\t{}\n".format(name, 1 + i * bin_size, bin_end, values[i]))
+            f.write("".join(rows))
+    f.close()
+
+
+class CoverageHistogram:
+    """Device-resident binned read-depth histogram over a set of contigs.
+
+    ``push(contig, start, end, mapq, flag, min_q)`` adds a batch of alignment records (0-based
+    start, exclusive end, the read filter of __main__.py:231-235 / tiddit_signal.pyx:171-181 is
+    applied on device); ``finish(contig)`` returns the float64 bins.
+    """
+
+    def __init__(self, contigs, bin_size, ctx=None):
+        """contigs: list of (name, length) or a bam header dict."""
+        if isinstance(contigs, dict):
+            contigs = [(c["SN"], c["LN"]) for c in contigs["SQ"]]
+        self.ctx = ctx or _native.default_context()
+        self.lib = self.ctx.lib
+        self.names = [c[0] for c in contigs]
+        self.lengths = numpy.array([c[1] for c in contigs], dtype=numpy.int64)
+        self.tid = {n: i for i, n in enumerate(self.names)}
+        self.bin_size = int(bin_size)
+        h = ctypes.c_void_p()
+        _native.check(self.lib.tdt_cov_create(self.ctx.handle, _native.ptr(self.lengths), len(self.names), self.bin_size,
+                                              ctypes.byref(h)))
+        self.handle = h
+
+    def nbins(self, contig):
+        nb = ctypes.c_int64()
+        eb = ctypes.c_int()
+        _native.check(self.lib.tdt_cov_nbins(self.handle, self._tid(contig), ctypes.byref(nb), ctypes.byref(eb)))
+        return nb.value, eb.value
+
+    def _tid(self, contig):
+        return contig if isinstance(contig, (int, numpy.integer)) else self.tid[contig]
+
+    def push(self, contig, start, end, mapq, flag, min_q):
+        start = numpy.ascontiguousarray(start, dtype=numpy.int32)
+        end = numpy.ascontiguousarray(end, dtype=numpy.int32)
+        mapq = numpy.ascontiguousarray(mapq, dtype=numpy.uint8)
+        flag = numpy.ascontiguousarray(flag, dtype=numpy.uint16)
+        n = len(start)
+        if not (len(end) == len(mapq) == len(flag) == n):
+            raise ValueError("start/end/mapq/flag must have the same length")
+        _native.check(self.lib.tdt_cov_push(self.handle, self._tid(contig), _native.ptr(start), _native.ptr(end),
+                                            _native.ptr(mapq), _native.ptr(flag), n, int(min_q)))
+
+    def push_device(self, contig, d_start, d_end, d_mapq, d_flag, n, min_q):
+        """Device pointers (ints), e.g. ``tensor.data_ptr()``; asynchronous on the context stream."""
+        _native.check(self.lib.tdt_cov_push_device(self.handle, self._tid(contig), d_start, d_end, d_mapq, d_flag, n, int(min_q)))
+
+    def finish(self, contig):
+        nb, _ = self.nbins(contig)
+        out = numpy.empty(nb, dtype=numpy.float64)
+        _native.check(self.lib.tdt_cov_finish(self.handle, self._tid(contig), _native.ptr(out)))
+        return out
+
+    def finish_device(self, contig, d_out):
+        _native.check(self.lib.tdt_cov_finish_device(self.handle, self._tid(contig), d_out))
+
+    def kept(self):
+        k = ctypes.c_int64()
+        _native.check(self.lib.tdt_cov_kept(self.handle, ctypes.byref(k)))
+        return k.value
+
+    def reset(self):
+        _native.check(self.lib.tdt_cov_reset(self.handle))
+
+    def close(self):
+        if self.handle:
+            self.lib.tdt_cov_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _contig_length(coverage_data, bin_size, end_bin_size):
+    return (len(coverage_data) - 1) * bin_size + end_bin_size if len(coverage_data) else 0
+
+
+def update_coverage_batch(ref_start, ref_end, mapq, flag, min_q, bin_size, coverage_data, end_bin_size):
+    """Batch form of the per-read loop: filter + update_coverage for every record, in place.
+
+    Equivalent to calling the reference's ``update_coverage`` for each kept read in any order
+    (the float64 sum is exact).  Returns ``coverage_data`` like the reference.
+    """
+    LN = _contig_length(coverage_data, bin_size, end_bin_size)
+    h = CoverageHistogram([("c", LN)], bin_size)
+    try:
+        h.push(0, ref_start, ref_end, mapq, flag, min_q)
+        coverage_data += h.finish(0)
+    finally:
+        h.close()
+    return coverage_data
+
+
+def update_coverage(ref_start, ref_end, bin_size, coverage_data, end_bin_size):
+    """tiddit_coverage.pyx:48-74 — one read.  Kept for drop-in compatibility (one device round trip
+    per call: use ``update_coverage_batch`` / ``CoverageHistogram`` in loops).  Raises IndexError where
+    the reference does (bin index outside the array)."""
+    try:
+        return update_coverage_batch(numpy.array([ref_start]), numpy.array([ref_end]), numpy.array([255], dtype=numpy.uint8),
+                                     numpy.array([0], dtype=numpy.uint16), 0, bin_size, coverage_data, end_bin_size)
+    except _native.TdtError as e:
+        if e.code == -3:
+            raise IndexError("index out of bounds for coverage_data") from e
+        raise
