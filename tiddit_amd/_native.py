@@ -2,6 +2,7 @@
 or a missing GPU raises."""
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -58,6 +59,14 @@ def load():
     global _lib
     with _lock:
         if _lib is None:
+            # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP/HSA runtimes in
+            # one process cannot both own the GPU, so when torch is installed it must be loaded first:
+            # libtiddit_hip.so (NEEDED libamdhip64.so.7) then binds to the runtime torch already mapped.
+            if "torch" not in sys.modules and not os.environ.get("TIDDIT_AMD_NO_TORCH"):
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
             if not os.path.exists(SO_PATH):
                 raise ImportError("libtiddit_hip.so is not built (run `python -m tiddit_amd.build`); "
                                   "tiddit_amd has no CPU fallback")
