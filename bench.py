@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the TIDDIT hot path on MI355X (one process per GPU).
+
+A *step* is one pass of the hot path over one batch of synthetic input that is already resident in
+HBM when the timed region starts:
+  * coverage (the JSON line's `value`): BASELINE configs[1] — 3 Gb genome (24 contigs x 125 Mb),
+    30x 150-bp coordinate-sorted alignment stream (600 M reads), 500-bp bins, --cov read filter
+    (q 20): reset accumulators -> 24 cov_accumulate launches -> 24 int64->float64 finalize launches;
+  * clustering (reported under "dbscan"): BASELINE configs[2] — gen_points(5_000_000), one chr pair,
+    e=500 l=3, x pass + y pass (16 launches); with N>1 ranks every rank clusters its own bucket and
+    the label arrays are all-gathered over RCCL.
+Weak scaling: every rank owns a full-size shard (its own sample's stream / bucket).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--contigs", type=int, default=24)
+    ap.add_argument("--contig-len", type=int, default=125_000_000)
+    ap.add_argument("--depth", type=int, default=30)
+    ap.add_argument("--bin", type=int, default=500)
+    ap.add_argument("--min-q", type=int, default=20)
+    ap.add_argument("--dbscan-n", type=int, default=5_000_000)
+    ap.add_argument("--cpu-contigs", type=int, default=4, help="contigs of the stream the CPU baseline (oracle) is timed on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dbscan", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tiddit_amd import _native, dist as tdist, synth, tiddit_coverage  # noqa: F401
+    ctx = _native.default_context(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ---------------------------------------------------------------- coverage: data resident in HBM
+    C, L, z = args.contigs, args.contig_len, args.bin
+    reads = []
+    with torch.cuda.stream(stream):
+        for c in range(C):
+            reads.append(synth.gen_reads_device(L, args.depth, dev, seed=synth.SEED + 1000 * rank + c))
+    torch.cuda.synchronize()
+    n_reads = [int(r[0].numel()) for r in reads]
+    hist = tiddit_coverage.CoverageHistogram([("s%02d" % (c + 1), L) for c in range(C)], z, ctx=ctx)
+    nbins = [hist.nbins(c)[0] for c in range(C)]
+    outs = [torch.empty(nb, dtype=torch.float64, device=dev) for nb in nbins]
+    total_reads, total_bins = sum(n_reads), sum(nbins)
+
+    ev_pairs = []
+
+    def cov_step(timed):
+        hist.reset()
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+        for c in range(C):
+            s, e, mq, fl = reads[c]
+            hist.push_device(c, s.data_ptr(), e.data_ptr(), mq.data_ptr(), fl.data_ptr(), n_reads[c], args.min_q)
+        if timed:
+            b.record(stream)
+            ev_pairs.append((a, b))
+        for c in range(C):
+            hist.finish_device(c, outs[c].data_ptr())
+
+    for _ in range(args.warmup):
+        cov_step(False)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cov_step(True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t_cov = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([t_cov], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_cov = float(tt.item())
+    ms_per_step = 1e3 * t_cov / args.steps
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / (len(ev_pairs) * C)  # avg cov_accumulate launch
+    alg_bytes_launch = 12.0 * total_reads / C + 8.0 * total_bins / C             # 12 B/read + 8 B/bin
+    achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tp = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("cov_accumulate_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "cov bins/sec (binned read-depth histogram); signals clustered/sec under 'dbscan'",
+        "value": total_bins * world / (t_cov / args.steps),
+        "unit": "bins/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int64 (2^-S fixed point of the reference's float32 quotients; float64 out)",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: coverage histogram, %d contigs x %d bp (%.2f Gb), %dx 150-bp sorted "
+                               "stream, %d-bp bins, q>=%d filter, per GPU" % (C, L, C * L / 1e9, args.depth, z, args.min_q),
+                   "reads_per_gpu": total_reads, "bins_per_gpu": total_bins, "launches_per_step": 2 * C + 1},
+        "reads_per_sec": total_reads * world / (t_cov / args.steps),
+        "roofline": {"bound": "hbm", "kernel": "cov_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes_launch},
+    }
+
+    # ---------------------------------------------------------------- CPU baseline + in-bench parity (rank 0, N=1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        k = min(args.cpu_contigs, C)
+        t_cpu = 0.0
+        ok = True
+        kept = 0
+        for c in range(k):
+            s, e, mq, fl = [t.cpu().numpy() for t in reads[c]]
+            fl = fl.view(np.uint16)
+            t1 = time.perf_counter()
+            want, kk = oracle.coverage_stream(s, e, mq, fl, L, z, args.min_q)
+            t_cpu += time.perf_counter() - t1
+            kept += kk
+            ok = ok and np.array_equal(outs[c].cpu().numpy(), want)
+        if not ok:
+            raise SystemExit("PARITY FAILURE: GPU bins differ from the CPU oracle")
+        result["cpu_baseline"] = {"value": sum(nbins[:k]) / t_cpu, "unit": "bins/s", "cores": 1, "kind": "port",
+                                  "reads_per_sec": sum(n_reads[:k]) / t_cpu,
+                                  "sample": "%d of %d contigs (%d reads, %d bins), oracle/tiddit_oracle.c scalar C port of the "
+                                            "update_coverage loop, arrays in memory; bins verified bit-identical to the GPU's"
+                                            % (k, C, sum(n_reads[:k]), sum(nbins[:k]))}
+        result["parity_checked"] = True
+    del reads, outs
+    hist.close()
+    torch.cuda.empty_cache()
+
+    # ---------------------------------------------------------------- clustering (configs[2])
+    if not args.no_dbscan:
+        import ctypes
+        n = args.dbscan_n
+        pts = synth.gen_points(n, seed=synth.SEED + rank)
+        x = torch.from_numpy(pts[:, 0].astype(np.uint32).view(np.int32)).to(dev)
+        y = torch.from_numpy(pts[:, 1].astype(np.uint32).view(np.int32)).to(dev)
+        lab = torch.empty(n, dtype=torch.float64, device=dev)
+        lid = torch.empty(1, dtype=torch.int64, device=dev)
+        gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if world > 1 else None
+        off = np.array([0, n], dtype=np.int64)
+        torch.cuda.synchronize()
+        dev_ms = []
+
+        def db_step(timed):
+            with torch.cuda.stream(stream):
+                if timed:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                _native.check(ctx.lib.tdt_dbscan_device(ctx.handle, x.data_ptr(), y.data_ptr(), n, _native.ptr(off), 1,
+                                                        ctypes.c_uint64(500), 3, 0, lab.data_ptr(), lid.data_ptr()))
+                if timed:
+                    b.record(stream)
+                    dev_ms.append((a, b))
+                if world > 1:  # the exchange step: every rank ends up with the whole cluster set
+                    dist.all_gather_into_tensor(gathered, lab)
+
+        for _ in range(args.warmup):
+            db_step(False)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            db_step(True)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t_db = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t_db], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_db = float(tt.item())
+        k_ms = sum(a.elapsed_time(b) for a, b in dev_ms) / len(dev_ms)
+        db_ach = 16.0 * n / (k_ms * 1e-3) / 1e9
+        dbres = {"metric": "signals clustered/sec", "value": n * world / (t_db / args.steps), "unit": "signals/s",
+                 "ms_per_step": 1e3 * t_db / args.steps,
+                 "config": {"workload": "BASELINE configs[2]: gen_points(%d) one chr pair, e=500 l=3, per GPU%s"
+                                        % (n, "; labels all-gathered over RCCL" if world > 1 else "")},
+                 "roofline": {"bound": "hbm", "kernel": "tdt_dbscan_device (16 launches)", "achieved": db_ach, "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": db_ach / HBM_PEAK_GBS, "traffic": None, "avg_pass_ms": k_ms,
+                              "algorithmic_bytes_per_pass": 16.0 * n}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            import oracle
+            t1 = time.perf_counter()
+            want = oracle.dbscan_main(pts, 500, 3)
+            t_sweep = time.perf_counter() - t1
+            if not np.array_equal(lab.cpu().numpy(), want):
+                raise SystemExit("PARITY FAILURE: GPU labels differ from the CPU oracle")
+            ns = min(n, 200_000)
+            t1 = time.perf_counter()
+            oracle.dbscan_main(pts[:ns], 500, 3, literal=True)
+            t_lit = time.perf_counter() - t1
+            dbres["cpu_baseline"] = {"value": n / t_sweep, "unit": "signals/s", "cores": 1, "kind": "port",
+                                     "sample": "all %d points, oracle C port with the O(N) membership sweep" % n,
+                                     "literal_O(KN)": {"value": ns / t_lit, "unit": "signals/s",
+                                                       "sample": "first %d points, literal `clusters == cluster` mask per x-cluster "
+                                                                 "(DBSCAN.py:72) in C" % ns}}
+            dbres["parity_checked"] = True
+        result["dbscan"] = dbres
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libtiddit_hip.so")
+SO_PATH = os.environ.get("TIDDIT_HIP_LIB") or os.path.join(_HERE, "libtiddit_hip.so")
 
 TDT_OK = 0
 ERRORS = {-1: "TDT_E_ARG", -2: "TDT_E_HIP", -3: "TDT_E_RANGE", -4: "TDT_E_INEXACT", -5: "TDT_E_NOMEM",

@@ -21,11 +21,15 @@
 #define COV_THREADS 256
 #define COV_RPL 4                                  // reads per lane per step
 #define COV_TILE (COV_THREADS * COV_RPL)           // 1024 reads per workgroup step
+#ifndef COV_STEPS
 #define COV_STEPS 8
+#endif
 #define COV_READS_PER_BLOCK (COV_TILE * COV_STEPS) // 8192
 #define COV_WIN 2048                               // LDS window, int64 bins (16 KiB)
 #define COV_LUT_LDS_MAX 1024                       // LUT entries kept in LDS (bin_size < 1024)
 #define COV_PUSH_CHUNK (4u << 20)                  // reads per staged host chunk
+#define COV_STATUS_BYTES (128 + COV_KEPT_SLOTS * 128)
+#define COV_KEPT_SLOTS 512                         // kept-read counters, one 128-byte line each
 
 struct CovParams {
     const int32_t *start;
@@ -51,6 +55,69 @@ __device__ __forceinline__ int cov_div(int x, unsigned magic, int shift) {
     return shift < 0 ? x : (int)(__umulhi((unsigned)x, magic) >> shift);
 }
 
+// ---- wavefront primitives (DPP: pure VALU cross-lane moves, no LDS crossbar) -------------------
+#define DPP_ROW_SHR(n) (0x110 | (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {  // lanes without a source read 0
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (row_shr 1,2,4,8 then the two row broadcasts)
+__device__ __forceinline__ unsigned long long wave_scan_u64(unsigned long long v) {
+    v += dpp_u64<DPP_ROW_SHR(1), 0xf>(v);
+    v += dpp_u64<DPP_ROW_SHR(2), 0xf>(v);
+    v += dpp_u64<DPP_ROW_SHR(4), 0xf>(v);
+    v += dpp_u64<DPP_ROW_SHR(8), 0xf>(v);
+    v += dpp_u64<DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp_u64<DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+
+// out-of-window contributions (unsorted input, reads longer than the window): plain HBM atomics.
+// noinline keeps the LDS path a real ds_add_u64 instead of a flat atomic on a selected pointer.
+__device__ __noinline__ void cov_global_add(unsigned long long *acc, int bin, unsigned long long v) {
+    atomicAdd(&acc[bin], v);
+}
+
+struct CovTile {
+    int4 s, e;
+    unsigned mq;
+    uint2 fl;
+};
+
+__device__ __forceinline__ CovTile cov_load(const CovParams &P, unsigned long long idx, unsigned long long r1) {
+    CovTile t;
+    if (P.aligned && idx + COV_RPL <= r1) {
+        t.s = *reinterpret_cast<const int4 *>(P.start + idx);
+        t.e = *reinterpret_cast<const int4 *>(P.end + idx);
+        t.mq = *reinterpret_cast<const unsigned *>(P.mapq + idx);
+        t.fl = *reinterpret_cast<const uint2 *>(P.flag + idx);
+    } else {
+        int sv[COV_RPL], ev[COV_RPL];
+        unsigned mq = 0, f[COV_RPL];
+#pragma unroll
+        for (int j = 0; j < COV_RPL; j++) {
+            const bool ok = idx + j < r1;
+            sv[j] = ok ? P.start[idx + j] : 0;
+            ev[j] = ok ? P.end[idx + j] : 1;
+            mq |= (ok ? (unsigned)P.mapq[idx + j] : 0u) << (8 * j);
+            f[j] = ok ? (unsigned)P.flag[idx + j] : 0x4u;  // padding lanes look unmapped
+        }
+        t.s = make_int4(sv[0], sv[1], sv[2], sv[3]);
+        t.e = make_int4(ev[0], ev[1], ev[2], ev[3]);
+        t.mq = mq;
+        t.fl = make_uint2(f[0] | (f[1] << 16), f[2] | (f[3] << 16));
+    }
+    return t;
+}
+
 template <bool LDS_LUT>
 __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
@@ -65,6 +132,9 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     const int lane = tid & 63;
     const unsigned long long r0 = (unsigned long long)blockIdx.x * COV_READS_PER_BLOCK;
     const unsigned long long r1 = min(P.n, r0 + COV_READS_PER_BLOCK);
+
+    // first tile's loads go out before the LDS set-up
+    CovTile cur = cov_load(P, r0 + (unsigned long long)tid * COV_RPL, r1);
 
     for (int i = tid; i < COV_WIN; i += COV_THREADS) win[i] = 0;
     if (LDS_LUT) {
@@ -87,108 +157,106 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     const int last_bin = P.nbins - 1;
 
     auto contribute = [&](int bin, unsigned long long v) {
-        unsigned off = (unsigned)(bin - base);
-        if (off < COV_WIN) atomicAdd(&win[off], v);
-        else atomicAdd(&P.acc[bin], v);
+        const unsigned off = (unsigned)(bin - base);
+#ifdef COV_EXP_NOATOMIC
+        if (v == 0x1234567ull) win[0] = v;
+#else
+        if (off < COV_WIN) atomicAdd(&win[off], v);  // ds_add_u64 (bins past the contig end only ever see +x and -x)
+        else if ((unsigned)bin <= (unsigned)last_bin) cov_global_add(P.acc, bin, v);
+#endif
     };
 
     unsigned nkept = 0;
     bool bad = false;
 
     for (unsigned long long t0 = r0; t0 < r1; t0 += COV_TILE) {
-        const unsigned long long idx = t0 + (unsigned long long)tid * COV_RPL;
-        int sv[COV_RPL], ev[COV_RPL];
-        unsigned mq[COV_RPL], fl[COV_RPL];
-        if (P.aligned && idx + COV_RPL <= r1) {
-            const int4 s4 = *reinterpret_cast<const int4 *>(P.start + idx);
-            const int4 e4 = *reinterpret_cast<const int4 *>(P.end + idx);
-            const unsigned m4 = *reinterpret_cast<const unsigned *>(P.mapq + idx);
-            const uint2 f4 = *reinterpret_cast<const uint2 *>(P.flag + idx);
-            sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w;
-            ev[0] = e4.x; ev[1] = e4.y; ev[2] = e4.z; ev[3] = e4.w;
-            mq[0] = m4 & 0xff; mq[1] = (m4 >> 8) & 0xff; mq[2] = (m4 >> 16) & 0xff; mq[3] = m4 >> 24;
-            fl[0] = f4.x & 0xffff; fl[1] = f4.x >> 16; fl[2] = f4.y & 0xffff; fl[3] = f4.y >> 16;
-        } else {
-#pragma unroll
-            for (int j = 0; j < COV_RPL; j++) {
-                const bool ok = idx + j < r1;
-                sv[j] = ok ? P.start[idx + j] : 0;
-                ev[j] = ok ? P.end[idx + j] : 1;
-                mq[j] = ok ? P.mapq[idx + j] : 0;
-                fl[j] = ok ? P.flag[idx + j] : 0x4;  // padding lanes look unmapped
-            }
-        }
+        // software prefetch: the next tile's loads are in flight while this one is reduced
+        CovTile nxt = cur;
+        if (t0 + COV_TILE < r1) nxt = cov_load(P, t0 + COV_TILE + (unsigned long long)tid * COV_RPL, r1);
 
-        // lane key: first bin of the lane's first read (any value is correct; sorted input makes
-        // it non-decreasing across lanes so equal keys form runs)
-        int K;
-        {
-            int s = sv[0] < 0 ? 0 : sv[0];
-            K = cov_div(s, P.magic, P.shift);
-        }
-        unsigned long long vA = 0, vB = 0;
-        auto add = [&](int bin, unsigned long long v) {
-            if (bin == K) vA += v;
-            else if (bin == K + 1) vB += v;
-            else if (v) contribute(bin, v);
-        };
+        const int sv[COV_RPL] = {cur.s.x, cur.s.y, cur.s.z, cur.s.w};
+        const int ev[COV_RPL] = {cur.e.x, cur.e.y, cur.e.z, cur.e.w};
+        const unsigned mq[COV_RPL] = {cur.mq & 0xff, (cur.mq >> 8) & 0xff, (cur.mq >> 16) & 0xff, cur.mq >> 24};
+        const unsigned fl[COV_RPL] = {cur.fl.x & 0xffff, cur.fl.x >> 16, cur.fl.y & 0xffff, cur.fl.y >> 16};
+
+        // lane key K: first bin of the lane's first read.  Contributions to bins K, K+1, K+2 are
+        // folded into three registers (the common case: 4 consecutive sorted reads, eb - fb <= 1);
+        // anything else takes the rare slow path.  Any K is correct; sorted input makes K
+        // non-decreasing across lanes so equal keys form runs.
+        const int K = cov_div(sv[0] < 0 ? 0 : sv[0], P.magic, P.shift);
+        unsigned long long a0 = 0, a1 = 0, a2 = 0;
+#ifdef COV_EXP_LOADONLY
+        a0 = (unsigned)(sv[0] + sv[1] + sv[2] + sv[3] + ev[0] + ev[1] + ev[2] + ev[3]) + mq[0] + mq[3] + fl[0] + fl[3];
+        if (a0 == 0x1234567ull) contribute(K, a0);
+        cur = nxt;
+        continue;
+#endif
 
 #pragma unroll
         for (int j = 0; j < COV_RPL; j++) {
-            int s = sv[j], e = ev[j];
-            bool keep = !(fl[j] & 0x404u) && (int)mq[j] >= P.min_q;
-            int fb = 0, eb = 0;
+            const int s = sv[j], e = ev[j];
+            bool keep = !(fl[j] & 0x404u) && (int)mq[j] >= P.min_q;   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+            if (keep && (s < 0 || e <= s)) { bad = true; keep = false; }
+            const int fb = cov_div(keep ? s : 0, P.magic, P.shift);
+            const int eb = cov_div(keep ? e - 1 : 0, P.magic, P.shift);
+            if (keep && eb > last_bin) { bad = true; keep = false; }
+            nkept += keep ? 1u : 0u;
+            const bool multi = eb != fb;
+            // bases in the first bin (:55 single-bin / :61 multi-bin) and in the last bin (:63, one short)
+            const unsigned bf = multi ? (unsigned)(fb + 1) * (unsigned)z - (unsigned)s : (unsigned)(e - s);
+            const unsigned bl = (unsigned)(e - 1) - (unsigned)eb * (unsigned)z;
+            unsigned long long vF = 0, vL = 0;
             if (keep) {
-                if (s < 0 || e <= s) { bad = true; keep = false; }
+                vF = LM[bf];                                        // :57 / :62
+                if (multi) vL = eb < last_bin ? LM[bl] : LE[bl];    // :66-69
             }
-            if (keep) {
-                fb = cov_div(s, P.magic, P.shift);
-                eb = cov_div(e - 1, P.magic, P.shift);
-                if (eb > last_bin) { bad = true; keep = false; }
-            }
-            if (keep) {
-                nkept++;
-                if (fb == eb) {
-                    add(fb, LM[e - s]);                                  // tiddit_coverage.pyx:55-57
-                } else {
-                    add(fb, LM[(unsigned)(fb + 1) * (unsigned)z - (unsigned)s]);                     // :61-62
-                    const int bl = (int)((unsigned)(e - 1) - (unsigned)eb * (unsigned)z);                   // :63 (one short of the true overlap)
-                    add(eb, eb < last_bin ? LM[bl] : LE[bl]);            // :66-69
-                    for (int b = fb + 1; b < eb; b++) add(b, P.one);     // :71-72
-                }
+            const unsigned r = (unsigned)(fb - K);
+            const bool fast = r <= 1u && (unsigned)(eb - fb) <= 1u;
+            if (fast) {
+                const bool r0_ = r == 0;
+                a0 += r0_ ? vF : 0ull;
+                a1 += r0_ ? vL : vF;
+                a2 += r0_ ? 0ull : vL;
+            } else if (keep) {
+                contribute(fb, vF);
+                if (multi) contribute(eb, vL);
+                for (int b = fb + 1; b < eb; b++) contribute(b, P.one);   // :71-72
             }
         }
 
-        // wavefront segmented reduction of (vA, vB) over runs of equal K
-        const int Kprev = __shfl_up(K, 1);
-        const bool head = (lane == 0) || (Kprev != K);
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long below = heads & ((2ull << lane) - 1ull);  // heads at lanes <= lane
-        const int run_start = 63 - __clzll((long long)below);
-        const int dist = lane - run_start;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long a = __shfl_up(vA, d);
-            const unsigned long long b = __shfl_up(vB, d);
-            if (dist >= d) { vA += a; vB += b; }
+        // wavefront merge: inclusive prefix sums of the three registers; a run [a..b] of equal K sums to
+        // P[b] - P[a-1], so run-tail lanes add +P[b] and run-head lanes add -P[a-1] (two's complement)
+        const unsigned long long p0 = wave_scan_u64(a0), p1 = wave_scan_u64(a1), p2 = wave_scan_u64(a2);
+        const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
+        const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
+        // (cross-lane reads must happen with every lane active: a DPP source lane that is masked off returns nothing)
+        const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1, 0xf>(p0), q1 = dpp_u64<DPP_WAVE_SHR1, 0xf>(p1),
+                                 q2 = dpp_u64<DPP_WAVE_SHR1, 0xf>(p2);
+        if (Knext != K) {  // run tail (lane 63 always: it reads ~K)
+            if (p0) contribute(K, p0);
+            if (p1) contribute(K + 1, p1);
+            if (p2) contribute(K + 2, p2);
         }
-        const bool tail = (lane == 63) || ((heads >> lane >> 1) & 1ull);
-        if (tail) {
-            if (vA) contribute(K, vA);
-            if (vB) contribute(K + 1, vB);
+        if (Kprev != K && lane != 0) {  // run head
+            if (q0) contribute(K, 0ull - q0);
+            if (q1) contribute(K + 1, 0ull - q1);
+            if (q2) contribute(K + 2, 0ull - q2);
         }
+        cur = nxt;
     }
 
-    // kept-read count: one atomic per wave
+    // kept-read count: one atomic per wave, spread over COV_KEPT_SLOTS cache lines (thousands of
+    // same-address atomics serialise at ~12 ns each and would bound the whole launch)
     for (int d = 32; d > 0; d >>= 1) nkept += __shfl_down(nkept, d);
-    if (lane == 0 && nkept) atomicAdd(P.kept, (unsigned long long)nkept);
+    if (lane == 0 && nkept)
+        atomicAdd(P.kept + (size_t)((blockIdx.x * (COV_THREADS / 64) + (tid >> 6)) % COV_KEPT_SLOTS) * 16, (unsigned long long)nkept);
     if (bad) atomicOr(P.status, 1);
 
     __syncthreads();
     // coalesced spill of the LDS window
     for (int i = tid; i < COV_WIN; i += COV_THREADS) {
         const unsigned long long v = win[i];
-        if (v) atomicAdd(&P.acc[base + i], v);
+        if (v && base + i <= last_bin) atomicAdd(&P.acc[base + i], v);
     }
 }
 
@@ -219,8 +287,8 @@ struct tdt_cov {
     unsigned long long *d_acc = nullptr;
     unsigned long long *d_lut_main = nullptr;
     unsigned long long *d_lut_end = nullptr;  // [n_contigs][bin_size+1]
-    int *d_status = nullptr;                  // [0] status bits, (8 B further) kept counter
-    unsigned long long *d_kept = nullptr;
+    int *d_status = nullptr;                  // [0] status bits; kept counters start 128 B further
+    unsigned long long *d_kept = nullptr;     // COV_KEPT_SLOTS counters, 128 B apart
     // staging slots for host pushes
     void *d_stage[2] = {nullptr, nullptr};
     void *h_stage[2] = {nullptr, nullptr};
@@ -333,13 +401,13 @@ extern "C" int tdt_cov_create(tdt_ctx *ctx, const int64_t *contig_len, int n_con
     if ((e = hipMalloc((void **)&c->d_acc, (size_t)(total > 0 ? total : 1) * 8)) != hipSuccess) return fail("hipMalloc(acc)");
     if ((e = hipMalloc((void **)&c->d_lut_main, lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut)");
     if ((e = hipMalloc((void **)&c->d_lut_end, (size_t)n_contigs * lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut_end)");
-    if ((e = hipMalloc((void **)&c->d_status, 16)) != hipSuccess) return fail("hipMalloc(status)");
-    c->d_kept = (unsigned long long *)((char *)c->d_status + 8);
+    if ((e = hipMalloc((void **)&c->d_status, COV_STATUS_BYTES)) != hipSuccess) return fail("hipMalloc(status)");
+    c->d_kept = (unsigned long long *)((char *)c->d_status + 128);
     if ((e = hipMemcpy(c->d_lut_main, lut.data(), lut_n * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(lut)");
     if ((e = hipMemcpy(c->d_lut_end, lute.data(), (size_t)n_contigs * lut_n * 8, hipMemcpyHostToDevice)) != hipSuccess)
         return fail("hipMemcpy(lut_end)");
     if ((e = hipMemset(c->d_acc, 0, (size_t)(total > 0 ? total : 1) * 8)) != hipSuccess) return fail("hipMemset(acc)");
-    if ((e = hipMemset(c->d_status, 0, 16)) != hipSuccess) return fail("hipMemset(status)");
+    if ((e = hipMemset(c->d_status, 0, COV_STATUS_BYTES)) != hipSuccess) return fail("hipMemset(status)");
     for (int i = 0; i < 2; i++)
         if ((e = hipEventCreateWithFlags(&c->slot_ev[i], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate");
     *out = c;
@@ -378,7 +446,7 @@ extern "C" int tdt_cov_reset(tdt_cov *c) {
     if (!c) return TDT_E_ARG;
     TDT_HIP(hipSetDevice(c->ctx->device));
     TDT_HIP(hipMemsetAsync(c->d_acc, 0, (size_t)(c->total_bins > 0 ? c->total_bins : 1) * 8, c->ctx->stream));
-    TDT_HIP(hipMemsetAsync(c->d_status, 0, 16, c->ctx->stream));
+    TDT_HIP(hipMemsetAsync(c->d_status, 0, COV_STATUS_BYTES, c->ctx->stream));
     return TDT_OK;
 }
 
@@ -519,9 +587,11 @@ extern "C" int tdt_cov_finish(tdt_cov *c, int tid, double *out) {
 extern "C" int tdt_cov_kept(tdt_cov *c, int64_t *kept) {
     if (!c || !kept) return TDT_E_ARG;
     TDT_HIP(hipSetDevice(c->ctx->device));
-    unsigned long long k = 0;
-    TDT_HIP(hipMemcpyAsync(&k, c->d_kept, 8, hipMemcpyDeviceToHost, c->ctx->stream));
+    std::vector<unsigned long long> h((size_t)COV_KEPT_SLOTS * 16);
+    TDT_HIP(hipMemcpyAsync(h.data(), c->d_kept, h.size() * 8, hipMemcpyDeviceToHost, c->ctx->stream));
     TDT_HIP(hipStreamSynchronize(c->ctx->stream));
+    unsigned long long k = 0;
+    for (int i = 0; i < COV_KEPT_SLOTS; i++) k += h[(size_t)i * 16];
     *kept = (int64_t)k;
     return TDT_OK;
 }

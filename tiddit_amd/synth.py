@@ -73,3 +73,34 @@ def gen_sequence(L, seed=SEED, n_frac=0.02, lower_frac=0.3, gc=0.41):
     for s, ln in zip(rng.integers(0, L, l_runs), rng.integers(1, 600, l_runs)):
         seq[s:s + ln] |= 0x20
     return seq
+
+
+def gen_reads_device(L, depth, device, read_len=150, seed=SEED):
+    """Same distribution as :func:`gen_reads`, generated directly in HBM with torch (different RNG
+    stream, so not the golden-checksum input): -> (start i32, end i32, mapq u8, flag i16-as-u16 bits)
+    tensors on ``device``.  Used by bench.py for the 600 M-read config-2 stream."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n = int(L * depth / read_len)
+    start = torch.randint(0, L - read_len + 1, (n,), generator=g, device=device, dtype=torch.int32)
+    start, _ = torch.sort(start)
+    kind = torch.rand(n, generator=g, device=device)
+    clip = torch.randint(1, 60, (n,), generator=g, device=device, dtype=torch.int32)
+    dele = torch.randint(1, 30, (n,), generator=g, device=device, dtype=torch.int32)
+    reflen = torch.full((n,), read_len, device=device, dtype=torch.int32)
+    reflen = torch.where(kind < 0.05, read_len - clip, reflen)
+    reflen = torch.where((kind >= 0.05) & (kind < 0.10), read_len + dele, reflen)
+    end = torch.minimum(start + reflen, torch.tensor(L, device=device, dtype=torch.int32))
+    del kind, clip, dele, reflen
+    u = torch.rand(n, generator=g, device=device)
+    cdf = torch.tensor([.04, .05, .07, .10, .20], device=device)
+    vals = torch.tensor([0, 1, 10, 20, 30, 60], device=device, dtype=torch.uint8)
+    mapq = vals[torch.bucketize(u, cdf, right=True)]
+    flag = torch.full((n,), 0x3, device=device, dtype=torch.int16)
+    u = torch.rand(n, generator=g, device=device)
+    flag |= torch.where(u < .5, 0x10, 0x20).to(torch.int16)
+    for p, bit in ((.02, 0x400), (.005, 0x4), (.01, 0x800), (.005, 0x100)):
+        u = torch.rand(n, generator=g, device=device)
+        flag |= torch.where(u < p, bit, 0).to(torch.int16)
+    return start, end, mapq, flag
