@@ -25,7 +25,9 @@
 #define COV_STEPS 8
 #endif
 #define COV_READS_PER_BLOCK (COV_TILE * COV_STEPS) // 8192
+#ifndef COV_WIN
 #define COV_WIN 2048                               // LDS window, int64 bins (16 KiB)
+#endif
 #define COV_LUT_LDS_MAX 1024                       // LUT entries kept in LDS (bin_size < 1024)
 #define COV_PUSH_CHUNK (4u << 20)                  // reads per staged host chunk
 #define COV_STATUS_BYTES (128 + COV_KEPT_SLOTS * 128)
@@ -56,28 +58,45 @@ __device__ __forceinline__ int cov_div(int x, unsigned magic, int shift) {
 }
 
 // ---- wavefront primitives (DPP: pure VALU cross-lane moves, no LDS crossbar) -------------------
-#define DPP_ROW_SHR(n) (0x110 | (n))
-#define DPP_ROW_BCAST15 0x142
-#define DPP_ROW_BCAST31 0x143
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 
-template <int CTRL, int ROW_MASK>
+template <int CTRL>
 __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {  // lanes without a source read 0
-    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, ROW_MASK, 0xf, false);
-    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// inclusive prefix sum over the 64 lanes of a wave (row_shr 1,2,4,8 then the two row broadcasts)
-__device__ __forceinline__ unsigned long long wave_scan_u64(unsigned long long v) {
-    v += dpp_u64<DPP_ROW_SHR(1), 0xf>(v);
-    v += dpp_u64<DPP_ROW_SHR(2), 0xf>(v);
-    v += dpp_u64<DPP_ROW_SHR(4), 0xf>(v);
-    v += dpp_u64<DPP_ROW_SHR(8), 0xf>(v);
-    v += dpp_u64<DPP_ROW_BCAST15, 0xa>(v);
-    v += dpp_u64<DPP_ROW_BCAST31, 0xc>(v);
-    return v;
+// One step of an in-place inclusive wave scan on three 64-bit values at once:
+//   x += dpp(x)   as   v_add_co_u32_dpp lo / v_addc_co_u32_dpp hi   (2 instructions per value).
+// bound_ctrl:0 makes lanes without a source add 0; rows disabled by row_mask keep their value
+// because the add is in place.  The three values are interleaved so that every DPP read of a VGPR
+// is >= 4 instructions behind the VALU write of that VGPR (the DPP read-after-write hazard needs 2
+// wait states, which inline asm does not get from the compiler).
+#define COV_SCAN_STEP(CTRL)                                                                     \
+    asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\t"                                \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"                          \
+                 "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n\t"                                \
+                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL "\n\t"                          \
+                 "v_add_co_u32_dpp %4, vcc, %4, %4 " CTRL "\n\t"                                \
+                 "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " CTRL                                 \
+                 : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2)::"vcc")
+
+__device__ __forceinline__ void wave_scan3_u64(unsigned long long &a0, unsigned long long &a1, unsigned long long &a2) {
+    unsigned l0 = (unsigned)a0, h0 = (unsigned)(a0 >> 32), l1 = (unsigned)a1, h1 = (unsigned)(a1 >> 32),
+             l2 = (unsigned)a2, h2 = (unsigned)(a2 >> 32);
+    asm volatile("s_nop 1" ::: "memory");  // the values were just written by plain VALU
+    COV_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    COV_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::: "memory");
+    a0 = ((unsigned long long)h0 << 32) | l0;
+    a1 = ((unsigned long long)h1 << 32) | l1;
+    a2 = ((unsigned long long)h2 << 32) | l2;
 }
 
 // out-of-window contributions (unsorted input, reads longer than the window): plain HBM atomics.
@@ -122,25 +141,26 @@ template <bool LDS_LUT>
 __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
     // everything lives in the dynamic region (a static __shared__ in front of it would shift its
-    // base off 16-byte alignment): [0] window base bin, [2..) window, then the two LUTs
+    // base off 16-byte alignment): [0] window base bin, [2..) window, then the LUT pair
+    // (main table, then the contig's end-bin table, each bin_size+1 entries)
     int *s_base = reinterpret_cast<int *>(smem);
     unsigned long long *win = smem + 2;
-    unsigned long long *lutM = win + COV_WIN;
-    unsigned long long *lutE = lutM + (LDS_LUT ? (P.bin_size + 1) : 0);
+    unsigned long long *lutS = win + COV_WIN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const unsigned long long r0 = (unsigned long long)blockIdx.x * COV_READS_PER_BLOCK;
     const unsigned long long r1 = min(P.n, r0 + COV_READS_PER_BLOCK);
+    const unsigned z = (unsigned)P.bin_size;
 
     // first tile's loads go out before the LDS set-up
     CovTile cur = cov_load(P, r0 + (unsigned long long)tid * COV_RPL, r1);
 
     for (int i = tid; i < COV_WIN; i += COV_THREADS) win[i] = 0;
     if (LDS_LUT) {
-        for (int i = tid; i <= P.bin_size; i += COV_THREADS) {
-            lutM[i] = P.lut_main[i];
-            lutE[i] = P.lut_end[i];
+        for (unsigned i = tid; i <= z; i += COV_THREADS) {
+            lutS[i] = P.lut_main[i];
+            lutS[i + z + 1] = P.lut_end[i];
         }
     }
     if (tid == 0) {
@@ -151,10 +171,12 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     }
     __syncthreads();
     const int base = *s_base;
-    const unsigned long long *LM = LDS_LUT ? lutM : P.lut_main;
-    const unsigned long long *LE = LDS_LUT ? lutE : P.lut_end;
-    const int z = P.bin_size;
     const int last_bin = P.nbins - 1;
+    // LUT[i] for i <= z: float32(i)/float32(z); LUT[z+1+i]: float32(i)/float32(end_bin_size).  LUT[0] == 0.
+    auto lut = [&](unsigned i) -> unsigned long long {
+        if (LDS_LUT) return lutS[i];
+        return i <= z ? P.lut_main[i] : P.lut_end[i - z - 1];
+    };
 
     auto contribute = [&](int bin, unsigned long long v) {
         const unsigned off = (unsigned)(bin - base);
@@ -164,6 +186,20 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         if (off < COV_WIN) atomicAdd(&win[off], v);  // ds_add_u64 (bins past the contig end only ever see +x and -x)
         else if ((unsigned)bin <= (unsigned)last_bin) cov_global_add(P.acc, bin, v);
 #endif
+    };
+
+    // the literal per-read update (tiddit_coverage.pyx:50-72) for reads the register path cannot hold
+    auto slow_read = [&](int s, int e) {
+        const int fb = cov_div(s, P.magic, P.shift);
+        const int eb = cov_div(e - 1, P.magic, P.shift);
+        if (fb == eb) {
+            contribute(fb, lut((unsigned)(e - s)));
+        } else {
+            contribute(fb, lut((unsigned)(fb + 1) * z - (unsigned)s));
+            const unsigned bl = (unsigned)(e - 1) - (unsigned)eb * z;
+            contribute(eb, lut(eb < last_bin ? bl : bl + z + 1));
+            for (int b = fb + 1; b < eb; b++) contribute(b, P.one);
+        }
     };
 
     unsigned nkept = 0;
@@ -179,11 +215,13 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         const unsigned mq[COV_RPL] = {cur.mq & 0xff, (cur.mq >> 8) & 0xff, (cur.mq >> 16) & 0xff, cur.mq >> 24};
         const unsigned fl[COV_RPL] = {cur.fl.x & 0xffff, cur.fl.x >> 16, cur.fl.y & 0xffff, cur.fl.y >> 16};
 
-        // lane key K: first bin of the lane's first read.  Contributions to bins K, K+1, K+2 are
-        // folded into three registers (the common case: 4 consecutive sorted reads, eb - fb <= 1);
-        // anything else takes the rare slow path.  Any K is correct; sorted input makes K
-        // non-decreasing across lanes so equal keys form runs.
+        // lane key K: first bin of the lane's first read (the only division of the step).  A read whose
+        // first bin is K or K+1 and whose last bin is at most one further is folded into the three
+        // registers a0,a1,a2 (bins K, K+1, K+2) without branches; anything else (reads spanning more
+        // bins, unsorted input) is flagged and replayed literally below.  Any K is correct; sorted
+        // input makes K non-decreasing across lanes so equal keys form runs.
         const int K = cov_div(sv[0] < 0 ? 0 : sv[0], P.magic, P.shift);
+        const unsigned Kz = (unsigned)K * z;
         unsigned long long a0 = 0, a1 = 0, a2 = 0;
 #ifdef COV_EXP_LOADONLY
         a0 = (unsigned)(sv[0] + sv[1] + sv[2] + sv[3] + ev[0] + ev[1] + ev[2] + ev[3]) + mq[0] + mq[3] + fl[0] + fl[3];
@@ -191,51 +229,54 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         cur = nxt;
         continue;
 #endif
-
+        unsigned slowmask = 0;
 #pragma unroll
         for (int j = 0; j < COV_RPL; j++) {
             const int s = sv[j], e = ev[j];
             bool keep = !(fl[j] & 0x404u) && (int)mq[j] >= P.min_q;   // __main__.py:231-235 / tiddit_signal.pyx:171-181
-            if (keep && (s < 0 || e <= s)) { bad = true; keep = false; }
-            const int fb = cov_div(keep ? s : 0, P.magic, P.shift);
-            const int eb = cov_div(keep ? e - 1 : 0, P.magic, P.shift);
-            if (keep && eb > last_bin) { bad = true; keep = false; }
+            const bool invalid = keep && (s < 0 || e <= s);
+            const unsigned rs = (unsigned)s - Kz;        // offsets from the start of bin K
+            const unsigned re = (unsigned)(e - 1) - Kz;
+            const unsigned r = (rs >= z) ? 1u : 0u;      // first bin = K + r   (rs < 2z on the register path)
+            const unsigned q = (re >= z ? 1u : 0u) + (re >= 2u * z ? 1u : 0u);  // last bin = K + q (re < 3z)
+            const bool over = keep && !invalid && (K + (int)q > last_bin) && re < 3u * z;
+            bad = bad || invalid || over;
+            keep = keep && !invalid && !over;
             nkept += keep ? 1u : 0u;
-            const bool multi = eb != fb;
+            const bool fast = rs < 2u * z && re < 3u * z && q - r <= 1u;
+            const bool ok = keep && fast;
+            slowmask |= (keep && !fast) ? (1u << j) : 0u;
+            const bool multi = q != r;
             // bases in the first bin (:55 single-bin / :61 multi-bin) and in the last bin (:63, one short)
-            const unsigned bf = multi ? (unsigned)(fb + 1) * (unsigned)z - (unsigned)s : (unsigned)(e - s);
-            const unsigned bl = (unsigned)(e - 1) - (unsigned)eb * (unsigned)z;
-            unsigned long long vF = 0, vL = 0;
-            if (keep) {
-                vF = LM[bf];                                        // :57 / :62
-                if (multi) vL = eb < last_bin ? LM[bl] : LE[bl];    // :66-69
-            }
-            const unsigned r = (unsigned)(fb - K);
-            const bool fast = r <= 1u && (unsigned)(eb - fb) <= 1u;
-            if (fast) {
-                const bool r0_ = r == 0;
-                a0 += r0_ ? vF : 0ull;
-                a1 += r0_ ? vL : vF;
-                a2 += r0_ ? 0ull : vL;
-            } else if (keep) {
-                contribute(fb, vF);
-                if (multi) contribute(eb, vL);
-                for (int b = fb + 1; b < eb; b++) contribute(b, P.one);   // :71-72
-            }
+            const unsigned bf = multi ? (r + 1u) * z - rs : (unsigned)(e - s);
+            const unsigned bl = re - q * z + ((K + (int)q == last_bin) ? z + 1u : 0u);   // :66-69 picks the end-bin table
+            const unsigned long long vF = lut(ok ? bf : 0u);                 // :57 / :62
+            const unsigned long long vL = lut((ok && multi) ? bl : 0u);      // :66-69
+            const bool r0_ = r == 0;
+            a0 += r0_ ? vF : 0ull;
+            a1 += r0_ ? vL : vF;
+            a2 += r0_ ? 0ull : vL;
+        }
+        if (slowmask) {
+#pragma unroll
+            for (int j = 0; j < COV_RPL; j++)
+                if (slowmask & (1u << j)) {
+                    if (cov_div(ev[j] - 1, P.magic, P.shift) > last_bin) { bad = true; nkept--; }
+                    else slow_read(sv[j], ev[j]);
+                }
         }
 
         // wavefront merge: inclusive prefix sums of the three registers; a run [a..b] of equal K sums to
-        // P[b] - P[a-1], so run-tail lanes add +P[b] and run-head lanes add -P[a-1] (two's complement)
-        const unsigned long long p0 = wave_scan_u64(a0), p1 = wave_scan_u64(a1), p2 = wave_scan_u64(a2);
+        // P[b] - P[a-1], so run-tail lanes add +P[b] and run-head lanes add -P[a-1] (two's complement).
+        // (cross-lane reads happen with every lane active: a masked-off DPP source lane returns nothing)
+        wave_scan3_u64(a0, a1, a2);
         const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
         const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
-        // (cross-lane reads must happen with every lane active: a DPP source lane that is masked off returns nothing)
-        const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1, 0xf>(p0), q1 = dpp_u64<DPP_WAVE_SHR1, 0xf>(p1),
-                                 q2 = dpp_u64<DPP_WAVE_SHR1, 0xf>(p2);
+        const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(a0), q1 = dpp_u64<DPP_WAVE_SHR1>(a1), q2 = dpp_u64<DPP_WAVE_SHR1>(a2);
         if (Knext != K) {  // run tail (lane 63 always: it reads ~K)
-            if (p0) contribute(K, p0);
-            if (p1) contribute(K + 1, p1);
-            if (p2) contribute(K + 2, p2);
+            if (a0) contribute(K, a0);
+            if (a1) contribute(K + 1, a1);
+            if (a2) contribute(K + 2, a2);
         }
         if (Kprev != K && lane != 0) {  // run head
             if (q0) contribute(K, 0ull - q0);
