@@ -387,3 +387,35 @@ def test_sort_dbscan(ctx, nat):
         assert np.array_equal(perm[lo:hi], lo + order), b
         d = np.stack([xa[lo:hi][order], ya[lo:hi][order]], 1)
         assert np.array_equal(lab[lo:hi], oracle.dbscan_main(d, 300, 3)), b
+
+
+# ------------------------------------------------------------------------------------- cluster
+def _jsonable(c):
+    if isinstance(c, dict):
+        return {str(k): _jsonable(v) for k, v in c.items()}
+    if isinstance(c, set):
+        return {"__set__": sorted(_jsonable(x) for x in c)}
+    if isinstance(c, (list, tuple)):
+        return [_jsonable(x) for x in c]
+    if isinstance(c, np.integer):
+        return int(c)
+    if isinstance(c, np.floating):
+        return float(c)
+    return c
+
+
+def test_cluster_main_golden(ctx, golden_dir, tmp_path):
+    from tiddit_amd import tiddit_cluster
+    g = json.load(open(os.path.join(golden_dir, "cluster.json")))
+    for t in g["find_discordant_pos"]:
+        frag = ["q", "1", "1", "100", "250", t["revA"], "900", "1050", t["revB"]]
+        assert list(tiddit_cluster.find_discordant_pos(frag, t["is_mp"])) == t["out"]
+    for ci, case in enumerate(g["cases"]):
+        d = tmp_path / ("case%d" % ci)
+        (d / "p_tiddit").mkdir(parents=True)
+        (d / "p_tiddit" / "discordants_S.tab").write_text("".join(l + "\n" for l in case["discordants_tab"]))
+        (d / "p_tiddit" / "splits_S.tab").write_text("".join(l + "\n" for l in case["splits_tab"]))
+        cand = tiddit_cluster.main(str(d / "p"), case["chromosomes"], case["contig_length"], ["S"], case["is_mp"], case["epsilon"],
+                                   case["m"], case["max_ins_len"], case["min_contig"], True, case["min_reads"])
+        # same keys, same values AND same insertion order (the order defines the VCF SV ids downstream)
+        assert json.dumps(_jsonable(cand)) == json.dumps(case["candidates"]), ci

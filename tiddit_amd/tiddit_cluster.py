@@ -1,0 +1,208 @@
+"""Drop-in for ``tiddit.tiddit_cluster`` (tiddit_cluster.pyx) on the MI355X.
+
+``main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig,
+skip_assembly, min_reads) -> candidates`` (:39-338) and ``find_discordant_pos(fragment, is_mp)`` (:7-37)
+keep the reference's arguments and return the same nested ``candidates[chrA][chrB][cluster_id]``
+dictionaries (same keys, same insertion order — the order later defines the VCF ``SV_n`` ids).
+
+What moved to the GPU: the stable sort of every (chrA,chrB) bucket by posA and ``DBSCAN.main`` on it
+(:152-154) — all buckets in ONE ``tdt_sort_dbscan`` call instead of a serial Python loop.  What stays on
+the host: parsing the ``.tab`` signal files (:47-137) and regrouping signals into candidates (:156-336).
+Reference quirks that are reproduced on purpose are marked QUIRK.
+"""
+from collections import Counter
+
+import numpy
+
+from . import _native
+
+# (orientation of read A, orientation of read B) -> which of (start, end) is the breakpoint side,
+# indexes into the 9-column discordants_*.tab row: 3=startA 4=endA 6=startB 7=endB   (:7-37)
+_PE_SIDE = {("False", "True"): (4, 6), ("False", "False"): (4, 7), ("True", "True"): (3, 6)}
+_MP_SIDE = {("False", "True"): (3, 7), ("False", "False"): (3, 6), ("True", "True"): (4, 7)}
+
+
+def find_discordant_pos(fragment, is_mp):
+    """Pick (posA, posB) of a discordant pair from its read coordinates and orientations."""
+    key = (fragment[5], fragment[8])
+    if is_mp:
+        a, b = _MP_SIDE.get(key, (4, 6))
+    else:
+        a, b = _PE_SIDE.get(key, (3, 7))
+    return (fragment[a], fragment[b])
+
+
+def _new_candidate():
+    side = lambda: {"contigs": [], "splits": [], "discordants": [], "orientation_contigs": [], "orientation_splits": [],
+                    "orientation_discordants": [], "start": [], "end": []}
+    c = {"signal_type": {}, "samples": set([]), "sample_discordants": {}, "sample_splits": {}, "sample_contigs": {},
+         "N_discordants": 0, "discordants": set([]), "N_splits": 0, "splits": set([]), "N_contigs": 0, "contigs": set([]),
+         "n_signals": 0, "posA": 0}
+    c["positions_A"] = side()
+    c["start_A"] = 0
+    c["end_A"] = 0
+    c["posB"] = 0
+    c["positions_B"] = side()
+    c["start_B"] = 0
+    c["end_B"] = 0
+    return c
+
+
+_KIND = {"D": "discordants", "S": "splits", "A": "contigs"}
+
+
+def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly):
+    """Parse discordants_/splits_/contigs_{sample}.tab in the reference's order (:46-137).
+    -> signals[chrA][chrB] = list of records, positions[chrA][chrB] = list of [posA, posB, i]."""
+    signals, positions = {}, {}
+    i = 0
+
+    def bucket(chrA, chrB):
+        positions.setdefault(chrA, {}).setdefault(chrB, [])
+        return signals.setdefault(chrA, {}).setdefault(chrB, [])
+
+    for sample in samples:
+        for line in open("{}_tiddit/discordants_{}.tab".format(prefix, sample)):
+            c = line.rstrip().split("\t")
+            chrA, chrB = c[1], c[2]
+            if contig_length[chrA] < min_contig or contig_length[chrB] < min_contig:
+                continue
+            recs = bucket(chrA, chrB)
+            posA, posB = find_discordant_pos(c, is_mp)
+            if int(posA) > contig_length[chrA]:
+                posA = contig_length[chrA]
+                if int(posB) > contig_length[chrB]:
+                    posA = contig_length[chrB]      # QUIRK (:67-70): posB is never clipped, posA takes chrB's length
+            recs.append([c[0], sample, "D", posA, c[5], posB, c[8], i, int(c[3]), int(c[4]), int(c[6]), int(c[7])])
+            positions[chrA][chrB].append([int(posA), int(posB), i])
+            i += 1
+        files = [("S", "{}_tiddit/splits_{}.tab")]
+        if not skip_assembly:
+            files.append(("A", "{}_tiddit/contigs_{}.tab"))
+        for kind, pattern in files:
+            for line in open(pattern.format(prefix, sample)):
+                c = line.rstrip().split("\t")
+                chrA, chrB = c[1], c[2]
+                if contig_length[chrA] < min_contig or contig_length[chrB] < min_contig:
+                    continue
+                recs = bucket(chrA, chrB)
+                posA, posB = c[3], c[5]
+                if int(posA) > contig_length[chrA]:
+                    posA = contig_length[chrA]
+                if int(posB) > contig_length[chrB]:
+                    posB = contig_length[chrB]
+                recs.append([c[0], sample, kind, posA, c[4], posB, c[6], i, int(c[7]), int(c[8]), int(c[9]), int(c[10])])
+                positions[chrA][chrB].append([int(posA), int(posB), i])
+                i += 1
+    return signals, positions
+
+
+def cluster_buckets(buckets, epsilon, m, ctx=None):
+    """buckets: list of int64 [n_b, >=2] arrays (posA, posB, ...) in signal order.
+    -> list of float64 label arrays, labels[b][j] = cluster of the bucket's j-th signal
+    (= DBSCAN.main on the bucket stably sorted by posA, mapped back; tiddit_cluster.pyx:152-160)."""
+    ctx = ctx or _native.default_context()
+    sizes = [len(b) for b in buckets]
+    n = int(sum(sizes))
+    off = numpy.zeros(len(buckets) + 1, dtype=numpy.int64)
+    numpy.cumsum(sizes, out=off[1:])
+    if n == 0:
+        return [numpy.zeros(0) for _ in buckets]
+    posA = numpy.ascontiguousarray(numpy.concatenate([numpy.asarray(b, dtype=numpy.int64).reshape(len(b), -1)[:, 0] for b in buckets]))
+    posB = numpy.ascontiguousarray(numpy.concatenate([numpy.asarray(b, dtype=numpy.int64).reshape(len(b), -1)[:, 1] for b in buckets]))
+    perm = numpy.empty(n, dtype=numpy.uint32)
+    lab = numpy.empty(n, dtype=numpy.float64)
+    _native.check(ctx.lib.tdt_sort_dbscan(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets),
+                                          float(epsilon), int(m), _native.ptr(perm), _native.ptr(lab)))
+    by_signal = numpy.empty(n, dtype=numpy.float64)
+    by_signal[perm] = lab
+    return [by_signal[off[b]:off[b + 1]] for b in range(len(buckets))]
+
+
+def _mode(values):
+    return Counter(values).most_common(1)[0][0]   # ties: first inserted (CPython Counter)
+
+
+def _breakpoints_from_discordants(cand, is_mp):
+    """:277-330 — orientation-consistent clusters take the extreme positions, others the mode."""
+    A, B = cand["positions_A"], cand["positions_B"]
+    revA, fwdA = A["orientation_discordants"].count("True"), A["orientation_discordants"].count("False")
+    revB, fwdB = B["orientation_discordants"].count("True"), B["orientation_discordants"].count("False")
+    consistent = (revA >= 5 * fwdA or revA * 5 <= fwdA) and (revB >= 5 * fwdB or revB * 5 <= fwdB)
+    if not consistent:
+        return _mode(A["discordants"]), _mode(B["discordants"])
+    a_rev, b_rev = revA > fwdA, revB > fwdB
+    if is_mp:
+        pickA = max if a_rev else min
+        pickB = max if b_rev else min
+    else:
+        pickA = min if a_rev else max
+        pickB = min if b_rev else max
+    return pickA(A["discordants"]), pickB(B["discordants"])
+
+
+def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
+    signals, positions = _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly)
+
+    order = [(a, b) for a in chromosomes if a in positions for b in chromosomes if b in positions[a]]
+    labels = cluster_buckets([numpy.array(positions[a][b], dtype=numpy.int64) for a, b in order], epsilon, m)
+
+    candidates = {}
+    for chrA in chromosomes:           # candidates[chrA] exists for every chrA that has signals (:141-145)
+        if chrA in positions:
+            candidates[chrA] = {}
+    for (chrA, chrB), lab in zip(order, labels):
+        bucket = candidates[chrA].setdefault(chrB, {})
+        recs = signals[chrA][chrB]
+        n_sig = len(recs)
+        n_ctg_clusters = 0
+        for j in range(n_sig):         # signal-index order == file order inside the bucket (:160)
+            rec = recs[j]
+            cid = int(lab[j])
+            if cid == -1:
+                lone_contig = chrA == chrB and rec[2] == "A" and (int(rec[5]) - int(rec[3])) < max_ins_len * 2
+                if not lone_contig:
+                    continue
+                cid = n_sig + n_ctg_clusters        # unclustered assembly contigs become their own candidate (:166-168)
+                n_ctg_clusters += 1
+            cand = bucket.get(cid)
+            if cand is None:
+                cand = bucket[cid] = _new_candidate()
+            qname, sample, kind = rec[0], rec[1], rec[2]
+            if sample not in cand["samples"]:
+                cand["sample_discordants"][sample] = set([])
+                cand["sample_splits"][sample] = set([])
+                cand["sample_contigs"][sample] = set([])
+            cand["samples"].add(sample)
+            cand["positions_A"]["start"].append(rec[8])
+            cand["positions_A"]["end"].append(rec[9])
+            cand["positions_B"]["start"].append(rec[10])
+            cand["positions_B"]["end"].append(rec[11])
+            name = _KIND[kind]
+            cand[name].add(qname)
+            cand["positions_A"][name].append(int(rec[3]))
+            cand["positions_A"]["orientation_" + name].append(rec[4])
+            cand["positions_B"][name].append(int(rec[5]))
+            cand["positions_B"]["orientation_" + name].append(rec[6])
+            cand["sample_" + name][sample].add(qname)
+
+    for chrA in candidates:
+        for chrB in candidates[chrA]:
+            for cand in candidates[chrA][chrB].values():
+                cand["N_discordants"] = len(cand["discordants"])
+                cand["N_splits"] = len(cand["splits"])
+                cand["N_contigs"] = len(cand["contigs"])
+                A, B = cand["positions_A"], cand["positions_B"]
+                if cand["N_splits"] and min_reads <= cand["N_splits"]:      # enough split reads: their mode (:266-268)
+                    cand["posA"], cand["posB"] = _mode(A["splits"]), _mode(B["splits"])
+                elif cand["N_contigs"]:
+                    cand["posA"], cand["posB"] = _mode(A["contigs"]), _mode(B["contigs"])
+                elif cand["N_splits"]:
+                    cand["posA"], cand["posB"] = _mode(A["splits"]), _mode(B["splits"])
+                else:
+                    cand["posA"], cand["posB"] = _breakpoints_from_discordants(cand, is_mp)
+                cand["startB"] = min(B["start"])
+                cand["endB"] = max(B["end"])
+                cand["startA"] = min(A["start"])
+                cand["endA"] = max(A["end"])
+    return candidates
