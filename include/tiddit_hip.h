@@ -107,6 +107,19 @@ int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, si
 int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
                     double eps, int m, uint32_t *perm_out, double *labels_out);
 
+/* ---- alignment-record decode (host) ---------------------------------------------------------- *
+ * Replaces the per-read pysam attribute access that feeds the path (read.reference_start,
+ * reference_end, mapq, flag, next_reference_id, next_reference_start, isize, cigartuples[0]/[-1],
+ * has_tag("SA") — __main__.py:229-240, tiddit_signal.pyx:169-221).  `buf` is uncompressed BAM record
+ * data (after the header), starting at a record boundary.  Decodes up to max_records whole records into
+ * the caller's arrays (any output pointer may be NULL); *consumed = bytes of whole records decoded.
+ * end = htslib bam_endpos(); cigar_first/cigar_last = raw (len<<4|op) words or 0xffffffff without CIGAR;
+ * rec_off = byte offset of each record (at its block_size field); sa_off = offset of the SA:Z string or -1. */
+int tdt_bam_decode(const uint8_t *buf, size_t len, size_t max_records, size_t *consumed, size_t *n_records,
+                   int32_t *tid, int32_t *pos, int32_t *end, uint8_t *mapq, uint16_t *flag, int32_t *mate_tid,
+                   int32_t *mate_pos, int32_t *tlen, int32_t *l_seq, uint32_t *cigar_first, uint32_t *cigar_last,
+                   uint64_t *rec_off, int64_t *sa_off);
+
 #ifdef __cplusplus
 }
 #endif

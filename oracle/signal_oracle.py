@@ -1,0 +1,279 @@
+"""Literal per-read restatement of tiddit_signal.pyx (worker :147-228, main :230-334) and of the
+`tiddit --cov` loop (__main__.py:225-242).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED at the BAM-decode boundary: the reference reads alignments through pysam/htslib, which
+cannot be installed here, so this restatement defines the record attributes itself (an independent
+pure-Python BAM parser below; reference_end = htslib bam_endpos; query_alignment_start = leading soft
+clip) and follows the reference's control flow line by line from there.  It cross-checks the product's C
+decoder + vectorised predicates; it is not a substitute for a pysam-backed run.
+"""
+import itertools
+import struct
+import zlib
+
+import numpy as np
+
+import oracle
+
+_SEQ = "=ACMGRSVTWYHKDBN"
+
+
+class Read:
+    pass
+
+
+def parse_bam(path):
+    """-> (header dict, list of Read) — independent of tiddit_amd.bamio"""
+    raw = bytearray()
+    with open(path, "rb") as f:
+        data = f.read()
+    o = 0
+    while o < len(data):
+        xlen = struct.unpack_from("<H", data, o + 10)[0]
+        bsize = struct.unpack_from("<H", data, o + 16)[0]
+        cdata = data[o + 12 + xlen:o + bsize + 1 - 8]
+        raw += zlib.decompress(bytes(cdata), -15) if cdata else b""
+        o += bsize + 1
+    raw = bytes(raw)
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text].split(b"\x00")[0].decode()
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    sq = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", raw, o)[0]
+        name = raw[o + 4:o + 4 + ln - 1].decode()
+        sq.append({"SN": name, "LN": struct.unpack_from("<i", raw, o + 4 + ln)[0]})
+        o += 8 + ln
+    header = {"SQ": sq}
+    for line in text.split("\n"):
+        if line.startswith("@RG"):
+            header.setdefault("RG", []).append(dict(f.split(":", 1) for f in line.split("\t")[1:] if ":" in f))
+    reads = []
+    while o < len(raw):
+        bs = struct.unpack_from("<i", raw, o)[0]
+        tid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", raw, o + 4)
+        p = o + 36
+        r = Read()
+        r.query_name = raw[p:p + l_name - 1].decode()
+        p += l_name
+        r.cigartuples = [(w & 0xf, w >> 4) for w in struct.unpack_from("<%dI" % n_cig, raw, p)]
+        p += 4 * n_cig
+        seq = []
+        for i in range(l_seq):
+            b = raw[p + i // 2]
+            seq.append(_SEQ[(b >> 4) if i % 2 == 0 else (b & 0xf)])
+        r.query_sequence = "".join(seq)
+        p += (l_seq + 1) // 2 + l_seq
+        r.tags = {}
+        end = o + 4 + bs
+        while p < end:
+            tag, typ = raw[p:p + 2].decode(), chr(raw[p + 2])
+            p += 3
+            if typ == "Z":
+                e = raw.index(b"\x00", p)
+                r.tags[tag] = raw[p:e].decode()
+                p = e + 1
+            elif typ == "i":
+                r.tags[tag] = struct.unpack_from("<i", raw, p)[0]
+                p += 4
+            elif typ == "A":
+                r.tags[tag] = chr(raw[p])
+                p += 1
+            else:
+                raise ValueError("tag type " + typ)
+        r.flag, r.mapq, r.isize = flag, mapq, tlen
+        r.is_unmapped, r.is_duplicate = bool(flag & 0x4), bool(flag & 0x400)
+        r.is_supplementary, r.is_secondary = bool(flag & 0x800), bool(flag & 0x100)
+        r.mate_is_unmapped, r.is_paired, r.is_reverse = bool(flag & 0x8), bool(flag & 0x1), bool(flag & 0x10)
+        r.reference_id, r.next_reference_id = tid, mtid
+        r.mate_pos = mpos
+        r.reference_name = sq[tid]["SN"] if tid >= 0 else None
+        r.next_reference_name = sq[mtid]["SN"] if mtid >= 0 else None
+        r.reference_start = pos
+        rlen = sum(l for op, l in r.cigartuples if op in (0, 2, 3, 7, 8))
+        r.reference_end = pos + (rlen if (rlen and not r.is_unmapped) else 1)       # bam_endpos
+        qs = 0
+        for op, l in r.cigartuples:
+            if op == 5:
+                continue
+            if op == 4:
+                qs += l
+            else:
+                break
+        r.query_alignment_start = qs
+        reads.append(r)
+        o = end
+    return header, reads
+
+
+def cov_main(header, reads, z, q):
+    """__main__.py:225-242 -> dict contig -> float64 bins"""
+    cov, ebs = {}, {}
+    for c in header["SQ"]:
+        cov[c["SN"]], ebs[c["SN"]] = oracle.create_coverage(c["LN"], z)
+    for read in reads:
+        if read.is_unmapped or read.is_duplicate:
+            continue
+        if read.mapq >= q:
+            oracle.update_coverage(read.reference_start, read.reference_end, z, cov[read.reference_name], ebs[read.reference_name])
+    return cov
+
+
+def _find_SA_query_range(SA):            # tiddit_signal.pyx:11-29
+    SC = ["".join(x) for _, x in itertools.groupby(SA[3], key=str.isdigit)]
+    s_to_op = {"M": 0, "S": 4, "H": 5, "D": 2, "I": 1}
+    cig = [(s_to_op[SC[i * 2 + 1]], int(SC[i * 2])) for i in range(0, int(len(SC) / 2))]
+    a = Read()
+    a.reference_start = int(SA[1])
+    ref = sum(l for op, l in cig if op in (0, 2))
+    a.reference_end = a.reference_start + (ref if ref else 1)
+    qs = 0
+    for op, l in cig:
+        if op == 5:
+            continue
+        if op == 4:
+            qs += l
+        else:
+            break
+    a.query_alignment_start = qs
+    a.query_alignment_end = qs + sum(l for op, l in cig if op in (0, 1))
+    return a
+
+
+def _SA_analysis(read, min_q, reference_name):      # tiddit_signal.pyx:31-145, statement by statement
+    sas = read.tags["SA"].rstrip(";").split(";")
+    if len(sas) > 1:
+        SA_lengths, ok_q = [], []
+        for i in range(0, len(sas)):
+            SA_data = sas[0].split(",")
+            if int(SA_data[4]) >= min_q:
+                ok_q.append(i)
+                s = _find_SA_query_range(SA_data)
+                SA_lengths.append(s.query_alignment_end - s.query_alignment_start)
+        longest = 0
+        for i in range(0, len(ok_q)):
+            if SA_lengths[i] > SA_lengths[longest]:
+                longest = i
+        if len(ok_q) == 0:
+            return ()
+        elif len(ok_q) == 1:
+            sas[0] = sas[ok_q[0]]
+        else:
+            sas[0] = sas[longest]
+    SA_data = sas[0].split(",")
+    if int(SA_data[4]) < min_q:
+        return ()
+    clip_before = False
+    s = _find_SA_query_range(SA_data)
+    if s.query_alignment_start < read.query_alignment_start:
+        clip_before = True
+    if not clip_before:
+        split_pos = read.reference_start + 1 if read.is_reverse else read.reference_end + 1
+    else:
+        split_pos = read.reference_end + 1 if read.is_reverse else read.reference_start + 1
+    SA_chr = SA_data[0]
+    startA, endA = read.reference_start + 1, read.reference_end + 1
+    startB, endB = s.reference_start, s.reference_end
+    if clip_before:
+        SA_split_pos = s.reference_start if SA_data[2] == "-" else s.reference_end
+    else:
+        SA_split_pos = s.reference_end if SA_data[2] == "-" else s.reference_start
+    if SA_chr < reference_name:
+        chrA, chrB = SA_chr, reference_name
+        split_pos, SA_split_pos = SA_split_pos, split_pos
+        startB, endB = read.reference_start + 1, read.reference_end + 1
+        startA, endA = s.reference_start, s.reference_end
+    else:
+        chrA, chrB = reference_name, SA_chr
+        if chrA == chrB:
+            if SA_split_pos < split_pos:
+                split_pos, SA_split_pos = SA_split_pos, split_pos
+                startB, endB = read.reference_start + 1, read.reference_end + 1
+                startA, endA = s.reference_start, s.reference_end
+    return [chrA, chrB, read.query_name, split_pos, read.is_reverse, SA_split_pos, "-" == SA_data[2], startA, endA, startB, endB]
+
+
+def signal_main(header, reads, min_q, max_ins, sample_id, min_contig, min_anchor_len, min_clip_len):
+    """-> (coverage dict, discordants.tab text, splits.tab text, clips.fa text, per-contig clip texts)"""
+    bin_size = 50
+    chromosomes = [c["SN"] for c in header["SQ"] if c["LN"] >= min_contig]
+    data = {a: {b["SN"]: {} for b in header["SQ"]} for a in chromosomes}
+    splits = {a: {b["SN"]: {} for b in header["SQ"]} for a in chromosomes}
+    coverage_data, clip_texts = {}, {}
+    res = []
+    for chromosome in chromosomes:           # worker(), one contig at a time
+        LN = [c["LN"] for c in header["SQ"] if c["SN"] == chromosome][0]
+        cov, ebs = oracle.create_coverage(LN, bin_size)
+        clips, d, sp = [], [], []
+        for read in reads:
+            if read.reference_name != chromosome:
+                continue
+            if read.is_unmapped or read.is_duplicate:
+                continue
+            read_chromosome, mate_chromosome = read.reference_name, read.next_reference_name
+            if read.mapq >= min_q:
+                oracle.update_coverage(read.reference_start, read.reference_end, bin_size, cov, ebs)
+            if read.is_supplementary or read.is_secondary:
+                continue
+            if read.mapq < min_q:
+                continue
+            if abs(read.isize) < max_ins and mate_chromosome == read_chromosome:
+                ct = read.cigartuples
+                if (ct[0][0] == 4 and ct[0][1] > min_clip_len) and (ct[-1][0] == 0 and ct[-1][1] > min_anchor_len):
+                    clips.append([">{}|{}|{}\n".format(read.query_name, read_chromosome, read.reference_start + 1), read.query_sequence + "\n"])
+                elif ct[-1][0] == 4 and ct[-1][1] > min_clip_len and (ct[0][0] == 0 and ct[0][1] > min_anchor_len):
+                    clips.append([">{}|{}|{}\n".format(read.query_name, read_chromosome, read.reference_start + 1), read.query_sequence + "\n"])
+            if "SA" in read.tags:
+                split = _SA_analysis(read, min_q, read_chromosome)
+                if split:
+                    sp.append(split)
+            if read.mate_is_unmapped:
+                continue
+            if not read.is_paired:
+                continue
+            if abs(read.isize) > max_ins or mate_chromosome != read_chromosome:
+                if mate_chromosome < read_chromosome:
+                    chrA, chrB = mate_chromosome, read_chromosome
+                else:
+                    chrA, chrB = read_chromosome, mate_chromosome
+                d.append([chrA, chrB, read.query_name, read.reference_start + 1, read.reference_end + 1, read.is_reverse, read_chromosome])
+        clip_texts[chromosome] = "".join("".join(c) for c in clips)
+        res.append((chromosome, d, sp, cov))
+    for chromosome, d, sp, cov in res:
+        coverage_data[chromosome] = cov
+        for signal in d:
+            if signal[0] not in data:
+                continue
+            data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
+        for signal in sp:
+            if signal[0] not in splits:
+                continue
+            splits[signal[0]][signal[1]].setdefault(signal[2], [])
+            splits[signal[0]][signal[1]][signal[2]] += signal[3:]
+    disc_txt = []
+    for chrA in data:
+        for chrB in data[chrA]:
+            for fragment in data[chrA][chrB]:
+                fr = data[chrA][chrB][fragment]
+                if len(fr) < 2:
+                    continue
+                if chrA == chrB:
+                    if fr[1][-1] < fr[0][-1]:
+                        out = fr[1][0:-1] + fr[0][0:-1]
+                    else:
+                        out = fr[0][0:-1] + fr[1][0:-1]
+                else:
+                    if fr[0][-1] == chrA:
+                        out = fr[0][0:-1] + fr[1][0:-1]
+                    else:
+                        out = fr[1][0:-1] + fr[0][0:-1]
+                disc_txt.append("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, out))))
+    split_txt = []
+    for chrA in splits:
+        for chrB in splits[chrA]:
+            for fragment in splits[chrA][chrB]:
+                split_txt.append("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, splits[chrA][chrB][fragment]))))
+    return coverage_data, "".join(disc_txt), "".join(split_txt), "".join(clip_texts[c] for c in chromosomes), clip_texts

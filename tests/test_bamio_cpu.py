@@ -1,0 +1,63 @@
+"""Host-side format code (CPU): BGZF/BAM writer -> C record decoder round trip, checked against the
+independent pure-Python parser of oracle/signal_oracle.py; FASTA index reader."""
+import numpy as np
+import pytest
+
+from oracle import signal_oracle
+from tiddit_amd import bamio, build, synth, synth_bam
+from tiddit_amd.fasta import FastaFile
+
+
+@pytest.fixture(scope="module")
+def bam(tmp_path_factory):
+    build.build()
+    p = str(tmp_path_factory.mktemp("bam") / "syn.bam")
+    info = synth_bam.write_synthetic_bam(p, [("chr1", 60000), ("chr2", 40000), ("chrM", 3000), ("tiny", 500)], depth=6, seed=3)
+    return p, info
+
+
+def test_bam_roundtrip_against_independent_parser(bam):
+    path, info = bam
+    hdr, reads = signal_oracle.parse_bam(path)
+    rd = bamio.BamReader(path, batch_bytes=200_000)      # small batches: records straddle batch boundaries
+    assert rd.header["SQ"] == hdr["SQ"] and rd.header["RG"][0]["SM"] == "SYN"
+    k = 0
+    nb = 0
+    for b in rd.batches():
+        nb += 1
+        for i in range(len(b)):
+            r = reads[k]
+            assert (b.tid[i], b.pos[i], b.end[i], b.mapq[i], b.flag[i], b.mate_tid[i], b.tlen[i]) == \
+                (r.reference_id, r.reference_start, r.reference_end, r.mapq, r.flag, r.next_reference_id, r.isize), k
+            assert (int(b.sa_off[i]) >= 0) == ("SA" in r.tags)
+            if k % 37 == 0 or "SA" in r.tags:
+                v = b.record(i)
+                assert v.query_name == r.query_name and v.cigartuples == r.cigartuples and v.query_sequence == r.query_sequence
+                if "SA" in r.tags:
+                    assert v.get_tag_sa() == r.tags["SA"]
+            if r.cigartuples:
+                assert (int(b.cigar_first[i]) & 0xf, int(b.cigar_first[i]) >> 4) == r.cigartuples[0]
+                assert (int(b.cigar_last[i]) & 0xf, int(b.cigar_last[i]) >> 4) == r.cigartuples[-1]
+            else:
+                assert b.cigar_first[i] == 0xffffffff
+            k += 1
+    assert k == len(reads) == info["n_records"] and nb > 3
+    # coordinate sorted
+    keys = [(r.reference_id, r.reference_start) for r in reads]
+    assert keys == sorted(keys)
+
+
+def test_fasta_reader(tmp_path):
+    fa = tmp_path / "r.fa"
+    seqs = {"a": synth.gen_sequence(1234, seed=1), "b": synth.gen_sequence(60, seed=2), "c": synth.gen_sequence(61, seed=3)}
+    with open(fa, "w") as f:
+        for n, s in seqs.items():
+            f.write(">%s desc\n" % n)
+            t = s.tobytes().decode()
+            f.write("\n".join(t[i:i + 60] for i in range(0, len(t), 60)) + "\n")
+    ff = FastaFile(str(fa))
+    assert ff.references == ["a", "b", "c"]
+    for n, s in seqs.items():
+        assert ff.get_reference_length(n) == len(s)
+        assert np.array_equal(ff.fetch_array(n), s)
+    assert ff.fetch("a", 100, 150) == seqs["a"][100:150].tobytes().decode()

@@ -1,0 +1,147 @@
+"""GPU tests of the callers either side of the kernels: `tiddit --cov` (BASELINE configs[0]),
+tiddit_signal.main and `tiddit --sv --skip_assembly` on synthetic BAMs, against the per-read literal
+restatement in oracle/signal_oracle.py and the golden .bed/.wig checksums of the real reference."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import signal_oracle
+from tiddit_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+CONTIGS = [("chr1", 90000), ("chr10", 70000), ("chr2", 80000), ("chrM", 6000), ("tiny", 500)]
+
+
+@pytest.fixture(scope="module")
+def sv_bam(tmp_path_factory):
+    from tiddit_amd import synth_bam
+    d = tmp_path_factory.mktemp("sv")
+    p = str(d / "SYN.bam")
+    info = synth_bam.write_synthetic_bam(p, CONTIGS, depth=8, seed=11, n_events=14)
+    fa = str(d / "ref.fa")
+    with open(fa, "w") as f:
+        for i, (n, l) in enumerate(CONTIGS):
+            s = synth.gen_sequence(l, seed=100 + i).tobytes().decode()
+            f.write(">%s\n" % n + "\n".join(s[k:k + 70] for k in range(0, l, 70)) + "\n")
+    return p, fa, info, d
+
+
+def test_cli_cov_config1_bed_and_wig_sha(golden_dir, tmp_path):
+    """BASELINE configs[0]: `tiddit --cov` on the 1 Mb / 10x single-contig stream, -z 500 (q 20)."""
+    from tiddit_amd import __main__ as cli
+    from tiddit_amd.bamio import BamWriter
+    g = json.load(open(os.path.join(golden_dir, "coverage.json")))["config1"]["cov"]
+    start, end, mapq, flag = synth.gen_reads(1_000_000, 10)
+    bam = str(tmp_path / "c1.bam")
+    w = BamWriter(bam, [("chrS", 1_000_000)])
+    for i in range(len(start)):
+        ref = int(end[i] - start[i])
+        cig = "%dM" % ref if ref >= 150 else "%dS%dM" % (150 - ref, ref)
+        if ref > 150:
+            cig = "75M%dD75M" % (ref - 150)
+        w.write("r%d" % i, int(flag[i]), 0, int(start[i]), int(mapq[i]), cig, 0, int(start[i]), 0, seq="")
+    w.close()
+    out = str(tmp_path / "cov")
+    cli.main(["--cov", "--bam", bam, "-o", out, "-z", "500"])
+    assert hashlib.sha256(open(out + ".bed", "rb").read()).hexdigest() == g["bed_sha256"]
+    cli.main(["--cov", "--bam", bam, "-o", out, "-z", "500", "-w"])
+    assert hashlib.sha256(open(out + ".wig", "rb").read()).hexdigest() == g["wig_sha256"]
+
+
+def test_cli_cov_multi_contig_vs_oracle(sv_bam, tmp_path):
+    from tiddit_amd import __main__ as cli, tiddit_coverage
+    bam, fa, info, d = sv_bam
+    hdr, reads = signal_oracle.parse_bam(bam)
+    want = signal_oracle.cov_main(hdr, reads, 500, 20)
+    out = str(tmp_path / "o")
+    cli.main(["--cov", "--bam", bam, "-o", out])
+    ref_bed = str(tmp_path / "ref.bed")
+    tiddit_coverage.print_coverage(want, hdr, 500, "bed", ref_bed)     # formatting only; values come from the oracle
+    assert open(out + ".bed").read() == open(ref_bed).read()
+
+
+def test_signal_main_vs_literal_restatement(sv_bam, tmp_path):
+    from tiddit_amd import tiddit_signal
+    bam, fa, info, d = sv_bam
+    hdr, reads = signal_oracle.parse_bam(bam)
+    for min_q, max_ins, min_contig in ((5, 600, 10000), (20, 450, 1000)):
+        prefix = str(tmp_path / ("s%d" % min_q))
+        os.makedirs(prefix + "_tiddit/clips")
+        cov = tiddit_signal.main(bam, fa, prefix, min_q, max_ins, "SYN", 1, min_contig, False, 60, 25)
+        wcov, wdisc, wsplit, wclips, wclip_each = signal_oracle.signal_main(hdr, reads, min_q, max_ins, "SYN", min_contig, 60, 25)
+        assert list(cov) == list(wcov)
+        for c in wcov:
+            assert np.array_equal(cov[c], wcov[c]), c
+        assert open(prefix + "_tiddit/discordants_SYN.tab").read() == wdisc
+        assert open(prefix + "_tiddit/splits_SYN.tab").read() == wsplit
+        assert open(prefix + "_tiddit/clips_SYN.fa").read() == wclips
+        for c, txt in wclip_each.items():
+            assert open(prefix + "_tiddit/clips/%s.fa" % c).read() == txt
+        assert wdisc.count("\n") > 50 and wsplit.count("\n") > 10 and wclips.count(">") > 10
+
+
+def test_stats_vs_per_read_loop(sv_bam):
+    from tiddit_amd import tiddit_stats
+    bam, fa, info, d = sv_bam
+    hdr, reads = signal_oracle.parse_bam(bam)
+    for n_reads in (100000, 777):
+        lib = tiddit_stats.statistics(bam, fa, 5, 100000, n_reads)
+        # tiddit_stats.py:17-47, read by read
+        rl, ins, innie, outtie, ns = [], [], 0, 0, 0
+        for r in reads:
+            if r.reference_id < 0:
+                continue
+            rl.append(len(r.query_sequence))
+            ns += 1
+            if ns > n_reads:
+                break
+            if r.mate_is_unmapped or r.is_reverse == bool(r.flag & 0x20):
+                continue
+            if r.next_reference_name != r.reference_name or r.isize > 100000:
+                continue
+            if r.next_reference_id < 0 or r.flag is None:
+                continue
+            mpos = None
+            ins_ok = True
+            # next_reference_start < reference_start -> skip
+            import struct  # noqa: F401
+            if r.mate_pos < r.reference_start:
+                continue
+            if r.is_supplementary or r.is_secondary or r.is_duplicate or r.mapq < 5:
+                continue
+            ins.append(r.isize)
+            if r.is_reverse and not (r.flag & 0x20):
+                outtie += 1
+            else:
+                innie += 1
+        assert lib["avg_read_length"] == np.average(rl)
+        assert lib["avg_insert_size"] == np.average(ins) and lib["std_insert_size"] == np.std(ins)
+        assert lib["percentile_insert_size"] == np.percentile(ins, 99.9)
+        assert lib["mp"] == (not innie > outtie)
+
+
+def test_cli_sv_skip_assembly_end_to_end(sv_bam, tmp_path):
+    from tiddit_amd import __main__ as cli
+    bam, fa, info, d = sv_bam
+    out = str(tmp_path / "svrun")
+    cli.main(["--sv", "--bam", bam, "--ref", fa, "-o", out, "--skip_assembly", "--min_contig", "5000"])
+    for f in ("_tiddit/discordants_SYN.tab", "_tiddit/splits_SYN.tab", "_tiddit/clips_SYN.fa", ".ploidies.tab", ".candidates.tab"):
+        assert os.path.isfile(out + f), f
+    rows = [l.split("\t") for l in open(out + ".candidates.tab") if not l.startswith("#")]
+    assert len(rows) >= 5
+    found = 0
+    for ev in info["events"]:
+        if ev["type"] == "DEL":
+            for r in rows:
+                if r[0] == ev["chrom"] and r[2] == ev["chrom"] and abs(int(r[1]) - ev["start"]) < 400 and abs(int(r[3]) - ev["end"]) < 400:
+                    found += 1
+                    break
+    n_del = sum(1 for ev in info["events"] if ev["type"] == "DEL")
+    assert found >= n_del - 1, (found, n_del)
+    plo = open(out + ".ploidies.tab").read().splitlines()
+    assert plo[0] == "Chromosome\tPloidy\tPloidy_rounded\tMean_coverage" and len(plo) >= 4

@@ -1,0 +1,211 @@
+"""``tiddit`` command line on the MI355X hot path: ``python -m tiddit_amd --cov ...`` / ``--sv ...``.
+
+Same two modes and the same flags as the reference driver (tiddit/__main__.py:22-71, :211-219).
+``--cov`` is complete (byte-identical .bed/.wig for the same alignments).  ``--sv`` runs the stages this
+repository implements — library statistics, signal extraction + coverage (device), GC (device), ploidy,
+clustering (device) — and writes the signal ``.tab`` files, ``{o}.ploidies.tab`` and
+``{o}.candidates.tab``.  Variant typing / filtering / VCF (tiddit_variant.pyx) and local assembly are out
+of scope: if the reference package is importable its ``tiddit_variant`` is handed the
+candidates, otherwise the run stops after the candidates table and says so.
+"""
+import argparse
+import os
+import sys
+import time
+
+
+def _sv_parser():
+    p = argparse.ArgumentParser("""tiddit --sv --bam inputfile [-o prefix] --ref ref.fasta""")
+    p.add_argument("--sv", help="call structural variation", required=False, action="store_true")
+    p.add_argument("--force_overwrite", help="force the analysis and overwrite any data in the output folder", required=False, action="store_true")
+    p.add_argument("--bam", type=str, required=True, help="coordinate sorted bam file(required)")
+    p.add_argument("--ref", type=str, help="reference fasta", required=True)
+    p.add_argument("-o", type=str, default="output", help="output prefix(default=output)")
+    p.add_argument("-i", type=int, help="paired reads maximum allowed insert size (default= 99.9th percentile of insert size)")
+    p.add_argument("-d", type=str, help="expected reads orientations, possible values \"innie\" (-> <-) or \"outtie\" (<- ->)")
+    p.add_argument("-p", type=int, default=3, help="Minimum number of supporting pairs in order to call a variant (default 3)")
+    p.add_argument("--threads", type=int, default=1, help="Number of threads (default=1)")
+    p.add_argument("-r", type=int, default=3, help="Minimum number of supporting split reads to call a variant (default 3)")
+    p.add_argument("-q", type=int, default=5, help="Minimum mapping quality to consider an alignment (default 5)")
+    p.add_argument("-n", type=int, default=2, help="the ploidy of the organism,(default = 2)")
+    p.add_argument("-e", type=int, help="clustering distance parameter (default = half the average insert size)")
+    p.add_argument("-c", type=float, help="average coverage, overwrites the estimated average coverage")
+    p.add_argument("-l", type=int, default=3, help="min-pts parameter (default=3),must be set >= 2")
+    p.add_argument("-s", type=int, default=25000000, help="Number of reads to sample when computing library statistics(default=25000000)")
+    p.add_argument("--force_ploidy", action="store_true", help="force the ploidy to be set to -n across the entire genome")
+    p.add_argument("--n_mask", type=float, default=0.5, help="exclude regions from coverage calculation if they contain more than this fraction of N (default = 0.5)")
+    p.add_argument("--p_ratio", type=float, default=0.1, help="minimum discordant pair/normal pair ratio at the breakpoint junction(default=0.1)")
+    p.add_argument("--r_ratio", type=float, default=0.1, help="minimum split read/coverage ratio at the breakpoint junction(default=0.1)")
+    p.add_argument("--max_coverage", type=float, default=4, help="filter call if X times higher than chromosome average coverage (default=4)")
+    p.add_argument("--min_contig", type=int, default=10000, help="Skip calling on small contigs (default < 10000 bp)")
+    p.add_argument("-z", type=int, default=50, help="minimum variant size (default=50)")
+    p.add_argument("--skip_assembly", action="store_true", help="Skip running local assembly")
+    p.add_argument("--bwa", type=str, default="bwa", help="path to bwa executable file(default=bwa)")
+    p.add_argument("--min_clip", type=int, default=4, help="Minimum clip reads to initiate local assembly of a region(default=4)")
+    p.add_argument("--padding", type=int, default=100, help="Extend the local assembly by this number of bases (default=100bp)")
+    p.add_argument("--min_pts_clips", type=int, default=3, help="min-pts parameter for the clustering of candidates for local assembly (default=3)")
+    p.add_argument("--max_assembly_reads", type=int, default=100000, help="Skip assembly of regions containing too many reads")
+    p.add_argument("--max_local_assembly_region", type=int, default=2000, help="maximum size of the clip read cluster for local assembly")
+    p.add_argument("--min_anchor_len", type=int, default=60, help="minimum mapped bases to be considered a clip read  (default=60 bp)")
+    p.add_argument("--min_clip_len", type=int, default=25, help="minimum clipped bases to be considered a clip read (default=25 bp)")
+    p.add_argument("--min_contig_len", type=int, default=200, help="minimum contig length for SV analysis (default=200 bp)")
+    p.add_argument("-k", type=int, default=91, help="kmer lenght used by the local assembler (default=91 bp)")
+    return p
+
+
+def _cov_parser():
+    p = argparse.ArgumentParser("""tiddit --cov --bam inputfile [-o prefix]""")
+    p.add_argument("--cov", help="generate a coverage bed/wig file", required=False, action="store_true")
+    p.add_argument("--bam", type=str, required=True, help="coordinate sorted bam file(required)")
+    p.add_argument("-o", type=str, default="output", help="output prefix(default=output)")
+    p.add_argument("-z", type=int, default=500, help="use bins of specified size(default = 500bp) to measure the coverage of the entire bam file")
+    p.add_argument("-w", help="generate wig instead of bed", required=False, action="store_true")
+    p.add_argument("-q", type=int, help="minimum mapping quality(default=20)", required=False, default=20)
+    p.add_argument("--ref", type=str, help="reference fasta, used for reading cram")
+    return p
+
+
+def run_cov(args):
+    from . import tiddit_coverage
+    from .bamio import BamReader
+    if not os.path.isfile(args.bam):
+        print("error,  could not find the bam file")
+        quit()
+    reader = BamReader(args.bam)
+    bam_header = reader.header
+    coverage_data, end_bin_size = tiddit_coverage.create_coverage(bam_header, args.z)
+    hist = tiddit_coverage.CoverageHistogram(bam_header, args.z)
+    import numpy
+    for b in reader.batches():
+        tid = b.tid
+        edges = numpy.flatnonzero(numpy.diff(tid)) + 1
+        for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
+            if tid[lo] >= 0:
+                hist.push(int(tid[lo]), b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], args.q)
+    reader.close()
+    for contig in coverage_data:
+        coverage_data[contig] = hist.finish(contig)
+    hist.close()
+    if args.w:
+        tiddit_coverage.print_coverage(coverage_data, bam_header, args.z, "wig", args.o + ".wig")
+    else:
+        tiddit_coverage.print_coverage(coverage_data, bam_header, args.z, "bed", args.o + ".bed")
+
+
+def write_candidates(path, contigs, sv_clusters):
+    with open(path, "w") as f:
+        f.write("#chrA\tposA\tchrB\tposB\tcluster\tN_discordants\tN_splits\tN_contigs\tstartA\tendA\tstartB\tendB\n")
+        for chrA in contigs:
+            if chrA not in sv_clusters:
+                continue
+            for chrB in sv_clusters[chrA]:
+                for cid, c in sv_clusters[chrA][chrB].items():
+                    f.write("\t".join(map(str, [chrA, c["posA"], chrB, c["posB"], cid, c["N_discordants"], c["N_splits"], c["N_contigs"],
+                                                c["startA"], c["endA"], c["startB"], c["endB"]])) + "\n")
+
+
+def run_sv(args, version):
+    from . import tiddit_cluster, tiddit_coverage_analysis, tiddit_gc, tiddit_signal, tiddit_stats
+    from .bamio import BamReader
+    from .fasta import FastaFile
+    if args.l < 2:
+        print("error, too low --l value!")
+        quit()
+    if not args.skip_assembly:
+        print("error, local assembly is outside this build's scope; rerun with --skip_assembly")
+        quit()
+    if not os.path.isfile(args.ref):
+        print("error,  could not find the reference file")
+        quit()
+    FastaFile(args.ref)          # builds ref.fai when it is missing (pysam.faidx in the reference)
+    if not (args.bam.endswith(".bam") or args.bam.endswith(".cram")):
+        print("error, the input file is not a bam file, make sure that the file extension is .bam or .cram")
+        quit()
+    if args.bam.endswith(".cram"):
+        print("error, CRAM input is not supported by this build (BAM only)")
+        quit()
+    if not os.path.isfile(args.bam):
+        print("error,  could not find the bam file")
+        quit()
+    reader = BamReader(args.bam)
+    bam_header = reader.header
+    reader.close()
+    chromosomes = [c["SN"] for c in bam_header["SQ"]]
+    try:
+        sample_id = bam_header["RG"][0]["SM"]
+    except Exception:
+        sample_id = args.bam.split("/")[-1].split(".")[0]
+    samples = [sample_id]
+    contigs = list(chromosomes)
+    contig_number = {c: i for i, c in enumerate(contigs)}
+    contig_length = {c["SN"]: c["LN"] for c in bam_header["SQ"]}
+    prefix = args.o
+    try:
+        os.mkdir("{}_tiddit".format(prefix))
+        os.mkdir("{}_tiddit/clips".format(prefix))
+    except Exception:
+        if not args.force_overwrite:
+            print("Eror output folder exists")
+            quit()
+    min_mapq = args.q
+    max_ins_len = 100000
+    library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s)
+    max_ins_len = args.i if args.i else library["percentile_insert_size"]
+
+    t = time.time()
+    coverage_data = tiddit_signal.main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
+                                       False, args.min_anchor_len, args.min_clip_len)
+    print("extracted signals in:")
+    print(t - time.time())
+    gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
+    t = time.time()
+    library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,
+                                                        bam_header, gc_dictionary)
+    print("calculated coverage in:")
+    print(time.time() - t)
+    if not args.e:
+        args.e = int(library["avg_insert_size"] / 2.0)
+    if not args.e:
+        args.e = 50
+    t = time.time()
+    sv_clusters = tiddit_cluster.main(prefix, contigs, contig_length, samples, library["mp"], args.e, args.l, max_ins_len, args.min_contig,
+                                      args.skip_assembly, args.r)
+    print("generated clusters in")
+    print(time.time() - t)
+    write_candidates(prefix + ".candidates.tab", contigs, sv_clusters)
+    try:
+        import tiddit.tiddit_variant as tiddit_variant          # the reference package, when installed next to us
+        import tiddit.tiddit_vcf_header as tiddit_vcf_header
+    except Exception:
+        print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
+        return
+    vcf_header = tiddit_vcf_header.main(bam_header, library, sample_id, version)
+    variants = tiddit_variant.main(args.bam, sv_clusters, args, library, min_mapq, samples, coverage_data, contig_number, max_ins_len,
+                                   gc_dictionary)
+    with open(prefix + ".vcf", "w") as f:
+        f.write(vcf_header + "\n")
+        for chrom in contigs:
+            if chrom not in variants:
+                continue
+            for variant in sorted(variants[chrom], key=lambda x: x[0]):
+                f.write("\t".join(variant[1]) + "\n")
+
+
+def main(argv=None):
+    version = "3.9.5"
+    if argv is not None:
+        sys.argv = [sys.argv[0]] + list(argv)
+    parser = argparse.ArgumentParser("""tiddit-{}""".format(version), add_help=False)
+    parser.add_argument("--sv", help="call structural variation", required=False, action="store_true")
+    parser.add_argument("--cov", help="generate a coverage bed file", required=False, action="store_true")
+    args, unknown = parser.parse_known_args()
+    if args.sv:
+        run_sv(_sv_parser().parse_args(), version)
+    elif args.cov:
+        run_cov(_cov_parser().parse_args())
+    else:
+        parser.print_help()
+
+
+if __name__ == "__main__":
+    main()

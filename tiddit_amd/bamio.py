@@ -1,0 +1,265 @@
+"""Minimal BGZF/BAM reader + writer (the reference reads alignments through pysam/htslib, which is not
+a dependency here).
+
+``BamReader.batches()`` inflates BGZF blocks with zlib and hands whole-record chunks to the C decoder
+``tdt_bam_decode`` (csrc/tdt_bam.hip), yielding struct-of-arrays batches: the packed
+start/end/mapq/flag arrays go straight to the coverage kernel, the mate fields drive the discordant-pair
+predicate, and the few reads that need string work (SA tags, clipped sequences, names) are pulled out of
+the raw record bytes with :class:`RecordView`.  ``BamWriter`` produces small coordinate-sorted BAMs for
+tests and synthetic configs.  Semantics follow the SAM/BAM spec v1; ``end`` is htslib ``bam_endpos``.
+"""
+import ctypes
+import struct
+import zlib
+
+import numpy as np
+
+from . import _native
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+CIGAR_OPS = "MIDNSHP=X"
+_SEQ_CODES = "=ACMGRSVTWYHKDBN"
+
+
+# ------------------------------------------------------------------------------------- BGZF
+def bgzf_blocks(f):
+    """yield the uncompressed payload of every BGZF block of an open binary file"""
+    while True:
+        hdr = f.read(12)
+        if len(hdr) < 12:
+            return
+        if hdr[0] != 0x1f or hdr[1] != 0x8b or not (hdr[3] & 4):
+            raise ValueError("not a BGZF file")
+        xlen = struct.unpack_from("<H", hdr, 10)[0]
+        extra = f.read(xlen)
+        bsize = None
+        o = 0
+        while o + 4 <= xlen:
+            si1, si2, slen = extra[o], extra[o + 1], struct.unpack_from("<H", extra, o + 2)[0]
+            if si1 == 66 and si2 == 67:
+                bsize = struct.unpack_from("<H", extra, o + 4)[0]
+            o += 4 + slen
+        if bsize is None:
+            raise ValueError("BGZF block without BC field")
+        cdata = f.read(bsize - xlen - 19)
+        f.read(8)  # crc32, isize
+        yield zlib.decompress(cdata, -15) if cdata else b""
+
+
+def _bgzf_block(data, level=6):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    bsize = len(comp) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + comp +
+            struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+# ------------------------------------------------------------------------------------ reader
+class RecordView:
+    """Lazy string-level access to ONE record of a batch (name, CIGAR, sequence, aux tags)."""
+
+    def __init__(self, batch, i):
+        self.batch, self.i = batch, i
+        self.raw = batch.raw
+        self.off = int(batch.rec_off[i]) + 4
+
+    def _u(self, fmt, o):
+        return struct.unpack_from(fmt, self.raw, self.off + o)[0]
+
+    @property
+    def query_name(self):
+        l = self._u("<B", 8)
+        return self.raw[self.off + 32:self.off + 32 + l - 1].decode()
+
+    @property
+    def cigartuples(self):
+        l_name, n = self._u("<B", 8), self._u("<H", 12)
+        words = struct.unpack_from("<%dI" % n, self.raw, self.off + 32 + l_name)
+        return [(w & 0xf, w >> 4) for w in words]
+
+    @property
+    def query_sequence(self):
+        l_name, n, lseq = self._u("<B", 8), self._u("<H", 12), self._u("<i", 16)
+        o = self.off + 32 + l_name + 4 * n
+        packed = np.frombuffer(self.raw, dtype=np.uint8, count=(lseq + 1) // 2, offset=o)
+        codes = np.empty(2 * len(packed), dtype=np.uint8)
+        codes[0::2] = packed >> 4
+        codes[1::2] = packed & 0xf
+        lut = np.frombuffer(_SEQ_CODES.encode(), dtype=np.uint8)
+        return lut[codes[:lseq]].tobytes().decode()
+
+    def get_tag_sa(self):
+        o = int(self.batch.sa_off[self.i])
+        if o < 0:
+            raise KeyError("SA")
+        e = self.raw.index(b"\x00", o)
+        return self.raw[o:e].decode()
+
+
+class Batch:
+    """Struct-of-arrays view of consecutive BAM records (numpy arrays of equal length)."""
+    __slots__ = ("raw", "tid", "pos", "end", "mapq", "flag", "mate_tid", "mate_pos", "tlen", "l_seq", "cigar_first",
+                 "cigar_last", "rec_off", "sa_off")
+
+    def __len__(self):
+        return len(self.pos)
+
+    def record(self, i):
+        return RecordView(self, i)
+
+
+class BamReader:
+    def __init__(self, path, batch_bytes=64 << 20):
+        self.path = path
+        self.batch_bytes = batch_bytes
+        self._f = open(path, "rb")
+        self._blocks = bgzf_blocks(self._f)
+        self._buf = bytearray()
+        self._read_header()
+
+    def _need(self, n):
+        while len(self._buf) < n:
+            try:
+                self._buf += next(self._blocks)
+            except StopIteration:
+                return False
+        return True
+
+    def _take(self, n):
+        if not self._need(n):
+            raise ValueError("truncated BAM")
+        out = bytes(self._buf[:n])
+        del self._buf[:n]
+        return out
+
+    def _read_header(self):
+        if self._take(4) != b"BAM\x01":
+            raise ValueError("not a BAM file")
+        l_text = struct.unpack("<i", self._take(4))[0]
+        self.text = self._take(l_text).split(b"\x00")[0].decode()
+        n_ref = struct.unpack("<i", self._take(4))[0]
+        self.references, self.lengths = [], []
+        for _ in range(n_ref):
+            l_name = struct.unpack("<i", self._take(4))[0]
+            self.references.append(self._take(l_name)[:-1].decode())
+            self.lengths.append(struct.unpack("<i", self._take(4))[0])
+        # pysam-style header dict (what create_coverage / the CLI read: header["SQ"][i]["SN"/"LN"], ["RG"][0]["SM"])
+        self.header = {"SQ": [{"SN": n, "LN": l} for n, l in zip(self.references, self.lengths)]}
+        for line in self.text.split("\n"):
+            if line.startswith("@RG"):
+                rg = {}
+                for field in line.split("\t")[1:]:
+                    if ":" in field:
+                        k, v = field.split(":", 1)
+                        rg[k] = v
+                self.header.setdefault("RG", []).append(rg)
+
+    def batches(self):
+        """yield :class:`Batch` objects of whole records, ~batch_bytes of record data each"""
+        lib = _native.load()
+        done = False
+        while not done:
+            while len(self._buf) < self.batch_bytes:
+                try:
+                    self._buf += next(self._blocks)
+                except StopIteration:
+                    done = True
+                    break
+            if not self._buf:
+                break
+            raw = bytes(self._buf)
+            cap = len(raw) // 36 + 1
+            b = Batch()
+            b.raw = raw
+            arrs = {"tid": np.int32, "pos": np.int32, "end": np.int32, "mapq": np.uint8, "flag": np.uint16, "mate_tid": np.int32,
+                    "mate_pos": np.int32, "tlen": np.int32, "l_seq": np.int32, "cigar_first": np.uint32, "cigar_last": np.uint32,
+                    "rec_off": np.uint64, "sa_off": np.int64}
+            for k, dt in arrs.items():
+                setattr(b, k, np.empty(cap, dtype=dt))
+            consumed, nrec = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            _native.check(lib.tdt_bam_decode(raw, len(raw), cap, ctypes.byref(consumed), ctypes.byref(nrec),
+                                             *[_native.ptr(getattr(b, k)) for k in arrs]))
+            n = nrec.value
+            for k in arrs:
+                setattr(b, k, getattr(b, k)[:n])
+            del self._buf[:consumed.value]
+            if n == 0:
+                if done and self._buf:
+                    raise ValueError("truncated BAM record at end of file")
+                continue
+            yield b
+
+    def close(self):
+        self._f.close()
+
+
+# ------------------------------------------------------------------------------------ writer
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def parse_cigar(cigar):
+    out, num = [], ""
+    for ch in cigar:
+        if ch.isdigit():
+            num += ch
+        else:
+            out.append((CIGAR_OPS.index(ch), int(num)))
+            num = ""
+    return out
+
+
+class BamWriter:
+    """Write a BAM from Python values (test / synthetic-config tooling)."""
+
+    def __init__(self, path, references, text=None, level=1):
+        self._f = open(path, "wb")
+        self._buf = bytearray()
+        self.level = level
+        self.references = [r[0] for r in references]
+        if text is None:
+            text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in references)
+        t = text.encode()
+        self._buf += b"BAM\x01" + struct.pack("<i", len(t)) + t + struct.pack("<i", len(references))
+        for name, ln in references:
+            nb = name.encode() + b"\x00"
+            self._buf += struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln)
+
+    def write(self, qname, flag, tid, pos, mapq, cigar, mate_tid, mate_pos, tlen, seq="", tags=()):
+        """pos 0-based; cigar = string or list of (op, len); tags = iterable of (tag, type, value) with type Z/i/A"""
+        cig = parse_cigar(cigar) if isinstance(cigar, str) else list(cigar)
+        rlen = sum(l for op, l in cig if op in (0, 2, 3, 7, 8)) or 1
+        name = qname.encode() + b"\x00"
+        lseq = len(seq)
+        codes = [_SEQ_CODES.index(c) if c in _SEQ_CODES else 15 for c in seq.upper()]
+        if lseq & 1:
+            codes.append(0)
+        packed = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+        aux = b""
+        for tag, typ, val in tags:
+            if typ == "Z":
+                aux += tag.encode() + b"Z" + val.encode() + b"\x00"
+            elif typ == "i":
+                aux += tag.encode() + b"i" + struct.pack("<i", val)
+            elif typ == "A":
+                aux += tag.encode() + b"A" + val.encode()
+            else:
+                raise ValueError("unsupported tag type " + typ)
+        body = (struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, _reg2bin(pos, pos + rlen), len(cig), flag, lseq, mate_tid,
+                            mate_pos, tlen) + name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig) + packed +
+                b"\xff" * lseq + aux)
+        self._buf += struct.pack("<i", len(body)) + body
+        while len(self._buf) >= 0xff00:
+            self._f.write(_bgzf_block(bytes(self._buf[:0xff00]), self.level))
+            del self._buf[:0xff00]
+
+    def close(self):
+        while self._buf:
+            self._f.write(_bgzf_block(bytes(self._buf[:0xff00]), self.level))
+            del self._buf[:0xff00]
+        self._f.write(_BGZF_EOF)
+        self._f.close()

@@ -1,0 +1,115 @@
+// Host-side BAM record decoder (no device code): turns the uncompressed BAM record stream into the
+// packed SoA arrays the kernels consume.  The reference gets these fields through pysam attribute
+// access one read at a time (read.reference_start / reference_end / mapq / flag / next_reference_id /
+// isize ..., __main__.py:229-240, tiddit_signal.pyx:169-221); this walks the records in C.
+// reference_end follows htslib's bam_endpos(): pos + sum of M/D/N/=/X lengths, pos + 1 when that sum is 0.
+#include "tdt_common.h"
+
+static inline uint32_t rd_u32(const uint8_t *p) {
+    uint32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+static inline int32_t rd_i32(const uint8_t *p) {
+    int32_t v;
+    memcpy(&v, p, 4);
+    return v;
+}
+static inline uint16_t rd_u16(const uint8_t *p) {
+    uint16_t v;
+    memcpy(&v, p, 2);
+    return v;
+}
+
+// size in bytes of one aux value of type `t` at p (p points at the value), or -1 if malformed
+static long aux_size(uint8_t t, const uint8_t *p, const uint8_t *end) {
+    switch (t) {
+        case 'A': case 'c': case 'C': return 1;
+        case 's': case 'S': return 2;
+        case 'i': case 'I': case 'f': return 4;
+        case 'd': return 8;
+        case 'Z': case 'H': {
+            const uint8_t *q = p;
+            while (q < end && *q) q++;
+            return q < end ? (long)(q - p) + 1 : -1;
+        }
+        case 'B': {
+            if (p + 5 > end) return -1;
+            const uint8_t st = p[0];
+            const uint32_t cnt = rd_u32(p + 1);
+            long es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : -1;
+            return es < 0 ? -1 : 5 + es * (long)cnt;
+        }
+        default: return -1;
+    }
+}
+
+extern "C" int tdt_bam_decode(const uint8_t *buf, size_t len, size_t max_records, size_t *consumed, size_t *n_records,
+                              int32_t *tid, int32_t *pos, int32_t *end, uint8_t *mapq, uint16_t *flag, int32_t *mate_tid,
+                              int32_t *mate_pos, int32_t *tlen, int32_t *l_seq, uint32_t *cigar_first, uint32_t *cigar_last,
+                              uint64_t *rec_off, int64_t *sa_off) {
+    if (!buf || !consumed || !n_records) {
+        tdt_set_error("tdt_bam_decode: bad argument");
+        return TDT_E_ARG;
+    }
+    size_t o = 0, n = 0;
+    while (n < max_records && o + 4 <= len) {
+        const uint32_t bs = rd_u32(buf + o);
+        if (bs < 32) {
+            tdt_set_error("tdt_bam_decode: record %zu has block_size %u < 32 (corrupt stream)", n, bs);
+            return TDT_E_ARG;
+        }
+        if (o + 4 + (size_t)bs > len) break;  // partial record: caller supplies more bytes
+        const uint8_t *r = buf + o + 4;
+        const int32_t p = rd_i32(r + 4);
+        const uint8_t l_name = r[8];
+        const uint16_t n_cig = rd_u16(r + 12);
+        const int32_t lseq = rd_i32(r + 16);
+        const size_t var = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)lseq + 1) / 2 + (size_t)lseq;
+        if (lseq < 0 || var > bs) {
+            tdt_set_error("tdt_bam_decode: record %zu is inconsistent (block_size %u < %zu)", n, bs, var);
+            return TDT_E_ARG;
+        }
+        const uint8_t *cig = r + 32 + l_name;
+        int64_t rlen = 0;
+        for (uint16_t k = 0; k < n_cig; k++) {
+            const uint32_t c = rd_u32(cig + 4 * k);
+            const uint32_t op = c & 0xf;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += c >> 4;  // M D N = X consume the reference
+        }
+        const uint16_t fl = rd_u16(r + 14);
+        if ((fl & 0x4) || rlen == 0) rlen = 1;  // bam_endpos
+        if (tid) tid[n] = rd_i32(r);
+        if (pos) pos[n] = p;
+        if (end) end[n] = (int32_t)(p + rlen);
+        if (mapq) mapq[n] = r[9];
+        if (flag) flag[n] = fl;
+        if (mate_tid) mate_tid[n] = rd_i32(r + 20);
+        if (mate_pos) mate_pos[n] = rd_i32(r + 24);
+        if (tlen) tlen[n] = rd_i32(r + 28);
+        if (l_seq) l_seq[n] = lseq;
+        if (cigar_first) cigar_first[n] = n_cig ? rd_u32(cig) : 0xffffffffu;
+        if (cigar_last) cigar_last[n] = n_cig ? rd_u32(cig + 4 * (n_cig - 1)) : 0xffffffffu;
+        if (rec_off) rec_off[n] = o;
+        if (sa_off) {  // offset (from buf) of the SA:Z value, -1 when absent   (read.has_tag("SA"), tiddit_signal.pyx:199)
+            int64_t found = -1;
+            const uint8_t *a = r + var, *aend = r + bs;
+            while (a + 3 <= aend) {
+                const uint8_t t = a[2];
+                const long sz = aux_size(t, a + 3, aend);
+                if (sz < 0 || a + 3 + sz > aend) break;
+                if (a[0] == 'S' && a[1] == 'A' && t == 'Z') {
+                    found = (int64_t)((a + 3) - buf);
+                    break;
+                }
+                a += 3 + sz;
+            }
+            sa_off[n] = found;
+        }
+        o += 4 + (size_t)bs;
+        n++;
+    }
+    *consumed = o;
+    *n_records = n;
+    return TDT_OK;
+}

@@ -1,0 +1,131 @@
+"""Synthetic coordinate-sorted paired-end BAMs with planted structural variants (test / config
+tooling; the reference ships no sample data).  Everything is derived from a seed."""
+import numpy as np
+
+from .bamio import BamWriter
+
+_BASES = "ACGT"
+
+
+def write_synthetic_bam(path, contigs, depth=10, read_len=100, insert=350, insert_sd=30, seed=1, n_events=12,
+                        sample="SYN", with_rg=True):
+    """contigs: list of (name, length).  -> dict with the planted events.
+    Planted: deletions (pairs with a large insert + split reads with SA tags), inter-contig translocations
+    (mates on different contigs), inversions (same-orientation pairs), soft-clipped reads, plus
+    duplicates, low-mapq, secondary/supplementary records, unpaired and mate-unmapped reads."""
+    rng = np.random.default_rng(seed)
+    recs = []   # (tid, pos, dict)
+    big = [i for i, (n, l) in enumerate(contigs) if l > 16 * insert]
+
+    def seq(n):
+        return "".join(_BASES[i] for i in rng.integers(0, 4, n))
+
+    def pair(name, tidA, posA, tidB, posB, revA=False, revB=True, mapqA=60, mapqB=60, extra_flagA=0, extra_flagB=0,
+             cigA=None, cigB=None, tagsA=(), tagsB=()):
+        cigA = cigA or "%dM" % read_len
+        cigB = cigB or "%dM" % read_len
+        tl = (posB + read_len - posA) if tidA == tidB else 0
+        fa = 0x1 | 0x40 | (0x10 if revA else 0) | (0x20 if revB else 0) | extra_flagA
+        fb = 0x1 | 0x80 | (0x10 if revB else 0) | (0x20 if revA else 0) | extra_flagB
+        if tidA == tidB and abs(tl) < 3 * insert and not revA and revB:
+            fa |= 0x2
+            fb |= 0x2
+        recs.append((tidA, posA, dict(qname=name, flag=fa, tid=tidA, pos=posA, mapq=mapqA, cigar=cigA, mate_tid=tidB, mate_pos=posB,
+                                      tlen=tl, seq=seq(read_len), tags=tagsA)))
+        recs.append((tidB, posB, dict(qname=name, flag=fb, tid=tidB, pos=posB, mapq=mapqB, cigar=cigB, mate_tid=tidA, mate_pos=posA,
+                                      tlen=-tl, seq=seq(read_len), tags=tagsB)))
+
+    q = 0
+    for tid, (name, L) in enumerate(contigs):
+        if L < 3 * insert:
+            n_pairs = 2
+        else:
+            n_pairs = int(L * depth / (2 * read_len))
+        for _ in range(n_pairs):
+            q += 1
+            ins = max(read_len + 1, int(rng.normal(insert, insert_sd)))
+            if L <= ins + 2:
+                posA, posB = 0, max(0, L - read_len)
+            else:
+                posA = int(rng.integers(0, L - ins))
+                posB = posA + ins - read_len
+            u = rng.random()
+            kw = {}
+            if u < 0.02:
+                kw["extra_flagA"] = 0x400
+            elif u < 0.05:
+                kw["mapqA"] = int(rng.integers(0, 5))
+            elif u < 0.06:
+                kw["extra_flagB"] = 0x100
+            elif u < 0.07:
+                kw["extra_flagB"] = 0x800
+            elif u < 0.10 and L > 4 * read_len:
+                c = int(rng.integers(26, 40))
+                kw["cigA"] = "%dS%dM" % (c, read_len - c) if rng.random() < 0.5 else "%dM%dS" % (read_len - c, c)
+            elif u < 0.11:
+                kw["cigA"] = "40M5D60M"
+            pair("p%d" % q, tid, posA, tid, posB, **kw)
+    events = []
+    for ev in range(n_events):
+        kind = ["DEL", "BND", "INV", "DEL"][ev % 4]
+        tA = big[int(rng.integers(0, len(big)))]
+        LA = contigs[tA][1]
+        a = int(rng.integers(2 * insert, LA - 12 * insert))
+        support = int(rng.integers(4, 10))
+        if kind == "DEL":
+            size = int(rng.integers(3 * insert, 8 * insert))
+            b = a + size
+            for k in range(support):
+                q += 1
+                pair("del%d_%d" % (ev, k), tA, a - int(rng.integers(read_len, insert)), tA, b + int(rng.integers(0, insert - read_len)))
+            for k in range(int(rng.integers(3, 7))):      # split reads across the junction
+                q += 1
+                left = int(rng.integers(35, 65))
+                sa = "%s,%d,+,%dS%dM,60,0;" % (contigs[tA][0], b + 1, left, read_len - left)
+                pair("dsp%d_%d" % (ev, k), tA, a - left, tA, a - left + insert - read_len, cigA="%dM%dS" % (left, read_len - left),
+                     tagsA=[("SA", "Z", sa), ("NM", "i", 0)])
+            events.append({"type": "DEL", "chrom": contigs[tA][0], "start": a, "end": b})
+        elif kind == "BND":
+            tB = big[int(rng.integers(0, len(big)))]
+            while tB == tA and len(big) > 1:
+                tB = big[int(rng.integers(0, len(big)))]
+            LB = contigs[tB][1]
+            b = int(rng.integers(2 * insert, LB - 2 * insert))
+            for k in range(support):
+                q += 1
+                pair("bnd%d_%d" % (ev, k), tA, a - int(rng.integers(read_len, insert)), tB, b + int(rng.integers(0, insert - read_len)))
+            for k in range(int(rng.integers(0, 5))):
+                q += 1
+                left = int(rng.integers(35, 65))
+                sa = "%s,%d,%s,%dS%dM,%d,1;%s,%d,+,50M50S,0,0;" % (contigs[tB][0], b + 1, "-" if k % 2 else "+", left, read_len - left,
+                                                                     60 if k != 1 else 2, contigs[tA][0], 5)
+                pair("bsp%d_%d" % (ev, k), tA, a - left, tA, a - left + insert - read_len, cigA="%dM%dS" % (left, read_len - left),
+                     tagsA=[("SA", "Z", sa)])
+            events.append({"type": "BND", "chromA": contigs[tA][0], "posA": a, "chromB": contigs[tB][0], "posB": b})
+        else:
+            size = int(rng.integers(4 * insert, 9 * insert))
+            b = a + size
+            for k in range(support):
+                q += 1
+                pair("inv%d_%d" % (ev, k), tA, a - int(rng.integers(read_len, insert)), tA, b - int(rng.integers(read_len, insert)),
+                     revA=False, revB=False)
+            events.append({"type": "INV", "chrom": contigs[tA][0], "start": a, "end": b})
+    # odd records: mate unmapped, unpaired, unmapped-but-placed
+    for k in range(10):
+        tA = big[int(rng.integers(0, len(big)))]
+        p = int(rng.integers(0, contigs[tA][1] - read_len))
+        recs.append((tA, p, dict(qname="mu%d" % k, flag=0x1 | 0x8 | 0x40, tid=tA, pos=p, mapq=60, cigar="%dM" % read_len, mate_tid=tA,
+                                 mate_pos=p, tlen=0, seq=seq(read_len), tags=())))
+        recs.append((tA, p, dict(qname="mu%d" % k, flag=0x1 | 0x4 | 0x80, tid=tA, pos=p, mapq=0, cigar="", mate_tid=tA, mate_pos=p,
+                                 tlen=0, seq=seq(read_len), tags=())))
+        recs.append((tA, p + 7, dict(qname="se%d" % k, flag=0, tid=tA, pos=p + 7, mapq=60, cigar="%dM" % read_len, mate_tid=-1,
+                                     mate_pos=-1, tlen=0, seq=seq(read_len), tags=())))
+    order = sorted(range(len(recs)), key=lambda i: (recs[i][0], recs[i][1]))   # stable
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs)
+    if with_rg:
+        text += "@RG\tID:rg1\tSM:%s\n" % sample
+    w = BamWriter(path, contigs, text=text)
+    for i in order:
+        w.write(**recs[i][2])
+    w.close()
+    return {"events": events, "n_records": len(recs)}

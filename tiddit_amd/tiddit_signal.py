@@ -1,0 +1,224 @@
+"""Drop-in for ``tiddit.tiddit_signal`` (tiddit_signal.pyx) on the MI355X.
+
+``main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index,
+min_anchor_len, min_clip_len) -> coverage_data`` (:230-334) with the same side-effect files
+(``{prefix}_tiddit/discordants_{sample}.tab``, ``splits_{sample}.tab``, ``clips_{sample}.fa``,
+``clips/{contig}.fa``), plus ``SA_analysis`` / ``find_SA_query_range`` (:11-145).
+
+Redesign: the reference forks one joblib worker per contig and calls Python once per read
+(``worker`` :147-228).  Here ONE process streams the BAM through the C record decoder
+(``bamio.BamReader``); the packed start/end/mapq/flag arrays of every batch go to the device coverage
+histogram (bin 50, same read filter, :171-182), and the signal predicates (:184-221) are evaluated on
+whole arrays — only the ~1 % of reads that are discordant, split or clipped are touched one by one.
+``threads`` and ``skip_index`` are accepted for signature compatibility and ignored (no index needed).
+"""
+import itertools
+import os
+import time
+
+import numpy
+
+from . import tiddit_coverage
+from .bamio import BamReader
+
+_SA_OPS = {"M": 0, "S": 4, "H": 5, "D": 2, "I": 1}   # :23 — any other CIGAR letter raises KeyError, like the reference
+
+
+class _SASegment:
+    """The synthetic AlignedSegment the reference builds for an SA entry (:11-29), reduced to the
+    attributes SA_analysis reads.  reference_start is the SA tag's 1-based POS stored raw (:13)."""
+
+    def __init__(self, pos, is_minus, cigar):
+        self.reference_start = pos
+        self.flag = 80 if is_minus else 64
+        self.cigartuples = cigar
+        ref = sum(l for op, l in cigar if op in (0, 2))
+        self.reference_end = pos + (ref if ref else 1)               # htslib bam_endpos
+        self.query_alignment_start = _leading_softclip(cigar)
+        # no sequence: pysam derives the end from the CIGAR (leading S + M/I lengths)
+        self.query_alignment_end = self.query_alignment_start + sum(l for op, l in cigar if op in (0, 1))
+
+
+def _leading_softclip(cigar):
+    n = 0
+    for op, l in cigar:
+        if op == 5:
+            continue
+        if op == 4:
+            n += l
+        else:
+            break
+    return n
+
+
+def find_SA_query_range(SA):
+    """SA = one entry split on ',': rname,pos,strand,CIGAR,mapQ,NM  (:11-29)"""
+    parts = ["".join(x) for _, x in itertools.groupby(SA[3], key=str.isdigit)]
+    cigar = [(_SA_OPS[parts[i * 2 + 1]], int(parts[i * 2])) for i in range(0, int(len(parts) / 2))]
+    return _SASegment(int(SA[1]), SA[2] != "+", cigar)
+
+
+def SA_analysis(read, min_q, tag, reference_name):
+    """Split-read signal of a read carrying an SA tag (:31-145).  ``read`` needs query_name,
+    reference_start, reference_end, is_reverse, query_alignment_start and get_tag(tag).
+    QUIRK (:36-39): with several SA entries the selection loop only ever inspects entry 0, so entry 0
+    is always the one used and the read is dropped when its mapQ is below min_q."""
+    entries = read.get_tag(tag).rstrip(";").split(";")
+    sa = entries[0].split(",")
+    if int(sa[4]) < min_q:
+        return ()
+    seg = find_SA_query_range(sa)
+    clip_before = seg.query_alignment_start < read.query_alignment_start
+    read_start, read_end = read.reference_start + 1, read.reference_end + 1
+    if clip_before:
+        split_pos = read_end if read.is_reverse else read_start
+    else:
+        split_pos = read_start if read.is_reverse else read_end
+    sa_minus = sa[2] == "-"
+    if clip_before:
+        sa_split = seg.reference_start if sa_minus else seg.reference_end
+    else:
+        sa_split = seg.reference_end if sa_minus else seg.reference_start
+    sa_chr = sa[0]
+    startA, endA, startB, endB = read_start, read_end, seg.reference_start, seg.reference_end
+    swap = False
+    if sa_chr < reference_name:                     # string order, like the reference
+        chrA, chrB, swap = sa_chr, reference_name, True
+    else:
+        chrA, chrB = reference_name, sa_chr
+        if chrA == chrB and sa_split < split_pos:
+            swap = True
+    if swap:
+        split_pos, sa_split = sa_split, split_pos
+        startA, endA, startB, endB = seg.reference_start, seg.reference_end, read_start, read_end
+    return [chrA, chrB, read.query_name, split_pos, read.is_reverse, sa_split, sa_minus, startA, endA, startB, endB]
+
+
+class _ReadProxy:
+    """What SA_analysis needs from a decoded record."""
+
+    def __init__(self, batch, i):
+        self._rec = batch.record(i)
+        self.reference_start = int(batch.pos[i])
+        self.reference_end = int(batch.end[i])
+        self.is_reverse = bool(batch.flag[i] & 0x10)
+
+    @property
+    def query_name(self):
+        return self._rec.query_name
+
+    @property
+    def query_alignment_start(self):
+        return _leading_softclip(self._rec.cigartuples)
+
+    def get_tag(self, tag):
+        return self._rec.get_tag_sa()
+
+
+def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50):
+    """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
+    split rows, clip FASTA entries).  Rows are exactly what ``worker`` returns (:228)."""
+    reader = BamReader(bam_file_name)
+    header = reader.header
+    names, lengths = reader.references, reader.lengths
+    big = numpy.array([ln >= min_contig for ln in lengths], dtype=bool)
+    hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(names, lengths)], bin_size)
+    data = {n: [] for n in names}
+    splits = {n: [] for n in names}
+    clips = {n: [] for n in names}
+    for b in reader.batches():
+        tid = b.tid
+        flag = b.flag.astype(numpy.int32)
+        placed = tid >= 0
+        ok_contig = numpy.zeros(len(tid), dtype=bool)
+        ok_contig[placed] = big[tid[placed]]
+        # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
+        edges = numpy.flatnonzero(numpy.diff(tid)) + 1
+        for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
+            t = int(tid[lo])
+            if t >= 0 and big[t]:
+                hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
+        primary = ok_contig & ((flag & 0x404) == 0) & ((flag & 0x900) == 0) & (b.mapq >= min_q)   # :171,:184,:188
+        same_chr = b.mate_tid == tid
+        abs_isize = numpy.abs(b.tlen.astype(numpy.int64))
+        # clipped reads for local assembly (:190-197)
+        f_op, f_len = b.cigar_first & 0xf, b.cigar_first >> 4
+        l_op, l_len = b.cigar_last & 0xf, b.cigar_last >> 4
+        has_cigar = b.cigar_first != 0xffffffff
+        left = (f_op == 4) & (f_len > min_clip_len) & (l_op == 0) & (l_len > min_anchor_len)
+        right = (l_op == 4) & (l_len > min_clip_len) & (f_op == 0) & (f_len > min_anchor_len)
+        for i in numpy.flatnonzero(primary & (abs_isize < max_ins) & same_chr & has_cigar & (left | right)):
+            rec = b.record(i)
+            chrom = names[tid[i]]
+            clips[chrom].append([">{}|{}|{}\n".format(rec.query_name, chrom, int(b.pos[i]) + 1), rec.query_sequence + "\n"])
+        # split reads (:199-202)
+        for i in numpy.flatnonzero(primary & (b.sa_off >= 0)):
+            chrom = names[tid[i]]
+            split = SA_analysis(_ReadProxy(b, i), min_q, "SA", chrom)
+            if split:
+                splits[chrom].append(split)
+        # discordant pairs (:204-221)
+        disc = primary & ((flag & 0x8) == 0) & ((flag & 0x1) != 0) & (b.mate_tid >= 0) & ((abs_isize > max_ins) | ~same_chr)
+        for i in numpy.flatnonzero(disc):
+            chrom, mate = names[tid[i]], names[b.mate_tid[i]]
+            chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
+            data[chrom].append([chrA, chrB, b.record(i).query_name, int(b.pos[i]) + 1, int(b.end[i]) + 1, bool(flag[i] & 0x10), chrom])
+    reader.close()
+    chromosomes = [n for n, ok in zip(names, big) if ok]
+    coverage = {n: hist.finish(n) for n in chromosomes}
+    hist.close()
+    return header, chromosomes, coverage, data, splits, clips
+
+
+def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
+    t = time.time()
+    header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
+        bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
+    all_contigs = [c["SN"] for c in header["SQ"]]
+    data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
+    splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
+    os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
+    clip_fasta = []
+    for chrom in chromosomes:                                            # results in contig order (:262-284)
+        print("Collecting signals on contig: {}".format(chrom))
+        for signal in res_data[chrom]:
+            if signal[0] not in data:
+                continue
+            data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
+        for signal in res_splits[chrom]:
+            if signal[0] not in splits:
+                continue
+            splits[signal[0]][signal[1]].setdefault(signal[2], [])
+            splits[signal[0]][signal[1]][signal[2]] += signal[3:]
+        path = "{}_tiddit/clips/{}.fa".format(prefix, chrom)
+        with open(path, "w") as f:
+            for clip in res_clips[chrom]:
+                f.write("".join(clip))
+        clip_fasta.append(path)
+    print("total", time.time() - t)
+    print("Writing signals to file")
+
+    with open("{}_tiddit/discordants_{}.tab".format(prefix, sample_id), "w") as f:      # :298-318
+        for chrA in data:
+            for chrB in data[chrA]:
+                for fragment, reads in data[chrA][chrB].items():
+                    if len(reads) < 2:
+                        continue
+                    first, second = reads[0], reads[1]
+                    if chrA == chrB:
+                        if second[-1] < first[-1]:      # QUIRK (:307): compares the two read_chr strings, always equal
+                            first, second = second, first
+                    elif first[-1] != chrA:
+                        first, second = second, first
+                    out = first[0:-1] + second[0:-1]
+                    f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, out))))
+    with open("{}_tiddit/splits_{}.tab".format(prefix, sample_id), "w") as f:           # :320-326
+        for chrA in splits:
+            for chrB in splits[chrA]:
+                for fragment, fields in splits[chrA][chrB].items():
+                    f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
+    with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "w") as f:             # :328-332
+        for path in clip_fasta:
+            for line in open(path):
+                f.write(line)
+    return coverage_data
