@@ -5,7 +5,7 @@ A *step* is one pass of the hot path over one batch of synthetic input that is a
 HBM when the timed region starts:
   * coverage (the JSON line's `value`): BASELINE configs[1] — 3 Gb genome (24 contigs x 125 Mb),
     30x 150-bp coordinate-sorted alignment stream (600 M reads), 500-bp bins, --cov read filter
-    (q 20): reset accumulators -> 24 cov_accumulate launches -> 24 int64->float64 finalize launches;
+    (q 20): reset accumulators -> ONE cov_accumulate launch over all 24 contigs -> ONE int64->float64 pass;
   * clustering (reported under "dbscan"): BASELINE configs[2] — gen_points(5_000_000), one chr pair,
     e=500 l=3, x pass + y pass (16 launches); with N>1 ranks every rank clusters its own bucket and
     the label arrays are all-gathered over RCCL.
@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-contigs", type=int, default=4, help="contigs of the stream the CPU baseline (oracle) is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dbscan", action="store_true")
+    ap.add_argument("--no-gc", action="store_true")
+    ap.add_argument("--gc-len", type=int, default=3_000_000_000, help="reference bases for the GC histogram pass")
     return ap.parse_args()
 
 
@@ -83,8 +85,11 @@ def main():
     n_reads = [int(r[0].numel()) for r in reads]
     hist = tiddit_coverage.CoverageHistogram([("s%02d" % (c + 1), L) for c in range(C)], z, ctx=ctx)
     nbins = [hist.nbins(c)[0] for c in range(C)]
-    outs = [torch.empty(nb, dtype=torch.float64, device=dev) for nb in nbins]
+    out_all = torch.empty(hist.total_bins(), dtype=torch.float64, device=dev)
+    outs = [out_all[hist.offset(c):hist.offset(c) + nbins[c]] for c in range(C)]
     total_reads, total_bins = sum(n_reads), sum(nbins)
+    items = [(c, reads[c][0].data_ptr(), reads[c][1].data_ptr(), reads[c][2].data_ptr(), reads[c][3].data_ptr(), n_reads[c])
+             for c in range(C)]
 
     ev_pairs = []
 
@@ -93,14 +98,11 @@ def main():
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
-        for c in range(C):
-            s, e, mq, fl = reads[c]
-            hist.push_device(c, s.data_ptr(), e.data_ptr(), mq.data_ptr(), fl.data_ptr(), n_reads[c], args.min_q)
+        hist.push_device_multi(items, args.min_q)      # all contigs of the genome in ONE cov_accumulate launch
         if timed:
             b.record(stream)
             ev_pairs.append((a, b))
-        for c in range(C):
-            hist.finish_device(c, outs[c].data_ptr())
+        hist.finish_all_device(out_all.data_ptr())      # one int64 -> float64 pass over all bins
 
     for _ in range(args.warmup):
         cov_step(False)
@@ -119,14 +121,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_cov = float(tt.item())
     ms_per_step = 1e3 * t_cov / args.steps
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / (len(ev_pairs) * C)  # avg cov_accumulate launch
-    alg_bytes_launch = 12.0 * total_reads / C + 8.0 * total_bins / C             # 12 B/read + 8 B/bin
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)        # avg cov_accumulate launch (whole genome)
+    alg_bytes_launch = 12.0 * total_reads + 8.0 * total_bins                     # 12 B/read + 8 B/bin
     achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
     traffic = None
     tp = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("cov_accumulate_bytes_per_launch")
+            traffic = json.load(open(tp)).get("cov_accumulate_bytes_per_read") * total_reads
         except Exception:
             traffic = None
 
@@ -140,7 +142,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: coverage histogram, %d contigs x %d bp (%.2f Gb), %dx 150-bp sorted "
                                "stream, %d-bp bins, q>=%d filter, per GPU" % (C, L, C * L / 1e9, args.depth, z, args.min_q),
-                   "reads_per_gpu": total_reads, "bins_per_gpu": total_bins, "launches_per_step": 2 * C + 1},
+                   "reads_per_gpu": total_reads, "bins_per_gpu": total_bins, "launches_per_step": 3},
         "reads_per_sec": total_reads * world / (t_cov / args.steps),
         "roofline": {"bound": "hbm", "kernel": "cov_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kern_ms,
@@ -170,7 +172,7 @@ def main():
                                             "update_coverage loop, arrays in memory; bins verified bit-identical to the GPU's"
                                             % (k, C, sum(n_reads[:k]), sum(nbins[:k]))}
         result["parity_checked"] = True
-    del reads, outs
+    del reads, outs, out_all
     hist.close()
     torch.cuda.empty_cache()
 
@@ -244,6 +246,73 @@ def main():
                                                                  "(DBSCAN.py:72) in C" % ns}}
             dbres["parity_checked"] = True
         result["dbscan"] = dbres
+
+    # ---------------------------------------------------------------- GC / N-mask histogram (50-bp bins, cutoff 0.5)
+    if not args.no_gc:
+        G = args.gc_len
+        with torch.cuda.stream(stream):
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(synth.SEED + 7 + rank)
+            code = torch.randint(0, 256, (G,), generator=gen, device=dev, dtype=torch.uint8)
+            # bytes: mostly ACGT, some lower case, ~3 % N (runs come from the low bits of a coarse index)
+            lut = torch.tensor(list(b"ACGTACGTACGTacgtNnRYACGTGGCCAATT"), device=dev, dtype=torch.uint8)
+            seq = lut[(code & 31).long()] if G <= 500_000_000 else None
+            if seq is None:
+                seq = torch.empty(G, dtype=torch.uint8, device=dev)
+                step = 500_000_000
+                for o in range(0, G, step):
+                    seq[o:o + step] = lut[(code[o:o + step] & 31).long()]
+            del code
+            gout = torch.empty(-(-G // 50), dtype=torch.int8, device=dev)
+        torch.cuda.synchronize()
+        gev = []
+
+        def gc_step(timed):
+            with torch.cuda.stream(stream):
+                if timed:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                _native.check(ctx.lib.tdt_gc_bins_device(ctx.handle, seq.data_ptr(), G, 50, 0.5, gout.data_ptr()))
+                if timed:
+                    b.record(stream)
+                    gev.append((a, b))
+
+        for _ in range(args.warmup):
+            gc_step(False)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gc_step(True)
+        torch.cuda.synchronize()
+        barrier()
+        t_gc = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([t_gc], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_gc = float(tt.item())
+        g_ms = sum(a.elapsed_time(b) for a, b in gev) / len(gev)
+        g_ach = (G + G / 50.0) / (g_ms * 1e-3) / 1e9
+        gres = {"metric": "gc bins/sec", "value": (G / 50.0) * world / (t_gc / args.steps), "unit": "bins/s",
+                "bases_per_sec": G * world / (t_gc / args.steps), "ms_per_step": 1e3 * t_gc / args.steps,
+                "config": {"workload": "GC/N-mask histogram, %d bases, 50-bp bins, n_cutoff 0.5, per GPU" % G},
+                "roofline": {"bound": "hbm", "kernel": "gc_small_bins", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": g_ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": g_ms,
+                             "algorithmic_bytes_per_launch": G + G / 50.0}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            import oracle
+            ns = min(G, 200_000_000)
+            hs = seq[:ns].cpu().numpy()
+            t1 = time.perf_counter()
+            want = oracle.binned_gc(hs, 50, 0.5)
+            t_cpu = time.perf_counter() - t1
+            if not np.array_equal(gout[:len(want)].cpu().numpy()[:ns // 50], want[:ns // 50]):
+                raise SystemExit("PARITY FAILURE: GPU GC bins differ from the CPU oracle")
+            gres["cpu_baseline"] = {"value": len(want) / t_cpu, "unit": "bins/s", "cores": 1, "kind": "port",
+                                    "sample": "first %d bases, oracle C port of the per-character loop" % ns}
+            gres["parity_checked"] = True
+        result["gc"] = gres
+        del seq, gout
 
     if rank == 0:
         print(json.dumps(result))

@@ -72,6 +72,16 @@ int tdt_cov_push(tdt_cov *cov, int tid, const int32_t *start, const int32_t *end
 /* Same with device-resident arrays (asynchronous). */
 int tdt_cov_push_device(tdt_cov *cov, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq,
                         const uint16_t *d_flag, size_t n, int min_q);
+/* Several contigs' device-resident streams in ONE launch (no inter-launch gaps or tails): item i adds
+ * n[i] records of contig tids[i]; the pointer arrays are HOST arrays of device pointers. */
+int tdt_cov_push_device_multi(tdt_cov *cov, int n_items, const int *tids, const int32_t *const *d_start,
+                              const int32_t *const *d_end, const uint8_t *const *d_mapq, const uint16_t *const *d_flag,
+                              const size_t *n, int min_q);
+/* All contigs at once: d_out holds tdt_cov_total_bins doubles, contig tid starts at tdt_cov_offset(tid)
+ * (contigs are padded to 16-byte boundaries). */
+int tdt_cov_total_bins(tdt_cov *cov, int64_t *total);
+int tdt_cov_offset(tdt_cov *cov, int tid, int64_t *off);
+int tdt_cov_finish_all_device(tdt_cov *cov, double *d_out);
 /* Convert contig tid's accumulators to float64 bins (exact), copy to host / leave on device.
  * Returns TDT_E_RANGE / TDT_E_INEXACT if any pushed read / bin violated the domain. */
 int tdt_cov_finish(tdt_cov *cov, int tid, double *out_bins);

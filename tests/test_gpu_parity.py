@@ -419,3 +419,34 @@ def test_cluster_main_golden(ctx, golden_dir, tmp_path):
                                    case["m"], case["max_ins_len"], case["min_contig"], True, case["min_reads"])
         # same keys, same values AND same insertion order (the order defines the VCF SV ids downstream)
         assert json.dumps(_jsonable(cand)) == json.dumps(case["candidates"]), ci
+
+
+def test_coverage_multi_contig_single_launch(cov, ctx):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    contigs = [("a", 3_000_000), ("b", 1137), ("c", 1_500_001), ("d", 400), ("e", 2_000_000)]
+    h = cov.CoverageHistogram(contigs, 500)
+    items, keep, want = [], [], {}
+    for i, (name, LN) in enumerate(contigs):
+        if LN > 1000:
+            s, e, mq, fl = synth.gen_reads(LN, 25, seed=50 + i)
+            if name == "c":
+                s, e, mq, fl = s[:-1], e[:-1], mq[:-1], fl[:-1]      # odd count: scalar tail path
+        else:
+            s, e, mq, fl = (np.zeros(0, np.int64),) * 2 + (np.zeros(0, np.uint8), np.zeros(0, np.uint16))
+        want[name], _ = oracle.coverage_stream(s, e, mq, fl, LN, 500, 20)
+        ts = [torch.from_numpy(s.astype(np.int32)).to(dev), torch.from_numpy(e.astype(np.int32)).to(dev),
+              torch.from_numpy(mq).to(dev), torch.from_numpy(fl.view(np.int16)).to(dev)]
+        keep.append(ts)
+        items.append((name, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), len(s)))
+    out = torch.zeros(h.total_bins(), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    h.push_device_multi(items, 20)
+    h.finish_all_device(out.data_ptr())
+    ctx.sync()
+    res = out.cpu().numpy()
+    for name, LN in contigs:
+        o, nb = h.offset(name), h.nbins(name)[0]
+        assert np.array_equal(res[o:o + nb], want[name]), name
+        assert np.array_equal(h.finish(name), want[name]), name
+    h.close()

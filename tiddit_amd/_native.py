@@ -43,6 +43,10 @@ SYMBOLS = {
     "tdt_cov_reset": (_i, [_P]),
     "tdt_cov_push": (_i, [_P, _i, _P, _P, _P, _P, _sz, _i]),
     "tdt_cov_push_device": (_i, [_P, _i, _P, _P, _P, _P, _sz, _i]),
+    "tdt_cov_push_device_multi": (_i, [_P, _i, _P, _P, _P, _P, _P, _P, _i]),
+    "tdt_cov_total_bins": (_i, [_P, ctypes.POINTER(_i64)]),
+    "tdt_cov_offset": (_i, [_P, _i, ctypes.POINTER(_i64)]),
+    "tdt_cov_finish_all_device": (_i, [_P, _P]),
     "tdt_cov_finish": (_i, [_P, _i, _P]),
     "tdt_cov_finish_device": (_i, [_P, _i, _P]),
     "tdt_cov_kept": (_i, [_P, ctypes.POINTER(_i64)]),

@@ -33,24 +33,33 @@
 #define COV_STATUS_BYTES (128 + COV_KEPT_SLOTS * 128)
 #define COV_KEPT_SLOTS 512                         // kept-read counters, one 128-byte line each
 
-struct CovParams {
+// one contig's slice of a launch
+struct CovItem {
     const int32_t *start;
     const int32_t *end;
     const uint8_t *mapq;
     const uint16_t *flag;
     unsigned long long n;
-    unsigned long long *acc;  // this contig's accumulators
+    unsigned long long *acc;             // this contig's accumulators
+    const unsigned long long *lut_end;   // [bin_size+1] fixed-point float32(b)/float32(end_bin_size)
     int nbins;
+    int aligned;                         // all four arrays vector-load aligned
+    unsigned first_block;                // first workgroup of this item inside a multi-contig launch
+    unsigned pad_;
+};
+
+struct CovParams {
+    CovItem it;                          // the item of a single-contig launch
+    const CovItem *items;                // multi-contig launch: n_items descriptors in device memory
+    int n_items;
     int bin_size;
     unsigned magic;           // floor(x / bin_size) = mulhi(x, magic) >> shift for 0 <= x < 2^31
     int shift;                // -1: bin_size == 1
     int min_q;
     const unsigned long long *lut_main;  // [bin_size+1] fixed-point float32(b)/float32(bin_size)
-    const unsigned long long *lut_end;   // [bin_size+1] fixed-point float32(b)/float32(end_bin_size)
     unsigned long long one;              // 1.0 in fixed point
     int *status;                         // [0] |= 1 on range error
     unsigned long long *kept;
-    int aligned;                         // all four arrays vector-load aligned
 };
 
 __device__ __forceinline__ int cov_div(int x, unsigned magic, int shift) {
@@ -111,7 +120,7 @@ struct CovTile {
     uint2 fl;
 };
 
-__device__ __forceinline__ CovTile cov_load(const CovParams &P, unsigned long long idx, unsigned long long r1) {
+__device__ __forceinline__ CovTile cov_load(const CovItem &P, unsigned long long idx, unsigned long long r1) {
     CovTile t;
     if (P.aligned && idx + COV_RPL <= r1) {
         t.s = *reinterpret_cast<const int4 *>(P.start + idx);
@@ -149,33 +158,46 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const unsigned long long r0 = (unsigned long long)blockIdx.x * COV_READS_PER_BLOCK;
-    const unsigned long long r1 = min(P.n, r0 + COV_READS_PER_BLOCK);
+    // which contig does this workgroup belong to (wave-uniform: scalar loads + scalar binary search)
+    CovItem I = P.it;
+    unsigned blk = blockIdx.x;
+    if (P.n_items > 0) {
+        int lo = 0, hi = P.n_items;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (P.items[mid].first_block <= blk) lo = mid;
+            else hi = mid;
+        }
+        I = P.items[lo];
+        blk -= I.first_block;
+    }
+    const unsigned long long r0 = (unsigned long long)blk * COV_READS_PER_BLOCK;
+    const unsigned long long r1 = min(I.n, r0 + COV_READS_PER_BLOCK);
     const unsigned z = (unsigned)P.bin_size;
 
     // first tile's loads go out before the LDS set-up
-    CovTile cur = cov_load(P, r0 + (unsigned long long)tid * COV_RPL, r1);
+    CovTile cur = cov_load(I, r0 + (unsigned long long)tid * COV_RPL, r1);
 
     for (int i = tid; i < COV_WIN; i += COV_THREADS) win[i] = 0;
     if (LDS_LUT) {
         for (unsigned i = tid; i <= z; i += COV_THREADS) {
             lutS[i] = P.lut_main[i];
-            lutS[i + z + 1] = P.lut_end[i];
+            lutS[i + z + 1] = I.lut_end[i];
         }
     }
     if (tid == 0) {
-        int s = P.start[r0];
+        int s = I.start[r0];
         s = s < 0 ? 0 : s;
         int b = cov_div(s, P.magic, P.shift);
-        *s_base = b < P.nbins ? b : P.nbins - 1;
+        *s_base = b < I.nbins ? b : I.nbins - 1;
     }
     __syncthreads();
     const int base = *s_base;
-    const int last_bin = P.nbins - 1;
+    const int last_bin = I.nbins - 1;
     // LUT[i] for i <= z: float32(i)/float32(z); LUT[z+1+i]: float32(i)/float32(end_bin_size).  LUT[0] == 0.
     auto lut = [&](unsigned i) -> unsigned long long {
         if (LDS_LUT) return lutS[i];
-        return i <= z ? P.lut_main[i] : P.lut_end[i - z - 1];
+        return i <= z ? P.lut_main[i] : I.lut_end[i - z - 1];
     };
 
     auto contribute = [&](int bin, unsigned long long v) {
@@ -184,7 +206,7 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         if (v == 0x1234567ull) win[0] = v;
 #else
         if (off < COV_WIN) atomicAdd(&win[off], v);  // ds_add_u64 (bins past the contig end only ever see +x and -x)
-        else if ((unsigned)bin <= (unsigned)last_bin) cov_global_add(P.acc, bin, v);
+        else if ((unsigned)bin <= (unsigned)last_bin) cov_global_add(I.acc, bin, v);
 #endif
     };
 
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     for (unsigned long long t0 = r0; t0 < r1; t0 += COV_TILE) {
         // software prefetch: the next tile's loads are in flight while this one is reduced
         CovTile nxt = cur;
-        if (t0 + COV_TILE < r1) nxt = cov_load(P, t0 + COV_TILE + (unsigned long long)tid * COV_RPL, r1);
+        if (t0 + COV_TILE < r1) nxt = cov_load(I, t0 + COV_TILE + (unsigned long long)tid * COV_RPL, r1);
 
         const int sv[COV_RPL] = {cur.s.x, cur.s.y, cur.s.z, cur.s.w};
         const int ev[COV_RPL] = {cur.e.x, cur.e.y, cur.e.z, cur.e.w};
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     // coalesced spill of the LDS window
     for (int i = tid; i < COV_WIN; i += COV_THREADS) {
         const unsigned long long v = win[i];
-        if (v && base + i <= last_bin) atomicAdd(&P.acc[base + i], v);
+        if (v && base + i <= last_bin) atomicAdd(&I.acc[base + i], v);
     }
 }
 
@@ -491,29 +513,37 @@ extern "C" int tdt_cov_reset(tdt_cov *c) {
     return TDT_OK;
 }
 
-static int cov_launch(tdt_cov *c, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq,
-                      const uint16_t *d_flag, size_t n, int min_q) {
-    if (n == 0 || c->nbins[tid] == 0) return TDT_OK;
+static CovItem cov_item(tdt_cov *c, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq,
+                        const uint16_t *d_flag, size_t n) {
+    CovItem it;
+    it.start = d_start;
+    it.end = d_end;
+    it.mapq = d_mapq;
+    it.flag = d_flag;
+    it.n = n;
+    it.acc = c->d_acc + c->off[tid];
+    it.lut_end = c->d_lut_end + (size_t)tid * ((size_t)c->bin_size + 1);
+    it.nbins = (int)c->nbins[tid];
+    it.aligned = (((uintptr_t)d_start | (uintptr_t)d_end) & 15) == 0 && ((uintptr_t)d_mapq & 3) == 0 &&
+                 ((uintptr_t)d_flag & 7) == 0;
+    it.first_block = 0;
+    it.pad_ = 0;
+    return it;
+}
+
+static int cov_launch_items(tdt_cov *c, const CovItem &single, const CovItem *d_items, int n_items, unsigned grid, int min_q) {
     CovParams P;
-    P.start = d_start;
-    P.end = d_end;
-    P.mapq = d_mapq;
-    P.flag = d_flag;
-    P.n = n;
-    P.acc = c->d_acc + c->off[tid];
-    P.nbins = (int)c->nbins[tid];
+    P.it = single;
+    P.items = d_items;
+    P.n_items = n_items;
     P.bin_size = c->bin_size;
     P.magic = c->magic;
     P.shift = c->shift;
     P.min_q = min_q;
     P.lut_main = c->d_lut_main;
-    P.lut_end = c->d_lut_end + (size_t)tid * ((size_t)c->bin_size + 1);
     P.one = 1ull << c->S;
     P.status = c->d_status;
     P.kept = c->d_kept;
-    P.aligned = (((uintptr_t)d_start | (uintptr_t)d_end) & 15) == 0 && ((uintptr_t)d_mapq & 3) == 0 &&
-                ((uintptr_t)d_flag & 7) == 0;
-    const unsigned grid = (unsigned)((n + COV_READS_PER_BLOCK - 1) / COV_READS_PER_BLOCK);
     const bool lds_lut = c->bin_size + 1 <= COV_LUT_LDS_MAX;
     const size_t lds = 16 + (size_t)COV_WIN * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0);
     if (lds_lut)
@@ -522,6 +552,47 @@ static int cov_launch(tdt_cov *c, int tid, const int32_t *d_start, const int32_t
         hipLaunchKernelGGL(cov_accumulate<false>, dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     TDT_CHECK_LAUNCH();
     return TDT_OK;
+}
+
+static int cov_launch(tdt_cov *c, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq,
+                      const uint16_t *d_flag, size_t n, int min_q) {
+    if (n == 0 || c->nbins[tid] == 0) return TDT_OK;
+    const unsigned grid = (unsigned)((n + COV_READS_PER_BLOCK - 1) / COV_READS_PER_BLOCK);
+    return cov_launch_items(c, cov_item(c, tid, d_start, d_end, d_mapq, d_flag, n), nullptr, 0, grid, min_q);
+}
+
+extern "C" int tdt_cov_push_device_multi(tdt_cov *c, int n_items, const int *tids, const int32_t *const *d_start,
+                                         const int32_t *const *d_end, const uint8_t *const *d_mapq,
+                                         const uint16_t *const *d_flag, const size_t *n, int min_q) {
+    if (!c || n_items < 0 || (n_items && (!tids || !d_start || !d_end || !d_mapq || !d_flag || !n))) {
+        tdt_set_error("tdt_cov_push_device_multi: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    std::vector<CovItem> items;
+    unsigned long long blocks = 0;
+    for (int i = 0; i < n_items; i++) {
+        if (tids[i] < 0 || tids[i] >= c->n_contigs || (n[i] && (!d_start[i] || !d_end[i] || !d_mapq[i] || !d_flag[i]))) {
+            tdt_set_error("tdt_cov_push_device_multi: bad item %d", i);
+            return TDT_E_ARG;
+        }
+        if (n[i] == 0 || c->nbins[tids[i]] == 0) continue;
+        CovItem it = cov_item(c, tids[i], d_start[i], d_end[i], d_mapq[i], d_flag[i], n[i]);
+        it.first_block = (unsigned)blocks;
+        blocks += (n[i] + COV_READS_PER_BLOCK - 1) / COV_READS_PER_BLOCK;
+        items.push_back(it);
+    }
+    if (items.empty()) return TDT_OK;
+    if (blocks >= 0x7fffffffull) {
+        tdt_set_error("tdt_cov_push_device_multi: too many reads for one launch");
+        return TDT_E_ARG;
+    }
+    void *d_items = nullptr;
+    int rc = tdt_scratch(c->ctx, 7, items.size() * sizeof(CovItem), &d_items);
+    if (rc) return rc;
+    // pageable source: the runtime stages it before returning, so `items` may go out of scope
+    TDT_HIP(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(CovItem), hipMemcpyHostToDevice, c->ctx->stream));
+    return cov_launch_items(c, items[0], (const CovItem *)d_items, (int)items.size(), (unsigned)blocks, min_q);
 }
 
 extern "C" int tdt_cov_push_device(tdt_cov *c, int tid, const int32_t *d_start, const int32_t *d_end,
@@ -604,6 +675,36 @@ extern "C" int tdt_cov_finish_device(tdt_cov *c, int tid, double *d_out) {
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(cov_finalize, dim3((unsigned)blocks), dim3(threads), 0, c->ctx->stream,
                            (const long long *)(c->d_acc + c->off[tid]), d_out, nb, ldexp(1.0, -c->S), c->d_status);
+        TDT_CHECK_LAUNCH();
+    }
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_total_bins(tdt_cov *c, int64_t *total) {
+    if (!c || !total) return TDT_E_ARG;
+    *total = c->total_bins;
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_offset(tdt_cov *c, int tid, int64_t *off) {
+    if (!c || !off || tid < 0 || tid >= c->n_contigs) return TDT_E_ARG;
+    *off = c->off[tid];
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_finish_all_device(tdt_cov *c, double *d_out) {
+    if (!c || !d_out) {
+        tdt_set_error("tdt_cov_finish_all_device: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    const long long nb = c->total_bins;
+    if (nb) {
+        const int threads = 256;
+        long long blocks = (nb + threads - 1) / threads;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(cov_finalize, dim3((unsigned)blocks), dim3(threads), 0, c->ctx->stream, (const long long *)c->d_acc, d_out, nb,
+                           ldexp(1.0, -c->S), c->d_status);
         TDT_CHECK_LAUNCH();
     }
     return TDT_OK;

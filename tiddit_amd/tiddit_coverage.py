@@ -100,6 +100,29 @@ class CoverageHistogram:
         """Device pointers (ints), e.g. ``tensor.data_ptr()``; asynchronous on the context stream."""
         _native.check(self.lib.tdt_cov_push_device(self.handle, self._tid(contig), d_start, d_end, d_mapq, d_flag, n, int(min_q)))
 
+    def push_device_multi(self, items, min_q):
+        """items: list of (contig, d_start, d_end, d_mapq, d_flag, n) with device pointers — ONE launch."""
+        k = len(items)
+        tids = numpy.array([self._tid(it[0]) for it in items], dtype=numpy.int32)
+        ptrs = [numpy.array([it[j] for it in items], dtype=numpy.uint64) for j in (1, 2, 3, 4)]
+        ns = numpy.array([it[5] for it in items], dtype=numpy.uint64)
+        _native.check(self.lib.tdt_cov_push_device_multi(self.handle, k, _native.ptr(tids), _native.ptr(ptrs[0]), _native.ptr(ptrs[1]),
+                                                         _native.ptr(ptrs[2]), _native.ptr(ptrs[3]), _native.ptr(ns), int(min_q)))
+
+    def total_bins(self):
+        t = ctypes.c_int64()
+        _native.check(self.lib.tdt_cov_total_bins(self.handle, ctypes.byref(t)))
+        return t.value
+
+    def offset(self, contig):
+        o = ctypes.c_int64()
+        _native.check(self.lib.tdt_cov_offset(self.handle, self._tid(contig), ctypes.byref(o)))
+        return o.value
+
+    def finish_all_device(self, d_out):
+        """float64[total_bins()] on the device; contig c occupies [offset(c), offset(c)+nbins(c))."""
+        _native.check(self.lib.tdt_cov_finish_all_device(self.handle, d_out))
+
     def finish(self, contig):
         nb, _ = self.nbins(contig)
         out = numpy.empty(nb, dtype=numpy.float64)

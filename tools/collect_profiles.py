@@ -31,7 +31,8 @@ for line in out.splitlines():
         vals[p[0]] = float(p[2])
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-    json.dump({"cov_accumulate_bytes_per_launch": traffic, "source": "profiles/%s_pmc_cov_accumulate.txt" % tag,
+    nreads = float(os.environ.get("COV_READS_PER_LAUNCH", "600000000"))
+    json.dump({"cov_accumulate_bytes_per_launch": traffic, "reads_per_launch": nreads, "cov_accumulate_bytes_per_read": traffic / nreads, "source": "profiles/%s_pmc_cov_accumulate.txt" % tag,
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) KB; x2 = gfx950 FETCH_SIZE correction for wide coalesced reads",
                "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"]},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
