@@ -292,7 +292,10 @@ def test_dbscan_gen_golden(db, golden_dir):
 @pytest.mark.parametrize("n,span,eps,m,seed", [(200_000, 2_000_000, 500, 3, 1),      # dense: x-clusters of thousands of points
                                                (300_000, 100_000, 50, 3, 2),          # one giant x-cluster
                                                (150_000, 50_000_000, 500, 4, 3), (100_000, 5_000_000, 175, 2, 4),
-                                               (50_000, 1_000, 5, 3, 5), (257, 300, 500, 3, 6), (100_000, 3_000_000, 300, 9, 7)])
+                                               (50_000, 1_000, 5, 3, 5), (257, 300, 500, 3, 6), (100_000, 3_000_000, 300, 9, 7),
+                                               (60_000, 400_000, 2000, 64, 8),      # largest m of the fused chained-scan path
+                                               (60_000, 400_000, 2000, 65, 9), (5000, 20_000, 900, 200, 10),   # general multi-kernel path
+                                               (1025, 4000, 50, 3, 11), (2048, 9000, 60, 2, 12), (1, 10, 5, 3, 13)])
 def test_dbscan_dense_vs_oracle(db, n, span, eps, m, seed):
     rng = np.random.default_rng(seed)
     x = np.sort(rng.integers(0, span, n))

@@ -42,6 +42,7 @@ struct tdt_ctx {
     int num_cu = 256;
     tdt_buf scratch[TDT_NSCRATCH];
     tdt_buf pinned[TDT_NPINNED];
+    int *d_async_err = nullptr;  // device word kernels OR into (bounded-spin timeouts); checked by tdt_ctx_sync
 };
 
 int tdt_scratch(tdt_ctx *ctx, int slot, size_t bytes, void **out);

@@ -41,6 +41,8 @@ extern "C" int tdt_ctx_create(int device, tdt_ctx **out) {
     TDT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     TDT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) TDT_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    TDT_HIP(hipMalloc((void **)&c->d_async_err, 64));
+    TDT_HIP(hipMemset(c->d_async_err, 0, 64));
     c->stream = c->own_stream;
     *out = c;
     return TDT_OK;
@@ -51,6 +53,7 @@ extern "C" void tdt_ctx_destroy(tdt_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy_stream);
+    if (c->d_async_err) (void)hipFree(c->d_async_err);
     for (auto &b : c->scratch)
         if (b.p) (void)hipFree(b.p);
     for (auto &b : c->pinned)
@@ -67,6 +70,13 @@ extern "C" int tdt_ctx_sync(tdt_ctx *c) {
     TDT_HIP(hipSetDevice(c->device));
     TDT_HIP(hipStreamSynchronize(c->copy_stream));
     TDT_HIP(hipStreamSynchronize(c->stream));
+    int err = 0;
+    TDT_HIP(hipMemcpy(&err, c->d_async_err, 4, hipMemcpyDeviceToHost));
+    if (err) {
+        TDT_HIP(hipMemset(c->d_async_err, 0, 4));
+        tdt_set_error("a device scan timed out waiting for a predecessor tile (internal error %d)", err);
+        return TDT_E_HIP;
+    }
     return TDT_OK;
 }
 
@@ -114,5 +124,14 @@ int tdt_pinned(tdt_ctx *c, int slot, size_t bytes, void **out) {
         b.cap = bytes;
     }
     *out = b.p;
+    return TDT_OK;
+}
+
+// debugging aid: the 16 words behind the async error word (spin statistics in DBF_DEBUG_SPINS builds)
+extern "C" int tdt_debug_words(tdt_ctx *c, unsigned *out16, int reset) {
+    if (!c || !out16) return TDT_E_ARG;
+    TDT_HIP(hipStreamSynchronize(c->stream));
+    TDT_HIP(hipMemcpy(out16, c->d_async_err, 64, hipMemcpyDeviceToHost));
+    if (reset) TDT_HIP(hipMemset(c->d_async_err, 0, 64));
     return TDT_OK;
 }

@@ -38,6 +38,8 @@ __device__ __forceinline__ int db_bucket(const int *__restrict__ boff, int nb, i
 
 __device__ __forceinline__ unsigned db_absdiff(unsigned a, unsigned b) { return a > b ? a - b : b - a; }
 
+#include "tdt_dbscan_fused.h"
+
 // ---------------------------------------------------------------------------------------- scan
 // In-place inclusive scan of a u32 array: reduce tiles -> scan the tile sums (one block) -> apply.
 __global__ __launch_bounds__(DB_THREADS) void scan_reduce(const unsigned *__restrict__ v, int n, unsigned *__restrict__ tsum) {
@@ -398,6 +400,49 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         TDT_CHECK_LAUNCH();
         return TDT_OK;
     }
+    const bool fused = m <= DBF_M_MAX;
+    if (fused) {
+        // control block + three tile-status arrays, zeroed by ONE memset (scan state must be fresh every call)
+        const int ntf = (n + DBF_TILE - 1) / DBF_TILE;
+        const size_t ctl_bytes = db_align(sizeof(DbfCtl)) + 3 * db_align((size_t)ntf * 8);
+        void *cb = nullptr;
+        rc = tdt_scratch(ctx, 8, ctl_bytes, &cb);
+        if (rc) return rc;
+        TDT_HIP(hipMemsetAsync(cb, 0, ctl_bytes, st));
+        DbfCtl *ctl = (DbfCtl *)cb;
+        ull *st_x = (ull *)((char *)cb + db_align(sizeof(DbfCtl)));
+        ull *st_a = (ull *)((char *)st_x + db_align((size_t)ntf * 8));
+        ull *st_b = (ull *)((char *)st_a + db_align((size_t)ntf * 8));
+        hipLaunchKernelGGL(dbf_x, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, st_x, ctl,
+                           ctx->d_async_err, d_xlab, d_runbase, d_seg0, d_seg1);
+        TDT_CHECK_LAUNCH();
+        if (mode == 1) {
+            hipLaunchKernelGGL(dbx_final, dim3(blocks_nb), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_boff, nb,
+                               (const unsigned *)d_runbase, d_labels, (long long *)d_last_id);
+            TDT_CHECK_LAUNCH();
+            return TDT_OK;
+        }
+        hipLaunchKernelGGL(dby_rank, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, d_y, n, (const int *)d_seg0,
+                           (const int *)d_seg1, d_ys, d_ord, d_key, d_lbeg, d_lend, &ctl->nlarge);
+        TDT_CHECK_LAUNCH();
+        unsigned nlarge = 0;
+        TDT_HIP(hipMemcpyAsync(&nlarge, &ctl->nlarge, 4, hipMemcpyDeviceToHost, st));
+        TDT_HIP(hipStreamSynchronize(st));
+        if (nlarge) {
+            rc = tdt_segsort_u64(ctx, 4, d_key, d_ksorted, (size_t)n, nlarge, d_lbeg, d_lend);
+            if (rc) return rc;
+            hipLaunchKernelGGL(dby_unpack_large, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
+                               (const int *)d_seg1, (const unsigned long long *)d_ksorted, d_ys, d_ord);
+            TDT_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(dbf_y, dim3(ntf), dim3(DBF_THREADS), 0, st, (const int *)d_xlab, (const unsigned *)d_ys, (const unsigned *)d_ord,
+                           n, (const int *)d_boff, nb, (const unsigned *)d_runbase, (ull)eps, m, st_a, st_b, ctl, ctx->d_async_err, d_labels,
+                           (long long *)d_last_id);
+        if (d_last_id && nb > 1)
+            hipLaunchKernelGGL(dbf_empty_buckets, dim3((nb + 255) / 256), dim3(256), 0, st, (const int *)d_boff, nb, (long long *)d_last_id);
+        TDT_CHECK_LAUNCH();
+        return TDT_OK;
+    }
     hipLaunchKernelGGL(dbx_flags, dim3(blocks4), dim3(DB_THREADS), 0, st, d_x, n, (const int *)d_boff, nb,
                        (unsigned long long)eps, m, d_px, d_sx);
     TDT_CHECK_LAUNCH();
@@ -604,3 +649,9 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     TDT_HIP(hipMemcpy(labels_out, dlab, n * 8, hipMemcpyDeviceToHost));
     return TDT_OK;
 }
+
+#ifdef DBF_DEBUG_SPINS
+extern "C" int tdt_debug_ts(unsigned long long *out, size_t bytes) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_ts), bytes) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -2,10 +2,11 @@
 # tools/build_variant.sh <name> <extra -D flags...> : experimental libtiddit_hip variants under gpurun-visible build/
 set -e
 NAME=$1; shift
+SRC=${VARIANT_SRC:-tdt_coverage}
 cd "$(dirname "$0")/.."
 mkdir -p variants
 OBJS=""
-for f in tdt_ctx tdt_gc tdt_dbscan tdt_sort tdt_bam; do OBJS="$OBJS tiddit_amd/csrc/$f.o"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c tiddit_amd/csrc/tdt_coverage.hip -o variants/cov_$NAME.o 2>/dev/null
+for f in tdt_ctx tdt_coverage tdt_gc tdt_dbscan tdt_sort tdt_bam; do [ "$f" != "$SRC" ] && OBJS="$OBJS tiddit_amd/csrc/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c tiddit_amd/csrc/$SRC.hip -o variants/cov_$NAME.o 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS variants/cov_$NAME.o -o variants/lib_$NAME.so
 echo built variants/lib_$NAME.so
