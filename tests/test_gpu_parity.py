@@ -318,6 +318,12 @@ def test_dbscan_config3_sha(db):
     assert np.array_equal(lab, oracle.dbscan_main(pts, 500, 3))
 
 
+def test_dbscan_many_tiles(db):
+    # > 2048 tiles of 4096 points: tile prefixes come from the tile_scan launch instead of the in-kernel reduction
+    pts = synth.gen_points(9_000_000, seed=5)
+    assert np.array_equal(db.main(pts, 500, 3), oracle.dbscan_main(pts, 500, 3))
+
+
 def test_dbscan_negative_and_offset_coordinates(db):
     rng = np.random.default_rng(3)
     x = np.sort(rng.integers(-50_000, 50_000, 5000)) + (1 << 40)

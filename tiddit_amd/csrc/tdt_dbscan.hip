@@ -215,6 +215,8 @@ __global__ __launch_bounds__(DB_THREADS) void dby_rank(const int *__restrict__ x
         ord[s0 + rank] = k;
     } else {
         key64[k] = ((unsigned long long)yk << 32) | (unsigned)k;
+        ys[k] = yk;   // placeholders: the speculative y pass runs before the large clusters are sorted and must
+        ord[k] = k;   // scatter in bounds; dby_unpack_large overwrites both
         if (k == s0) {
             const unsigned idx = atomicAdd(nlarge, 1u);
             lbeg[idx] = s0;
@@ -402,19 +404,34 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
     }
     const bool fused = m <= DBF_M_MAX;
     if (fused) {
-        // control block + three tile-status arrays, zeroed by ONE memset (scan state must be fresh every call)
+        // ballot-mask tiles; cross-tile prefixes from a one-workgroup scan between launches
         const int ntf = (n + DBF_TILE - 1) / DBF_TILE;
-        const size_t ctl_bytes = db_align(sizeof(DbfCtl)) + 3 * db_align((size_t)ntf * 8);
+        const size_t nw = (size_t)ntf * DBF_WORDS + 2;   // whole tiles: kernels store all 64 words of their tile
+        const size_t mask_bytes = db_align(nw * 8);
+        const size_t ctl_bytes = db_align(sizeof(DbfCtl)) + 3 * db_align((size_t)ntf * 8) + 7 * mask_bytes;
         void *cb = nullptr;
         rc = tdt_scratch(ctx, 8, ctl_bytes, &cb);
         if (rc) return rc;
-        TDT_HIP(hipMemsetAsync(cb, 0, ctl_bytes, st));
-        DbfCtl *ctl = (DbfCtl *)cb;
-        ull *st_x = (ull *)((char *)cb + db_align(sizeof(DbfCtl)));
-        ull *st_a = (ull *)((char *)st_x + db_align((size_t)ntf * 8));
-        ull *st_b = (ull *)((char *)st_a + db_align((size_t)ntf * 8));
-        hipLaunchKernelGGL(dbf_x, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, st_x, ctl,
-                           ctx->d_async_err, d_xlab, d_runbase, d_seg0, d_seg1);
+        char *q = (char *)cb;
+        DbfCtl *ctl = (DbfCtl *)q; q += db_align(sizeof(DbfCtl));
+        ull *agg_x = (ull *)q; q += db_align((size_t)ntf * 8);
+        ull *agg_1 = (ull *)q; q += db_align((size_t)ntf * 8);
+        ull *agg_2 = (ull *)q; q += db_align((size_t)ntf * 8);
+        ull *PM = (ull *)q; q += mask_bytes;
+        ull *PY = (ull *)q; q += mask_bytes;
+        ull *HM = (ull *)q; q += mask_bytes;
+        ull *BM = (ull *)q; q += mask_bytes;
+        ull *EM = (ull *)q; q += mask_bytes;
+        ull *S1M = (ull *)q; q += mask_bytes;
+        ull *FM = (ull *)q; q += mask_bytes;
+        TDT_HIP(hipMemsetAsync(ctl, 0, sizeof(DbfCtl), st));
+        TDT_HIP(hipMemsetAsync(PM, 0, 8, st));   // the word before the array
+        TDT_HIP(hipMemsetAsync(PM + (size_t)ntf * DBF_WORDS + 1, 0, 8, st));   // ... and the one after the last tile
+        TDT_HIP(hipMemsetAsync(PY, 0, 8, st));
+        hipLaunchKernelGGL(dbm_x_masks, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x);
+        if (ntf > DBM_INLINE_PREFIX_MAX) hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, agg_x, ntf);
+        hipLaunchKernelGGL(dbm_x_labels, dim3(ntf), dim3(DBF_THREADS), 0, st, (const ull *)PM, (const ull *)agg_x, n, (const int *)d_boff, nb,
+                           m, d_xlab, d_runbase, d_seg0, d_seg1);
         TDT_CHECK_LAUNCH();
         if (mode == 1) {
             hipLaunchKernelGGL(dbx_final, dim3(blocks_nb), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_boff, nb,
@@ -425,19 +442,31 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         hipLaunchKernelGGL(dby_rank, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, d_y, n, (const int *)d_seg0,
                            (const int *)d_seg1, d_ys, d_ord, d_key, d_lbeg, d_lend, &ctl->nlarge);
         TDT_CHECK_LAUNCH();
-        unsigned nlarge = 0;
-        TDT_HIP(hipMemcpyAsync(&nlarge, &ctl->nlarge, 4, hipMemcpyDeviceToHost, st));
-        TDT_HIP(hipStreamSynchronize(st));
-        if (nlarge) {
+        // The y pass is enqueued right away on the assumption that no x-cluster exceeded DB_SMALL members (the
+        // usual case), so the GPU never idles on a mid-pipeline readback; the counter is checked afterwards
+        // and only then are the large clusters sorted and the y pass repeated.
+        for (int attempt = 0; attempt < 2; attempt++) {
+            hipLaunchKernelGGL(dbm_y_masks, dim3(ntf), dim3(DBF_THREADS), 0, st, (const int *)d_xlab, (const unsigned *)d_ys, n,
+                               (const int *)d_boff, nb, (ull)eps, m, PY, HM, BM, agg_1);
+            if (ntf > DBM_INLINE_PREFIX_MAX) hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, agg_1, ntf);
+            hipLaunchKernelGGL(dbm_y_mid, dim3(ntf), dim3(DBF_THREADS), 0, st, (const ull *)PY, (const ull *)HM, (const ull *)BM,
+                               (const ull *)agg_1, n, m, EM, S1M, FM, agg_2);
+            if (ntf > DBM_INLINE_PREFIX_MAX) hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, agg_2, ntf);
+            hipLaunchKernelGGL(dbm_y_final, dim3(ntf), dim3(DBF_THREADS), 0, st, (const int *)d_xlab, (const unsigned *)d_ord, (const ull *)BM,
+                               (const ull *)EM, (const ull *)S1M, (const ull *)FM, (const ull *)agg_2, n, (const int *)d_boff, nb,
+                               (const unsigned *)d_runbase, d_labels, (long long *)d_last_id);
+            TDT_CHECK_LAUNCH();
+            if (attempt == 1) break;
+            unsigned nlarge = 0;
+            TDT_HIP(hipMemcpyAsync(&nlarge, &ctl->nlarge, 4, hipMemcpyDeviceToHost, st));
+            TDT_HIP(hipStreamSynchronize(st));
+            if (!nlarge) break;
             rc = tdt_segsort_u64(ctx, 4, d_key, d_ksorted, (size_t)n, nlarge, d_lbeg, d_lend);
             if (rc) return rc;
             hipLaunchKernelGGL(dby_unpack_large, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
                                (const int *)d_seg1, (const unsigned long long *)d_ksorted, d_ys, d_ord);
             TDT_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL(dbf_y, dim3(ntf), dim3(DBF_THREADS), 0, st, (const int *)d_xlab, (const unsigned *)d_ys, (const unsigned *)d_ord,
-                           n, (const int *)d_boff, nb, (const unsigned *)d_runbase, (ull)eps, m, st_a, st_b, ctl, ctx->d_async_err, d_labels,
-                           (long long *)d_last_id);
         if (d_last_id && nb > 1)
             hipLaunchKernelGGL(dbf_empty_buckets, dim3((nb + 255) / 256), dim3(256), 0, st, (const int *)d_boff, nb, (long long *)d_last_id);
         TDT_CHECK_LAUNCH();
