@@ -8,7 +8,7 @@
 //
 // Kernel shape (HBM-bound streaming, 11 B/read, no MFMA):
 //   * one workgroup = 4 waves walks a contiguous chunk of COV_READS_PER_BLOCK coordinate-sorted
-//     reads, 4 reads per lane per step (16-byte coalesced loads of start/end, 4 B of mapq, 8 B of flag);
+//     reads, 8 reads per lane per step (16-byte coalesced loads of start/end/flag, 8 B of mapq);
 //   * each lane folds its reads' contributions into two registers (bin K and K+1, K = first bin of
 //     its first read); a wavefront segmented reduction over runs of equal K (sorted input => long
 //     runs) merges the 64 lanes, so only run-tail lanes touch memory;
@@ -19,7 +19,9 @@
 #include "tdt_common.h"
 
 #define COV_THREADS 256
-#define COV_RPL 4                                  // reads per lane per step
+#ifndef COV_RPL
+#define COV_RPL 8                                  // reads per lane per step (4 or 8)
+#endif
 #define COV_TILE (COV_THREADS * COV_RPL)           // 1024 reads per workgroup step
 #ifndef COV_STEPS
 #define COV_STEPS 8
@@ -115,33 +117,44 @@ __device__ __noinline__ void cov_global_add(unsigned long long *acc, int bin, un
 }
 
 struct CovTile {
-    int4 s, e;
-    unsigned mq;
-    uint2 fl;
+    int s[COV_RPL], e[COV_RPL];
+    unsigned mq[COV_RPL / 4];   // 4 mapq bytes per word
+    unsigned fl[COV_RPL / 2];   // 2 flags per word
 };
 
 __device__ __forceinline__ CovTile cov_load(const CovItem &P, unsigned long long idx, unsigned long long r1) {
     CovTile t;
     if (P.aligned && idx + COV_RPL <= r1) {
-        t.s = *reinterpret_cast<const int4 *>(P.start + idx);
-        t.e = *reinterpret_cast<const int4 *>(P.end + idx);
-        t.mq = *reinterpret_cast<const unsigned *>(P.mapq + idx);
-        t.fl = *reinterpret_cast<const uint2 *>(P.flag + idx);
+#pragma unroll
+        for (int k = 0; k < COV_RPL / 4; k++) {
+            const int4 s4 = *reinterpret_cast<const int4 *>(P.start + idx + 4 * k);
+            const int4 e4 = *reinterpret_cast<const int4 *>(P.end + idx + 4 * k);
+            t.s[4 * k] = s4.x; t.s[4 * k + 1] = s4.y; t.s[4 * k + 2] = s4.z; t.s[4 * k + 3] = s4.w;
+            t.e[4 * k] = e4.x; t.e[4 * k + 1] = e4.y; t.e[4 * k + 2] = e4.z; t.e[4 * k + 3] = e4.w;
+        }
+#if COV_RPL == 8
+        const uint2 m2 = *reinterpret_cast<const uint2 *>(P.mapq + idx);
+        const uint4 f4 = *reinterpret_cast<const uint4 *>(P.flag + idx);
+        t.mq[0] = m2.x; t.mq[1] = m2.y;
+        t.fl[0] = f4.x; t.fl[1] = f4.y; t.fl[2] = f4.z; t.fl[3] = f4.w;
+#else
+        t.mq[0] = *reinterpret_cast<const unsigned *>(P.mapq + idx);
+        const uint2 f2 = *reinterpret_cast<const uint2 *>(P.flag + idx);
+        t.fl[0] = f2.x; t.fl[1] = f2.y;
+#endif
     } else {
-        int sv[COV_RPL], ev[COV_RPL];
-        unsigned mq = 0, f[COV_RPL];
+#pragma unroll
+        for (int k = 0; k < COV_RPL / 4; k++) t.mq[k] = 0;
+#pragma unroll
+        for (int k = 0; k < COV_RPL / 2; k++) t.fl[k] = 0;
 #pragma unroll
         for (int j = 0; j < COV_RPL; j++) {
             const bool ok = idx + j < r1;
-            sv[j] = ok ? P.start[idx + j] : 0;
-            ev[j] = ok ? P.end[idx + j] : 1;
-            mq |= (ok ? (unsigned)P.mapq[idx + j] : 0u) << (8 * j);
-            f[j] = ok ? (unsigned)P.flag[idx + j] : 0x4u;  // padding lanes look unmapped
+            t.s[j] = ok ? P.start[idx + j] : 0;
+            t.e[j] = ok ? P.end[idx + j] : 1;
+            t.mq[j / 4] |= (ok ? (unsigned)P.mapq[idx + j] : 0u) << (8 * (j & 3));
+            t.fl[j / 2] |= (ok ? (unsigned)P.flag[idx + j] : 0x4u) << (16 * (j & 1));  // padding lanes look unmapped
         }
-        t.s = make_int4(sv[0], sv[1], sv[2], sv[3]);
-        t.e = make_int4(ev[0], ev[1], ev[2], ev[3]);
-        t.mq = mq;
-        t.fl = make_uint2(f[0] | (f[1] << 16), f[2] | (f[3] << 16));
     }
     return t;
 }
@@ -232,10 +245,15 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         CovTile nxt = cur;
         if (t0 + COV_TILE < r1) nxt = cov_load(I, t0 + COV_TILE + (unsigned long long)tid * COV_RPL, r1);
 
-        const int sv[COV_RPL] = {cur.s.x, cur.s.y, cur.s.z, cur.s.w};
-        const int ev[COV_RPL] = {cur.e.x, cur.e.y, cur.e.z, cur.e.w};
-        const unsigned mq[COV_RPL] = {cur.mq & 0xff, (cur.mq >> 8) & 0xff, (cur.mq >> 16) & 0xff, cur.mq >> 24};
-        const unsigned fl[COV_RPL] = {cur.fl.x & 0xffff, cur.fl.x >> 16, cur.fl.y & 0xffff, cur.fl.y >> 16};
+        int sv[COV_RPL], ev[COV_RPL];
+        unsigned mq[COV_RPL], fl[COV_RPL];
+#pragma unroll
+        for (int j = 0; j < COV_RPL; j++) {
+            sv[j] = cur.s[j];
+            ev[j] = cur.e[j];
+            mq[j] = (cur.mq[j / 4] >> (8 * (j & 3))) & 0xffu;
+            fl[j] = (cur.fl[j / 2] >> (16 * (j & 1))) & 0xffffu;
+        }
 
         // lane key K: first bin of the lane's first read (the only division of the step).  A read whose
         // first bin is K or K+1 and whose last bin is at most one further is folded into the three
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         const unsigned Kz = (unsigned)K * z;
         unsigned long long a0 = 0, a1 = 0, a2 = 0;
 #ifdef COV_EXP_LOADONLY
-        a0 = (unsigned)(sv[0] + sv[1] + sv[2] + sv[3] + ev[0] + ev[1] + ev[2] + ev[3]) + mq[0] + mq[3] + fl[0] + fl[3];
+        for (int j = 0; j < COV_RPL; j++) a0 += (unsigned)(sv[j] + ev[j]) + mq[j] + fl[j];
         if (a0 == 0x1234567ull) contribute(K, a0);
         cur = nxt;
         continue;
@@ -524,8 +542,8 @@ static CovItem cov_item(tdt_cov *c, int tid, const int32_t *d_start, const int32
     it.acc = c->d_acc + c->off[tid];
     it.lut_end = c->d_lut_end + (size_t)tid * ((size_t)c->bin_size + 1);
     it.nbins = (int)c->nbins[tid];
-    it.aligned = (((uintptr_t)d_start | (uintptr_t)d_end) & 15) == 0 && ((uintptr_t)d_mapq & 3) == 0 &&
-                 ((uintptr_t)d_flag & 7) == 0;
+    it.aligned = (((uintptr_t)d_start | (uintptr_t)d_end) & 15) == 0 && ((uintptr_t)d_mapq & (COV_RPL - 1)) == 0 &&
+                 ((uintptr_t)d_flag & (2 * COV_RPL - 1)) == 0;
     it.first_block = 0;
     it.pad_ = 0;
     return it;
