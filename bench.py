@@ -173,6 +173,19 @@ def main():
                                             "update_coverage loop, arrays in memory; bins verified bit-identical to the GPU's"
                                             % (k, C, sum(n_reads[:k]), sum(nbins[:k]))}
         result["parity_checked"] = True
+    # host-buffer path (tdt_cov_push: pinned double-buffered hipMemcpyAsync + kernel), PCIe/host-memcpy bound;
+    # reported for completeness, never the headline value
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        hs, he, hm, hf = [t.cpu().numpy() for t in reads[0]]
+        hf = hf.view(np.uint16)
+        hist.reset()
+        ctx.sync()
+        t1 = time.perf_counter()
+        hist.push(0, hs, he, hm, hf, args.min_q)
+        ctx.sync()
+        t_host = time.perf_counter() - t1
+        result["host_push"] = {"reads_per_sec": len(hs) / t_host, "GB_per_s": 11.0 * len(hs) / t_host / 1e9,
+                               "note": "one contig (%d reads) from pageable numpy arrays through the pinned staging ring" % len(hs)}
     del reads, outs, out_all
     hist.close()
     torch.cuda.empty_cache()

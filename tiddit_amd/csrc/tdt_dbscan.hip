@@ -21,8 +21,8 @@
 #define DB_TILE (DB_THREADS * DB_ITEMS)
 #define DB_SMALL 128  // x-clusters up to this many members are y-sorted by in-kernel rank counting
 
-int tdt_segsort_u64(tdt_ctx *ctx, int slot, const unsigned long long *d_in, unsigned long long *d_out, size_t n,
-                    unsigned nseg, const unsigned *d_begin, const unsigned *d_end);
+int tdt_radix_sort_pairs(tdt_ctx *ctx, unsigned long long *keys, unsigned *vals, unsigned long long *keys_tmp, unsigned *vals_tmp,
+                         size_t n, unsigned long long bitmask, unsigned long long **out_keys, unsigned **out_vals);   // tdt_sort.hip
 
 // largest b in [0, nb) with boff[b] <= i
 __device__ __forceinline__ int db_bucket(const int *__restrict__ boff, int nb, int i) {
@@ -188,55 +188,63 @@ __global__ __launch_bounds__(DB_THREADS) void dbx_final(const int *__restrict__ 
 }
 
 // -------------------------------------------------------------------------------------- y pass
-// stable sort by y inside every x-cluster (DBSCAN.py:76-81): rank counting for small clusters,
-// unique 64-bit keys (y << 32 | index) handed to the segmented radix sort for large ones
+// stable sort by y inside every x-cluster (DBSCAN.py:76-81): rank counting for small clusters; members of
+// larger clusters are flagged and go through the radix sort below
 __global__ __launch_bounds__(DB_THREADS) void dby_rank(const int *__restrict__ xlab, const unsigned *__restrict__ y, int n,
                                                        const int *__restrict__ seg_start, const int *__restrict__ seg_end,
                                                        unsigned *__restrict__ ys, unsigned *__restrict__ ord,
-                                                       unsigned long long *__restrict__ key64, unsigned *__restrict__ lbeg,
-                                                       unsigned *__restrict__ lend, unsigned *__restrict__ nlarge) {
+                                                       unsigned *__restrict__ lflag, unsigned *__restrict__ anylarge) {
     const int k = blockIdx.x * DB_THREADS + threadIdx.x;
     if (k >= n) return;
     const int l = xlab[k];
+    unsigned large = 0;
     if (l < 0) {
         ys[k] = 0;
         ord[k] = k;
-        return;
-    }
-    const int s0 = seg_start[l], s1 = seg_end[l];
-    const unsigned yk = y[k];
-    if (s1 - s0 <= DB_SMALL) {
-        int rank = 0;
-        for (int j = s0; j < s1; j++) {
-            const unsigned yj = y[j];
-            rank += (yj < yk) || (yj == yk && j < k);
-        }
-        ys[s0 + rank] = yk;
-        ord[s0 + rank] = k;
     } else {
-        key64[k] = ((unsigned long long)yk << 32) | (unsigned)k;
-        ys[k] = yk;   // placeholders: the speculative y pass runs before the large clusters are sorted and must
-        ord[k] = k;   // scatter in bounds; dby_unpack_large overwrites both
-        if (k == s0) {
-            const unsigned idx = atomicAdd(nlarge, 1u);
-            lbeg[idx] = s0;
-            lend[idx] = s1;
+        const int s0 = seg_start[l], s1 = seg_end[l];
+        const unsigned yk = y[k];
+        if (s1 - s0 <= DB_SMALL) {
+            int rank = 0;
+            for (int j = s0; j < s1; j++) {
+                const unsigned yj = y[j];
+                rank += (yj < yk) || (yj == yk && j < k);
+            }
+            ys[s0 + rank] = yk;
+            ord[s0 + rank] = k;
+        } else {
+            large = 1;
+            ys[k] = yk;   // placeholders: the speculative y pass runs before the large clusters are sorted and must
+            ord[k] = k;   // scatter in bounds; dby_large_scatter overwrites both
+            if (k == s0) *anylarge = 1u;
         }
+    }
+    lflag[k] = large;
+}
+
+// members of large clusters, compacted in position order: key = cluster id << 32 | y, value = position
+__global__ __launch_bounds__(DB_THREADS) void dby_large_compact(const int *__restrict__ xlab, const unsigned *__restrict__ y, int n,
+                                                                const unsigned *__restrict__ lincl, unsigned long long *__restrict__ ck,
+                                                                unsigned *__restrict__ cv, unsigned *__restrict__ cpos) {
+    const int k = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (k >= n) return;
+    const unsigned inc = lincl[k], prev = k ? lincl[k - 1] : 0u;
+    if (inc != prev) {
+        ck[prev] = ((unsigned long long)(unsigned)xlab[k] << 32) | y[k];
+        cv[prev] = (unsigned)k;
+        cpos[prev] = (unsigned)k;
     }
 }
 
-__global__ __launch_bounds__(DB_THREADS) void dby_unpack_large(const int *__restrict__ xlab, int n, const int *__restrict__ seg_start,
-                                                               const int *__restrict__ seg_end,
-                                                               const unsigned long long *__restrict__ ksorted,
-                                                               unsigned *__restrict__ ys, unsigned *__restrict__ ord) {
-    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
-    if (i >= n) return;
-    const int l = xlab[i];
-    if (l < 0) return;
-    if (seg_end[l] - seg_start[l] <= DB_SMALL) return;
-    const unsigned long long key = ksorted[i];
-    ys[i] = (unsigned)(key >> 32);
-    ord[i] = (unsigned)key;
+// clusters are contiguous and the compaction kept position order, so the j-th sorted pair belongs at the j-th position
+__global__ __launch_bounds__(DB_THREADS) void dby_large_scatter(const unsigned long long *__restrict__ ksorted, const unsigned *__restrict__ vsorted,
+                                                                const unsigned *__restrict__ cpos, int nl, unsigned *__restrict__ ys,
+                                                                unsigned *__restrict__ ord) {
+    const int j = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (j >= nl) return;
+    const unsigned p = cpos[j];
+    ys[p] = (unsigned)ksorted[j];
+    ord[p] = vsorted[j];
 }
 
 // window test on the sorted y of each x-cluster (DBSCAN.py:90-99) and sub-run starts (:101-110)
@@ -322,6 +330,34 @@ static int db_scan_inplace(tdt_ctx *ctx, unsigned *d_v, int n, unsigned *d_tsum)
     return TDT_OK;
 }
 
+int tdt_scan_u32_inclusive(tdt_ctx *ctx, unsigned *d_v, int n, unsigned *d_tsum) { return db_scan_inplace(ctx, d_v, n, d_tsum); }
+
+// y-sort of the clusters larger than DB_SMALL (runs only when dby_rank flagged any)
+static int db_sort_large(tdt_ctx *ctx, const int *d_xlab, const unsigned *d_y, int n, unsigned *d_lflag, unsigned *d_tsum,
+                         unsigned long long *d_k0, unsigned long long *d_k1, unsigned *d_v0, unsigned *d_v1, unsigned *d_cpos,
+                         unsigned *d_ys, unsigned *d_ord) {
+    hipStream_t st = ctx->stream;
+    int rc = db_scan_inplace(ctx, d_lflag, n, d_tsum);
+    if (rc) return rc;
+    unsigned nl = 0;
+    TDT_HIP(hipMemcpyAsync(&nl, d_lflag + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipStreamSynchronize(st));
+    if (!nl) return TDT_OK;
+    const int blocks1 = (n + DB_THREADS - 1) / DB_THREADS;
+    hipLaunchKernelGGL(dby_large_compact, dim3(blocks1), dim3(DB_THREADS), 0, st, d_xlab, d_y, n, (const unsigned *)d_lflag, d_k0, d_v0, d_cpos);
+    TDT_CHECK_LAUNCH();
+    unsigned long long mask = 0xffffffffull;                                 // y: all 32 bits
+    mask |= ((1ull << tdt_ceil_log2_u64((uint64_t)n + 1)) - 1ull) << 32;     // cluster id < number of runs <= n
+    unsigned long long *ks = nullptr;
+    unsigned *vs = nullptr;
+    rc = tdt_radix_sort_pairs(ctx, d_k0, d_v0, d_k1, d_v1, nl, mask, &ks, &vs);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dby_large_scatter, dim3((nl + DB_THREADS - 1) / DB_THREADS), dim3(DB_THREADS), 0, st, (const unsigned long long *)ks,
+                       (const unsigned *)vs, (const unsigned *)d_cpos, (int)nl, d_ys, d_ord);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
 extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, size_t n_, const int64_t *bucket_off,
                                  int nb, uint64_t eps, int m, int mode, double *d_labels, int64_t *d_last_id) {
     if (!ctx || nb < 1 || !bucket_off || m < 2 || (mode != 0 && mode != 1)) {
@@ -352,7 +388,8 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
     const size_t nlarge_cap = N / DB_SMALL + 1;
     size_t total = sz_boff + sz_rb + db_align(256) /*counters*/ + db_align((size_t)nt * 4) +
                    2 * db_align(N) /*px,py*/ + 3 * db_align(N * 4) /*sx,sy,ex*/ + 3 * db_align(N * 4) /*xlab,seg_start,seg_end*/ +
-                   2 * db_align(N * 4) /*ys,ord*/ + 2 * db_align(N * 8) /*key64 in/out*/ + 2 * db_align(nlarge_cap * 4);
+                   2 * db_align(N * 4) /*ys,ord*/ + 2 * db_align(N * 8) /*sort keys in/out*/ + 4 * db_align(N * 4) /*sort vals, cpos, lflag*/ +
+                   0 * nlarge_cap;
     void *base = nullptr;
     int rc = tdt_scratch(ctx, 3, total, &base);
     if (rc) return rc;
@@ -378,8 +415,10 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
     unsigned *d_ord = (unsigned *)carve(N * 4);
     unsigned long long *d_key = (unsigned long long *)carve(N * 8);
     unsigned long long *d_ksorted = (unsigned long long *)carve(N * 8);
-    unsigned *d_lbeg = (unsigned *)carve(nlarge_cap * 4);
-    unsigned *d_lend = (unsigned *)carve(nlarge_cap * 4);
+    unsigned *d_v0 = (unsigned *)carve(N * 4);
+    unsigned *d_v1 = (unsigned *)carve(N * 4);
+    unsigned *d_cpos = (unsigned *)carve(N * 4);
+    unsigned *d_lflag = (unsigned *)carve(N * 4);
 
     // bucket offsets: stage through pinned memory so the copy is truly asynchronous
     void *h_stage = nullptr;
@@ -440,7 +479,7 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
             return TDT_OK;
         }
         hipLaunchKernelGGL(dby_rank, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, d_y, n, (const int *)d_seg0,
-                           (const int *)d_seg1, d_ys, d_ord, d_key, d_lbeg, d_lend, &ctl->nlarge);
+                           (const int *)d_seg1, d_ys, d_ord, d_lflag, &ctl->nlarge);
         TDT_CHECK_LAUNCH();
         // The y pass is enqueued right away on the assumption that no x-cluster exceeded DB_SMALL members (the
         // usual case), so the GPU never idles on a mid-pipeline readback; the counter is checked afterwards
@@ -461,11 +500,8 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
             TDT_HIP(hipMemcpyAsync(&nlarge, &ctl->nlarge, 4, hipMemcpyDeviceToHost, st));
             TDT_HIP(hipStreamSynchronize(st));
             if (!nlarge) break;
-            rc = tdt_segsort_u64(ctx, 4, d_key, d_ksorted, (size_t)n, nlarge, d_lbeg, d_lend);
+            rc = db_sort_large(ctx, d_xlab, d_y, n, d_lflag, d_tsum, d_key, d_ksorted, d_v0, d_v1, d_cpos, d_ys, d_ord);
             if (rc) return rc;
-            hipLaunchKernelGGL(dby_unpack_large, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
-                               (const int *)d_seg1, (const unsigned long long *)d_ksorted, d_ys, d_ord);
-            TDT_CHECK_LAUNCH();
         }
         if (d_last_id && nb > 1)
             hipLaunchKernelGGL(dbf_empty_buckets, dim3((nb + 255) / 256), dim3(256), 0, st, (const int *)d_boff, nb, (long long *)d_last_id);
@@ -488,18 +524,15 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
     }
     hipLaunchKernelGGL(db_segments, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, d_seg0, d_seg1);
     hipLaunchKernelGGL(dby_rank, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, d_y, n, (const int *)d_seg0,
-                       (const int *)d_seg1, d_ys, d_ord, d_key, d_lbeg, d_lend, d_cnt);
+                       (const int *)d_seg1, d_ys, d_ord, d_lflag, d_cnt);
     TDT_CHECK_LAUNCH();
-    // x-clusters larger than DB_SMALL: one 4-byte readback decides whether the segmented sort runs
+    // x-clusters larger than DB_SMALL: one 4-byte readback decides whether the radix sort runs
     unsigned nlarge = 0;
     TDT_HIP(hipMemcpyAsync(&nlarge, d_cnt, 4, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipStreamSynchronize(st));
     if (nlarge) {
-        rc = tdt_segsort_u64(ctx, 4, d_key, d_ksorted, (size_t)n, nlarge, d_lbeg, d_lend);
+        rc = db_sort_large(ctx, d_xlab, d_y, n, d_lflag, d_tsum, d_key, d_ksorted, d_v0, d_v1, d_cpos, d_ys, d_ord);
         if (rc) return rc;
-        hipLaunchKernelGGL(dby_unpack_large, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
-                           (const int *)d_seg1, (const unsigned long long *)d_ksorted, d_ys, d_ord);
-        TDT_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(dby_flags, dim3(blocks1), dim3(DB_THREADS), 0, st, (const int *)d_xlab, n, (const int *)d_seg0,
                        (const int *)d_seg1, (const unsigned *)d_ys, (unsigned long long)eps, m, d_py, d_sy);
@@ -587,22 +620,20 @@ extern "C" int tdt_dbscan(tdt_ctx *ctx, const int64_t *data, size_t n, size_t st
 
 // -------------------------------------------------------------------- sort + cluster in one call
 __global__ __launch_bounds__(DB_THREADS) void sd_make_keys(const unsigned *__restrict__ x, int n, const int *__restrict__ boff, int nb,
-                                                           unsigned long long *__restrict__ key) {
+                                                           unsigned long long *__restrict__ key, unsigned *__restrict__ val) {
     const int i = blockIdx.x * DB_THREADS + threadIdx.x;
     if (i >= n) return;
-    const int b = db_bucket(boff, nb, i);
-    key[i] = ((unsigned long long)x[i] << 32) | (unsigned)(i - boff[b]);  // unique inside the bucket => stable order
+    key[i] = ((unsigned long long)(unsigned)db_bucket(boff, nb, i) << 32) | x[i];   // stable sort => ties keep signal order
+    val[i] = (unsigned)i;
 }
 
-__global__ __launch_bounds__(DB_THREADS) void sd_unpack(const unsigned long long *__restrict__ ksorted, const unsigned *__restrict__ y,
-                                                        int n, const int *__restrict__ boff, int nb, unsigned *__restrict__ xs,
+__global__ __launch_bounds__(DB_THREADS) void sd_unpack(const unsigned long long *__restrict__ ksorted, const unsigned *__restrict__ vsorted,
+                                                        const unsigned *__restrict__ y, int n, unsigned *__restrict__ xs,
                                                         unsigned *__restrict__ ysrt, unsigned *__restrict__ perm) {
     const int i = blockIdx.x * DB_THREADS + threadIdx.x;
     if (i >= n) return;
-    const int b = db_bucket(boff, nb, i);
-    const unsigned long long k = ksorted[i];
-    const unsigned src = (unsigned)boff[b] + (unsigned)k;
-    xs[i] = (unsigned)(k >> 32);
+    const unsigned src = vsorted[i];
+    xs[i] = (unsigned)ksorted[i];
     ysrt[i] = y[src];
     perm[i] = src;
 }
@@ -641,7 +672,7 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     if (rc) return rc;
     // device: x,y (in), xs,ys (sorted), perm, keys in/out, labels, boff
     const size_t szN4 = db_align(n * 4), szN8 = db_align(n * 8);
-    rc = tdt_scratch(ctx, 5, 5 * szN4 + 3 * szN8 + db_align((size_t)(nb + 1) * 4) + 256, &d);
+    rc = tdt_scratch(ctx, 5, 7 * szN4 + 3 * szN8 + db_align((size_t)(nb + 1) * 4) + 256, &d);
     if (rc) return rc;
     char *p = (char *)d;
     unsigned *dx = (unsigned *)p; p += szN4;
@@ -649,6 +680,8 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     unsigned *dxs = (unsigned *)p; p += szN4;
     unsigned *dys = (unsigned *)p; p += szN4;
     unsigned *dperm = (unsigned *)p; p += szN4;
+    unsigned *dv0 = (unsigned *)p; p += szN4;
+    unsigned *dv1 = (unsigned *)p; p += szN4;
     unsigned long long *dk = (unsigned long long *)p; p += szN8;
     unsigned long long *dks = (unsigned long long *)p; p += szN8;
     double *dlab = (double *)p; p += szN8;
@@ -664,12 +697,17 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     TDT_HIP(hipMemcpyAsync(dy, hy, n * 4, hipMemcpyHostToDevice, st));
     TDT_HIP(hipMemcpyAsync(dboff, hboff, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
     const int blocks = ((int)n + DB_THREADS - 1) / DB_THREADS;
-    hipLaunchKernelGGL(sd_make_keys, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned *)dx, (int)n, (const int *)dboff, nb, dk);
+    hipLaunchKernelGGL(sd_make_keys, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned *)dx, (int)n, (const int *)dboff, nb, dk, dv0);
     TDT_CHECK_LAUNCH();
-    rc = tdt_segsort_u64(ctx, 4, dk, dks, n, (unsigned)nb, (const unsigned *)dboff, (const unsigned *)dboff + 1);
+    // only the digits that can differ are sorted: the posA span and the bucket index
+    unsigned long long mask = amax > amin ? ((1ull << tdt_ceil_log2_u64((uint64_t)(amax - amin) + 1)) - 1ull) : 0ull;
+    if (nb > 1) mask |= ((1ull << tdt_ceil_log2_u64((uint64_t)nb)) - 1ull) << 32;
+    unsigned long long *ks = nullptr;
+    unsigned *vs = nullptr;
+    rc = tdt_radix_sort_pairs(ctx, dk, dv0, dks, dv1, n, mask, &ks, &vs);
     if (rc) return rc;
-    hipLaunchKernelGGL(sd_unpack, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned long long *)dks, (const unsigned *)dy, (int)n,
-                       (const int *)dboff, nb, dxs, dys, dperm);
+    hipLaunchKernelGGL(sd_unpack, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned long long *)ks, (const unsigned *)vs,
+                       (const unsigned *)dy, (int)n, dxs, dys, dperm);
     TDT_CHECK_LAUNCH();
     rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, nullptr);
     if (rc) return rc;
