@@ -117,6 +117,18 @@ int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, si
 int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
                     double eps, int m, uint32_t *perm_out, double *labels_out);
 
+/* ---- discordant-pair candidate selection ------------------------------------------------------ *
+ * Replaces the per-read predicate chain of tiddit_signal.worker (tiddit_signal.pyx:171-211): a read is a
+ * discordant-pair signal iff its contig is processed (contig_ok[tid], = LN >= min_contig) and it is mapped,
+ * not duplicate, primary, mapq >= min_q, paired with a mapped mate, and |tlen| > max_ins or the mate lies on
+ * another contig.  The indices of the selected reads are returned in stream order (wavefront compaction). */
+int tdt_signal_select(tdt_ctx *ctx, const uint16_t *flag, const uint8_t *mapq, const int32_t *tid, const int32_t *mate_tid,
+                      const int32_t *tlen, size_t n, const uint8_t *contig_ok, int n_contigs, int min_q, int64_t max_ins,
+                      uint32_t *out_idx, size_t *out_count);
+int tdt_signal_select_device(tdt_ctx *ctx, const uint16_t *d_flag, const uint8_t *d_mapq, const int32_t *d_tid,
+                             const int32_t *d_mate_tid, const int32_t *d_tlen, size_t n, const uint8_t *d_contig_ok, int n_contigs,
+                             int min_q, int64_t max_ins, uint32_t *d_out_idx, uint64_t *d_count);
+
 /* ---- alignment-record decode (host) ---------------------------------------------------------- *
  * Replaces the per-read pysam attribute access that feeds the path (read.reference_start,
  * reference_end, mapq, flag, next_reference_id, next_reference_start, isize, cigartuples[0]/[-1],

@@ -459,3 +459,28 @@ def test_coverage_multi_contig_single_launch(cov, ctx):
         assert np.array_equal(res[o:o + nb], want[name]), name
         assert np.array_equal(h.finish(name), want[name]), name
     h.close()
+
+
+# ------------------------------------------------------------------------------- signal select
+def test_signal_select_vs_numpy(ctx, nat):
+    rng = np.random.default_rng(31)
+    for n in (0, 1, 63, 64, 4097, 300_000, 9_000_000):
+        n_contigs = 6
+        ok = np.array([1, 1, 0, 1, 0, 1], dtype=np.uint8)
+        flag = rng.choice(np.array([0x63, 0x93, 0x1, 0x0, 0x403, 0x903, 0x103, 0x9, 0x5, 0x3], dtype=np.uint16), n)
+        mapq = rng.integers(0, 61, n).astype(np.uint8)
+        tid = rng.integers(-1, n_contigs, n).astype(np.int32)
+        mate = np.where(rng.random(n) < 0.9, tid, rng.integers(-1, n_contigs, n)).astype(np.int32)
+        tlen = rng.integers(-3000, 3000, n).astype(np.int32)
+        min_q, max_ins = 20, 1000
+        f = flag.astype(np.int64)
+        okc = np.zeros(n, dtype=bool)
+        okc[tid >= 0] = ok[tid[tid >= 0]] != 0
+        want = np.flatnonzero(okc & ((f & 0x404) == 0) & ((f & 0x900) == 0) & (mapq >= min_q) & ((f & 0x8) == 0) & ((f & 0x1) != 0)
+                              & (mate >= 0) & ((np.abs(tlen.astype(np.int64)) > max_ins) | (mate != tid)))
+        out = np.empty(max(n, 1), dtype=np.uint32)
+        cnt = ctypes.c_size_t(0)
+        nat.check(ctx.lib.tdt_signal_select(ctx.handle, nat.ptr(flag), nat.ptr(mapq), nat.ptr(tid), nat.ptr(mate), nat.ptr(tlen), n,
+                                            nat.ptr(ok), n_contigs, min_q, max_ins, nat.ptr(out), ctypes.byref(cnt)))
+        assert cnt.value == len(want), n
+        assert np.array_equal(out[:cnt.value], want), n

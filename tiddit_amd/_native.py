@@ -55,6 +55,8 @@ SYMBOLS = {
     "tdt_dbscan": (_i, [_P, _P, _sz, _sz, _dbl, _i, _i, _P, ctypes.POINTER(_i64)]),
     "tdt_dbscan_device": (_i, [_P, _P, _P, _sz, _P, _i, ctypes.c_uint64, _i, _i, _P, _P]),
     "tdt_sort_dbscan": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P]),
+    "tdt_signal_select": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, ctypes.POINTER(_sz)]),
+    "tdt_signal_select_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, _P]),
     "tdt_bam_decode": (_i, [_P, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)] + [_P] * 13),
 }
 

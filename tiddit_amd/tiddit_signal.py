@@ -18,7 +18,9 @@ import time
 
 import numpy
 
-from . import tiddit_coverage
+import ctypes
+
+from . import _native, tiddit_coverage
 from .bamio import BamReader
 
 _SA_OPS = {"M": 0, "S": 4, "H": 5, "D": 2, "I": 1}   # :23 — any other CIGAR letter raises KeyError, like the reference
@@ -115,6 +117,19 @@ class _ReadProxy:
         return self._rec.get_tag_sa()
 
 
+def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
+    """indices (ascending) of the reads of a decoded batch that are discordant-pair signals"""
+    ctx = ctx or _native.default_context()
+    n = len(batch)
+    out = numpy.empty(n, dtype=numpy.uint32)
+    cnt = ctypes.c_size_t(0)
+    ok = numpy.ascontiguousarray(contig_ok, dtype=numpy.uint8)
+    _native.check(ctx.lib.tdt_signal_select(ctx.handle, _native.ptr(batch.flag), _native.ptr(batch.mapq), _native.ptr(batch.tid),
+                                            _native.ptr(batch.mate_tid), _native.ptr(batch.tlen), n, _native.ptr(ok), len(ok),
+                                            int(min_q), int(max_ins), _native.ptr(out), ctypes.byref(cnt)))
+    return out[:cnt.value]
+
+
 def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50):
     """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
     split rows, clip FASTA entries).  Rows are exactly what ``worker`` returns (:228)."""
@@ -157,9 +172,8 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             split = SA_analysis(_ReadProxy(b, i), min_q, "SA", chrom)
             if split:
                 splits[chrom].append(split)
-        # discordant pairs (:204-221)
-        disc = primary & ((flag & 0x8) == 0) & ((flag & 0x1) != 0) & (b.mate_tid >= 0) & ((abs_isize > max_ins) | ~same_chr)
-        for i in numpy.flatnonzero(disc):
+        # discordant pairs (:204-221): predicate + order-preserving compaction on the device
+        for i in select_discordant(b, big, min_q, max_ins):
             chrom, mate = names[tid[i]], names[b.mate_tid[i]]
             chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
             data[chrom].append([chrA, chrB, b.record(i).query_name, int(b.pos[i]) + 1, int(b.end[i]) + 1, bool(flag[i] & 0x10), chrom])
