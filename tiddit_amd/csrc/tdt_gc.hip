@@ -18,23 +18,21 @@
 __device__ __forceinline__ unsigned gc_zero_bytes(unsigned x) {
     return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
 }
-// gather the four 0x80 flags of a word into 4 bits (bit i = byte i)
-__device__ __forceinline__ unsigned gc_nibble(unsigned flags) { return (flags * 0x00204081u) >> 28; }
-
-__device__ __forceinline__ void gc_classify_word(unsigned w, unsigned &gc4, unsigned &n4) {
-    const unsigned u = w | 0x20202020u;  // fold case: only 'C'/'c' map to 0x63, 'G'/'g' to 0x67, 'N'/'n' to 0x6e
-    gc4 = gc_nibble(gc_zero_bytes(u ^ 0x63636363u) | gc_zero_bytes(u ^ 0x67676767u));
-    n4 = gc_nibble(gc_zero_bytes(u ^ 0x6e6e6e6eu));
+// Per 4-byte word: fold case (only 'C'/'c' -> 0x63, 'G'/'g' -> 0x67, 'N'/'n' -> 0x6e); 'c' and 'g' differ in
+// bit 2 only, so ONE zero-byte test of ((u & ~0x04) ^ 'c') finds both; the GC flags (bits 7,15,23,31) and the
+// N flags shifted to bits 3,11,19,27 are gathered by ONE multiply: the partial products of the two sets land on
+// disjoint bits, GC nibble in bits 28..31, N nibble in bits 24..27.  Returns (gc4 << 4) | n4, bit i = byte i.
+__device__ __forceinline__ unsigned gc_classify_word(unsigned w) {
+    const unsigned u = w | 0x20202020u;
+    const unsigned gcf = gc_zero_bytes((u & 0xfbfbfbfbu) ^ 0x63636363u);
+    const unsigned nf = gc_zero_bytes(u ^ 0x6e6e6e6eu);
+    return ((gcf | (nf >> 4)) * 0x00204081u) >> 24;
 }
 
 __device__ __forceinline__ void gc_classify16(const uint4 v, unsigned &gc16, unsigned &n16) {
-    unsigned g0, g1, g2, g3, n0, n1, n2, n3;
-    gc_classify_word(v.x, g0, n0);
-    gc_classify_word(v.y, g1, n1);
-    gc_classify_word(v.z, g2, n2);
-    gc_classify_word(v.w, g3, n3);
-    gc16 = g0 | (g1 << 4) | (g2 << 8) | (g3 << 12);
-    n16 = n0 | (n1 << 4) | (n2 << 8) | (n3 << 12);
+    const unsigned r0 = gc_classify_word(v.x), r1 = gc_classify_word(v.y), r2 = gc_classify_word(v.z), r3 = gc_classify_word(v.w);
+    gc16 = (r0 >> 4) | (r1 & 0xf0u) | ((r2 & 0xf0u) << 4) | ((r3 & 0xf0u) << 8);
+    n16 = (r0 & 0xfu) | ((r1 & 0xfu) << 4) | ((r2 & 0xfu) << 8) | ((r3 & 0xfu) << 12);
 }
 
 // 16 bytes at byte offset g (16-aligned); bytes at or beyond len read as 0
@@ -71,11 +69,24 @@ __global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__res
 
     for (long long tile = blockIdx.x; tile * tile_bins < nbins; tile += gridDim.x) {
         const long long T0 = tile * (long long)tile_bytes;
-        for (int c = tid; c < chunks; c += GC_THREADS) {
-            unsigned gm, nm;
-            gc_classify16(gc_load16(seq, T0 + 16ll * c, len), gm, nm);
-            g16[c] = (unsigned short)gm;
-            n16[c] = (unsigned short)nm;
+        // phase 1, four chunks per lane per trip: the four 16-byte loads are issued back to back
+        for (int c0 = 0; c0 < chunks; c0 += 4 * GC_THREADS) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = c0 + k * GC_THREADS + tid;
+                if (c < chunks) v[k] = gc_load16(seq, T0 + 16ll * c, len);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = c0 + k * GC_THREADS + tid;
+                if (c < chunks) {
+                    unsigned gm, nm;
+                    gc_classify16(v[k], gm, nm);
+                    g16[c] = (unsigned short)gm;
+                    n16[c] = (unsigned short)nm;
+                }
+            }
         }
         if (tid == 0 && (chunks & 1)) {  // zero the unused upper half of the last word
             g16[chunks] = 0;
@@ -170,9 +181,11 @@ extern "C" int tdt_gc_bins_device(tdt_ctx *ctx, const uint8_t *d_seq, int64_t le
     const long long nbins = (len + bin_size - 1) / bin_size;
     const unsigned long long n_min = gc_n_min(bin_size, n_cutoff);
     if (bin_size <= GC_SMALL_MAX) {
-        int m = 1024 / bin_size;
-        if (m < 1) m = 1;
-        const int tile_bins = 16 * m;
+        // whole multiples of 256 bins per tile (every lane owns the same number of bins), ~64 KB of sequence,
+        // tile bytes a multiple of 16 so every tile starts on a 16-byte boundary
+        int tile_bins = 65536 / bin_size;
+        tile_bins = tile_bins >= GC_THREADS ? tile_bins / GC_THREADS * GC_THREADS : (tile_bins & ~15);
+        if (tile_bins < 16) tile_bins = 16;
         const long long tiles = (nbins + tile_bins - 1) / tile_bins;
         const int chunks = (tile_bins * bin_size) >> 4;
         const size_t lds = (size_t)((chunks + 1) / 2) * 2 * sizeof(unsigned);
