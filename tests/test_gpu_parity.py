@@ -484,3 +484,32 @@ def test_signal_select_vs_numpy(ctx, nat):
                                             nat.ptr(ok), n_contigs, min_q, max_ins, nat.ptr(out), ctypes.byref(cnt)))
         assert cnt.value == len(want), n
         assert np.array_equal(out[:cnt.value], want), n
+
+
+def test_cluster_buckets_sharded_single_rank_group(ctx):
+    """the multi-GPU entry point with a 1-rank RCCL group: same labels as the local path"""
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    from tiddit_amd import tiddit_cluster
+    rng = np.random.default_rng(8)
+    buckets = []
+    for s in (0, 50, 3000, 7, 800):
+        x = rng.integers(0, max(10, s * 30), s)
+        buckets.append(np.stack([x, x + rng.integers(0, 900, s), np.arange(s)], 1).astype(np.int64).reshape(s, 3))
+    want = tiddit_cluster.cluster_buckets(buckets, 300, 3)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        got = tiddit_cluster.cluster_buckets_sharded(buckets, 300, 3)
+    finally:
+        dist.destroy_process_group()
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    for b, w in zip(buckets, want):
+        if len(b):
+            d = b[np.argsort(b[:, 0], kind="stable")]
+            lab = oracle.dbscan_main(d, 300, 3)
+            back = np.empty(len(b))
+            back[np.argsort(b[:, 0], kind="stable")] = lab
+            assert np.array_equal(w, back)

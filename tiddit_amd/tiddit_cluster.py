@@ -108,8 +108,11 @@ def cluster_buckets(buckets, epsilon, m, ctx=None):
     numpy.cumsum(sizes, out=off[1:])
     if n == 0:
         return [numpy.zeros(0) for _ in buckets]
-    posA = numpy.ascontiguousarray(numpy.concatenate([numpy.asarray(b, dtype=numpy.int64).reshape(len(b), -1)[:, 0] for b in buckets]))
-    posB = numpy.ascontiguousarray(numpy.concatenate([numpy.asarray(b, dtype=numpy.int64).reshape(len(b), -1)[:, 1] for b in buckets]))
+    def column(b, c):
+        a = numpy.asarray(b, dtype=numpy.int64)
+        return a[:, c] if len(a) else numpy.zeros(0, dtype=numpy.int64)
+    posA = numpy.ascontiguousarray(numpy.concatenate([column(b, 0) for b in buckets]))
+    posB = numpy.ascontiguousarray(numpy.concatenate([column(b, 1) for b in buckets]))
     perm = numpy.empty(n, dtype=numpy.uint32)
     lab = numpy.empty(n, dtype=numpy.float64)
     _native.check(ctx.lib.tdt_sort_dbscan(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets),
@@ -117,6 +120,26 @@ def cluster_buckets(buckets, epsilon, m, ctx=None):
     by_signal = numpy.empty(n, dtype=numpy.float64)
     by_signal[perm] = lab
     return [by_signal[off[b]:off[b + 1]] for b in range(len(buckets))]
+
+
+def cluster_buckets_sharded(buckets, epsilon, m, group=None, device=None):
+    """Multi-GPU form of :func:`cluster_buckets` (one process per GPU, torch.distributed initialised, backend
+    nccl = RCCL): buckets are bin-packed onto ranks by signal count, every rank clusters only its own buckets
+    on its GPU, and ONE variable-count all-gather of the label arrays gives every rank the full result
+    (SURVEY.md §8(e)).  Returns the same list of per-bucket label arrays on every rank."""
+    import torch
+    import torch.distributed as dist
+    from .dist import cluster_buckets_distributed
+    sizes = [len(b) for b in buckets]
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+    def cluster_local(ids):
+        labs = cluster_buckets([buckets[i] for i in ids], epsilon, m)
+        flat = numpy.concatenate(labs) if labs else numpy.zeros(0)
+        return torch.from_numpy(numpy.ascontiguousarray(flat, dtype=numpy.float64)).to(device)
+
+    return [t.cpu().numpy() for t in cluster_buckets_distributed(sizes, cluster_local, group)]
 
 
 def _mode(values):
@@ -145,7 +168,13 @@ def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins
     signals, positions = _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly)
 
     order = [(a, b) for a in chromosomes if a in positions for b in chromosomes if b in positions[a]]
-    labels = cluster_buckets([numpy.array(positions[a][b], dtype=numpy.int64) for a, b in order], epsilon, m)
+    bucket_arrays = [numpy.array(positions[a][b], dtype=numpy.int64) for a, b in order]
+    try:
+        import torch.distributed as _dist
+        sharded = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+    except ImportError:
+        sharded = False
+    labels = cluster_buckets_sharded(bucket_arrays, epsilon, m) if sharded else cluster_buckets(bucket_arrays, epsilon, m)
 
     candidates = {}
     for chrA in chromosomes:           # candidates[chrA] exists for every chrA that has signals (:141-145)
