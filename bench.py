@@ -199,7 +199,7 @@ def main():
         y = torch.from_numpy(pts[:, 1].astype(np.uint32).view(np.int32)).to(dev)
         lab = torch.empty(n, dtype=torch.float64, device=dev)
         lid = torch.empty(1, dtype=torch.int64, device=dev)
-        gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if use_dist else None
+        gathered = torch.empty(n * world, dtype=torch.int32, device=dev) if use_dist else None   # labels travel as int32 (exact)
         off = np.array([0, n], dtype=np.int64)
         torch.cuda.synchronize()
         dev_ms = []
@@ -215,7 +215,7 @@ def main():
                     b.record(stream)
                     dev_ms.append((a, b))
                 if use_dist:  # the exchange step: every rank ends up with the whole cluster set
-                    dist.all_gather_into_tensor(gathered, lab)
+                    dist.all_gather_into_tensor(gathered, lab.to(torch.int32))
 
         for _ in range(args.warmup):
             db_step(False)
@@ -238,7 +238,7 @@ def main():
         dbres = {"metric": "signals clustered/sec", "value": n * world / (t_db / args.steps), "unit": "signals/s",
                  "ms_per_step": 1e3 * t_db / args.steps,
                  "config": {"workload": "BASELINE configs[2]: gen_points(%d) one chr pair, e=500 l=3, per GPU%s"
-                                        % (n, "; labels all-gathered over RCCL" if world > 1 else "")},
+                                        % (n, "; int32 labels all-gathered over RCCL" if world > 1 else "")},
                  "roofline": {"bound": "hbm", "kernel": "tdt_dbscan_device (16 launches)", "achieved": db_ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": db_ach / HBM_PEAK_GBS, "traffic": None, "avg_pass_ms": k_ms,
                               "algorithmic_bytes_per_pass": 16.0 * n}}

@@ -46,8 +46,11 @@ def allgatherv(t, group=None):
     return [out[r * mx:r * mx + counts[r]] for r in range(world)]
 
 
-def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None):
+def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None, wire_dtype="int32"):
     """Cluster every bucket on its owner rank, then all-gather the labels.
+
+    Labels are integers (-1 or a cluster id < 2^31) carried in float64 like the reference returns them; on
+    the wire they travel as int32 (half the xGMI bytes, exact) unless wire_dtype is None.
 
     bucket_sizes : number of signals of every bucket (identical on all ranks)
     cluster_local(bucket_ids) -> 1-D float64 tensor with the labels of those buckets, concatenated
@@ -58,8 +61,12 @@ def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     owned = shard_buckets(bucket_sizes, world)
+    import torch
     mine = cluster_local(owned[rank])
-    parts = allgatherv(mine, group)
+    out_dtype = mine.dtype
+    if wire_dtype is not None:
+        mine = mine.to(getattr(torch, wire_dtype))
+    parts = [p.to(out_dtype) for p in allgatherv(mine, group)]
     labels = [None] * len(bucket_sizes)
     for r in range(world):
         off = 0
