@@ -513,3 +513,15 @@ def test_cluster_buckets_sharded_single_rank_group(ctx):
             back = np.empty(len(b))
             back[np.argsort(b[:, 0], kind="stable")] = lab
             assert np.array_equal(w, back)
+
+
+def test_coverage_host_push_many_chunks(cov):
+    """> 2 staging chunks of 4 M reads: exercises the pinned double-buffer ring and its event hand-over"""
+    LN = 60_000_000
+    start, end, mapq, flag = synth.gen_reads(LN, 25, seed=123)       # 10 M reads
+    want, kept = oracle.coverage_stream(start, end, mapq, flag, LN, 50, 5)
+    h = cov.CoverageHistogram([("c", LN)], 50)
+    h.push("c", start, end, mapq, flag, 5)
+    got = h.finish("c")
+    assert h.kept() == kept and np.array_equal(got, want)
+    h.close()
