@@ -139,11 +139,12 @@ def main():
         "unit": "bins/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int64 (2^-S fixed point of the reference's float32 quotients; float64 out)",
+        "dtype": "int64",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: coverage histogram, %d contigs x %d bp (%.2f Gb), %dx 150-bp sorted "
                                "stream, %d-bp bins, q>=%d filter, per GPU" % (C, L, C * L / 1e9, args.depth, z, args.min_q),
-                   "reads_per_gpu": total_reads, "bins_per_gpu": total_bins, "launches_per_step": 3},
+                   "reads_per_gpu": total_reads, "bins_per_gpu": total_bins, "launches_per_step": 3,
+                   "arithmetic": "int64 accumulation of the reference's float32 quotients at 2^-S fixed point (exact), float64 bins out"},
         "reads_per_sec": total_reads * world / (t_cov / args.steps),
         "roofline": {"bound": "hbm", "kernel": "cov_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kern_ms,
