@@ -12,9 +12,11 @@
 #pragma once
 
 #define DBF_M_MAX 64
+#ifndef DBF_THREADS
 #define DBF_THREADS 256
+#endif
 #define DBF_WAVES (DBF_THREADS / 64)
-#define DBF_STEPS 16                       // 64-element words per wave
+#define DBF_STEPS (64 / DBF_WAVES)          // 64-element words per wave
 #define DBF_WORDS (DBF_WAVES * DBF_STEPS)   // 64 words per tile
 #define DBF_TILE (DBF_WORDS * 64)           // 4096 points
 #define DBF_SPIN_LIMIT (1u << 24)
