@@ -206,9 +206,14 @@ __global__ __launch_bounds__(DB_THREADS) void dby_rank(const int *__restrict__ x
         const unsigned yk = y[k];
         if (s1 - s0 <= DB_SMALL) {
             int rank = 0;
-            for (int j = s0; j < s1; j++) {
-                const unsigned yj = y[j];
-                rank += (yj < yk) || (yj == yk && j < k);
+            // rank = members sorting before k.  The wave runs as long as its largest cluster, so the cost is loop
+            // overhead x trip count: 4 members per trip (clamped loads, no per-member branch)
+            for (int j = s0; j < s1; j += 4) {
+                const unsigned v0 = y[j], v1 = y[min(j + 1, s1 - 1)], v2 = y[min(j + 2, s1 - 1)], v3 = y[min(j + 3, s1 - 1)];
+                rank += (v0 < yk) || (v0 == yk && j < k);
+                rank += (j + 1 < s1) && ((v1 < yk) || (v1 == yk && j + 1 < k));
+                rank += (j + 2 < s1) && ((v2 < yk) || (v2 == yk && j + 2 < k));
+                rank += (j + 3 < s1) && ((v3 < yk) || (v3 == yk && j + 3 < k));
             }
             ys[s0 + rank] = yk;
             ord[s0 + rank] = k;
@@ -467,7 +472,10 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         TDT_HIP(hipMemsetAsync(PM, 0, 8, st));   // the word before the array
         TDT_HIP(hipMemsetAsync(PM + (size_t)ntf * DBF_WORDS + 1, 0, 8, st));   // ... and the one after the last tile
         TDT_HIP(hipMemsetAsync(PY, 0, 8, st));
-        hipLaunchKernelGGL(dbm_x_masks, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x);
+        if (nb == 1 && m <= 4)
+            hipLaunchKernelGGL(dbm_x_masks<true>, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x);
+        else
+            hipLaunchKernelGGL(dbm_x_masks<false>, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x);
         if (ntf > DBM_INLINE_PREFIX_MAX) hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, agg_x, ntf);
         hipLaunchKernelGGL(dbm_x_labels, dim3(ntf), dim3(DBF_THREADS), 0, st, (const ull *)PM, (const ull *)agg_x, n, (const int *)d_boff, nb,
                            m, d_xlab, d_runbase, d_seg0, d_seg1);
@@ -717,8 +725,3 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     return TDT_OK;
 }
 
-#ifdef DBF_DEBUG_SPINS
-extern "C" int tdt_debug_ts(unsigned long long *out, size_t bytes) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_ts), bytes) == hipSuccess ? 0 : -2;
-}
-#endif

@@ -1,14 +1,13 @@
-// Fused single-pass ("chained scan", decoupled look-back) kernels of the clustering path.
-// Included by tdt_dbscan.hip.  Used when m <= DBF_M_MAX; the multi-kernel path stays as the general one.
+// Ballot-mask kernels of the clustering path.  Included by tdt_dbscan.hip.  Used when m <= DBF_M_MAX; the
+// multi-kernel byte-flag path in tdt_dbscan.hip stays as the general one.
 //
-// Every kernel walks tiles of 4096 points (tile index = an atomic ticket, so a tile's predecessors have
-// always started).  All per-point predicates are booleans, so the tile-local scans are done on 64-bit
-// ballot masks: lane = point, one coalesced load per array per 64 points, prefix counts are
-// popcounts of masked ballots, run heads/tails are shifts of those masks — no per-thread item arrays,
-// no shuffles, no LDS bank conflicts.  A tile publishes its aggregate, looks back over the predecessors'
-// 8-byte status words until it meets an inclusive prefix (or a reset) and then finishes its own points.  A status word carries flag + payload in ONE naturally aligned 8-byte store/load
-// (relaxed, agent scope: the load bypasses the per-CU L1), so no fences are needed; spins are bounded
-// and report through an error word instead of hanging.
+// Every kernel walks tiles of 4096 points = 64 mask words (tile = workgroup index).  All per-point predicates are
+// booleans, so the tile-local scans are done on 64-bit ballot masks: lane = point when predicates are
+// evaluated (one coalesced load per array per 64 points), lane = word when the bit algebra is done; prefix
+// counts are popcounts of masked ballots, run heads/tails are shifts of those masks — no per-thread item arrays,
+// no LDS bank conflicts.  Cross-tile prefixes come from the per-tile aggregates of the previous launch.
+// (An in-kernel chained scan with decoupled look-back over 8-byte status words was tried first and measured no
+// faster than this launch-boundary form)
 #pragma once
 
 #define DBF_M_MAX 64
@@ -19,132 +18,8 @@
 #define DBF_STEPS (64 / DBF_WAVES)          // 64-element words per wave
 #define DBF_WORDS (DBF_WAVES * DBF_STEPS)   // 64 words per tile
 #define DBF_TILE (DBF_WORDS * 64)           // 4096 points
-#define DBF_SPIN_LIMIT (1u << 24)
-
-#define CS_AGG 1ull
-#define CS_PREFIX 2ull
 
 typedef unsigned long long ull;
-#ifdef DBF_DEBUG_SPINS
-__device__ unsigned long long dbg_ts[2][8192][4];
-#define DBG_TS(k, tile, slot) do { if ((threadIdx.x & 63) == 0 && (tile) < 8192) dbg_ts[k][tile][slot] = wall_clock64(); } while (0)
-#else
-#define DBG_TS(k, tile, slot)
-#endif
-
-__device__ __forceinline__ ull cs_pack(ull flag, unsigned has, ull val) { return (flag << 62) | ((ull)(has & 1u) << 61) | (val & ((1ull << 61) - 1)); }
-__device__ __forceinline__ void cs_store(ull *p, ull w) { __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ ull cs_load(ull *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Segmented-sum monoid: state = (has_reset, value since the last reset).  combine(a then b) = b.has ? b : (a.has, a.val + b.val)
-//
-// Called by the 64 lanes of wave 0.  Publishes this tile's aggregate, looks back, publishes the inclusive
-// prefix and returns the exclusive prefix (state after all earlier tiles).
-__device__ __forceinline__ void cs_lookback(ull *status, int tile, unsigned agg_has, ull agg_val, unsigned &pre_has, ull &pre_val,
-                                            int *err) {
-    const int lane = threadIdx.x & 63;
-    pre_has = 0;
-    pre_val = 0;
-#ifdef DBF_DEBUG_SPINS
-    unsigned dbg_spins = 0, dbg_hops = 0;
-    unsigned *dbg = (unsigned *)err + 4;
-#endif
-#ifdef DBF_EXP_NOLOOKBACK
-    return;
-#endif
-    if (tile > 0) {
-        if (lane == 0) cs_store(&status[tile], cs_pack(CS_AGG, agg_has, agg_val));
-        int base = tile - 1;
-        unsigned spins = 0;
-#ifdef DBF_DEBUG_SPINS
-        dbg_spins = 0; dbg_hops = 0;
-#endif
-        // 256 predecessors per hop (4 status words per lane, nearest first): the prefix front has to cross
-        // all tiles in flight, so the number of ~1 us hops is what bounds the pass
-        while (true) {
-            ull w[4];
-            bool inv[4], trm[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int idx = base - (lane * 4 + r);
-                w[r] = idx >= 0 ? cs_load(&status[idx]) : cs_pack(CS_PREFIX, 0, 0);  // before tile 0: identity prefix
-                inv[r] = (w[r] >> 62) == 0;
-                trm[r] = (w[r] >> 62) == CS_PREFIX || ((w[r] >> 61) & 1ull);
-            }
-            // per lane: walk its 4 words nearest-first up to its first terminator
-            ull lv = 0;
-            bool linv = false, lterm = false;
-            unsigned lhas = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                if (!lterm) {
-                    linv = linv || inv[r];
-                    lv += w[r] & ((1ull << 61) - 1);
-                    if (trm[r]) {
-                        lterm = true;
-                        lhas = (unsigned)((w[r] >> 61) & 1ull);
-                    }
-                }
-            }
-            const unsigned long long invalid = __ballot(linv);
-            const unsigned long long term = __ballot(lterm);
-            const int L = term ? __ffsll((long long)term) - 1 : 64;   // first lane holding a terminator
-            const unsigned long long need = L >= 63 ? ~0ull : ((2ull << L) - 1ull);
-            if (invalid & need) {
-                // a nearer tile has not published yet.  Do NOT re-read the whole window in a loop (a thousand
-                // waves doing that saturate the few L2 channels holding the status array and delay the very
-                // stores they wait for): one lane polls the single nearest missing word, with a sleep.
-                const int F = __ffsll((long long)(invalid & need)) - 1;     // nearest lane with a missing word
-                int r0 = 0;
-                if (lane == F) {
-#pragma unroll
-                    for (int r = 3; r >= 0; r--)
-                        if (inv[r]) r0 = r;
-                    ull *wp = &status[base - (lane * 4 + r0)];
-                    while ((cs_load(wp) >> 62) == 0) {
-#ifdef DBF_DEBUG_SPINS
-                        dbg_spins++;
-#endif
-                        if (++spins > DBF_SPIN_LIMIT) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                }
-                spins = __shfl(spins, F);
-                if (spins > DBF_SPIN_LIMIT) {
-                    if (lane == 0) atomicOr(err, 1);
-                    break;
-                }
-                continue;
-            }
-#ifdef DBF_DEBUG_SPINS
-            dbg_hops++;
-#endif
-            ull v = (lane <= L) ? lv : 0ull;
-            for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-            pre_val += v;
-            if (term) {
-                pre_has = __shfl(lhas, L);
-                break;
-            }
-            base -= 256;
-        }
-    }
-#ifdef DBF_DEBUG_SPINS
-    if (lane == 0 && tile > 0) {
-        dbg_spins = 0;
-        for (int l = 0; l < 64; l++) dbg_spins += 0;
-        atomicAdd(&dbg[0], dbg_spins);
-        atomicMax(&dbg[1], dbg_spins);
-        atomicAdd(&dbg[2], dbg_hops);
-        atomicAdd(&dbg[3], 1u);
-    }
-#endif
-    if (lane == 0) {
-        const unsigned ih = agg_has | pre_has;
-        const ull iv = agg_has ? agg_val : pre_val + agg_val;
-        cs_store(&status[tile], cs_pack(CS_PREFIX, ih, iv));
-    }
-}
 
 struct DbfCtl {  // zeroed before every call
     unsigned ticket[4];
@@ -174,7 +49,9 @@ __device__ __forceinline__ unsigned dbf_cnt_le(ull mask, int lane) {
 // ------------------------------------------------------------------------------------------ x pass
 #define DBF_XSH (DBF_TILE + 128 + DBF_M_MAX)   // x staged for [t0-64, t0+TILE+64+m)
 
-// p word: bit = p[g0 + lane]  (DBSCAN.py:41-51), 0 for points outside [0, n); x comes from the LDS stage
+// p word: bit = p[g0 + lane]  (DBSCAN.py:41-51), 0 for points outside [0, n); x comes from the LDS stage.
+// For m <= 4 (the reference's default is 3) the window is read with four independent LDS loads and masked,
+// instead of a data-dependent loop that waits for every read in turn.
 __device__ __forceinline__ ull dbf_px_word(const unsigned *xsh, int sh0, int n, const int *__restrict__ boff, int nb, ull eps, int m,
                                            int g0, int lane) {
     const int i = g0 + lane;
@@ -183,293 +60,23 @@ __device__ __forceinline__ ull dbf_px_word(const unsigned *xsh, int sh0, int n, 
         const int bend = nb == 1 ? n : boff[db_bucket(boff, nb, i) + 1];
         if (i + m <= bend) {                          // `for i in range(0, len(data)-m+1)` (:39)
             const int hi = min(i + m, bend - 1);      // data[i+1:i+m+1] truncates at the array end (:43)
-            const unsigned xi = xsh[i - sh0];
+            const int o = i - sh0;
+            const unsigned xi = xsh[o];
             unsigned maxd = 0;
-            for (int q = i + 1; q <= hi; q++) maxd = max(maxd, db_absdiff(xsh[q - sh0], xi));
+            if (m <= 4) {
+                const unsigned v1 = xsh[o + 1], v2 = xsh[o + 2], v3 = xsh[o + 3], v4 = xsh[o + 4];   // staged range covers o+4
+                const int cnt = hi - i;               // 1..4 window members
+                maxd = db_absdiff(v1, xi);
+                if (cnt >= 2) maxd = max(maxd, db_absdiff(v2, xi));
+                if (cnt >= 3) maxd = max(maxd, db_absdiff(v3, xi));
+                if (cnt >= 4) maxd = max(maxd, db_absdiff(v4, xi));
+            } else {
+                for (int q = i + 1; q <= hi; q++) maxd = max(maxd, db_absdiff(xsh[q - sh0], xi));
+            }
             p = (ull)maxd < eps;
         }
     }
     return __ballot(p);
-}
-
-__global__ __launch_bounds__(DBF_THREADS) void dbf_x(const unsigned *__restrict__ x, int n, const int *__restrict__ boff, int nb,
-                                                     ull eps, int m, ull *status, DbfCtl *ctl, int *err, int *__restrict__ xlab,
-                                                     unsigned *__restrict__ runbase, int *__restrict__ seg0, int *__restrict__ seg1) {
-    __shared__ unsigned xsh[DBF_XSH];
-    __shared__ ull pm[DBF_WORDS + 2];   // p masks: [0] = the word before the tile, [1..64], [65] = the word after
-    __shared__ unsigned wcnt[DBF_WAVES];
-    __shared__ int s_tile;
-    __shared__ ull s_pre;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = (int)atomicAdd(&ctl->ticket[0], 1u);
-    __syncthreads();
-    const int tile = s_tile;
-    const int t0 = tile * DBF_TILE;
-    if (t0 >= n) return;
-    if (tid == 0) DBG_TS(0, tile, 0);
-    // stage the tile (+ halos) with independent coalesced loads: one memory round trip instead of one per word
-    const int sh0 = t0 - 64;
-#pragma unroll
-    for (int k = 0; k < (DBF_XSH + DBF_THREADS - 1) / DBF_THREADS; k++) {
-        const int o = tid + k * DBF_THREADS;
-        const int g = sh0 + o;
-        if (o < DBF_XSH) xsh[o] = (g >= 0 && g < n) ? x[g] : 0u;
-    }
-    __syncthreads();
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int W = wave * DBF_STEPS + s;
-        const ull w = dbf_px_word(xsh, sh0, n, boff, nb, eps, m, t0 + W * 64, lane);
-        if (lane == 0) pm[1 + W] = w;
-    }
-    if (wave == 0) {
-        const ull w = dbf_px_word(xsh, sh0, n, boff, nb, eps, m, t0 - 64, lane);
-        if (lane == 0) pm[0] = w;
-    }
-    if (wave == DBF_WAVES - 1) {
-        const ull w = dbf_px_word(xsh, sh0, n, boff, nb, eps, m, t0 + DBF_TILE, lane);
-        if (lane == 0) pm[DBF_WORDS + 1] = w;
-    }
-    __syncthreads();
-    // run starts (the `cluster` boolean going False -> True, :52-62) of this wave's 1024 points
-    unsigned cnt = 0;
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int W = wave * DBF_STEPS + s;
-        const ull cur = pm[1 + W], prev = pm[W];
-        cnt += dbf_popc(cur & ~((cur << 1) | (prev >> 63)));
-    }
-    if (lane == 0) wcnt[wave] = cnt;
-    __syncthreads();
-    if (wave == 0) {
-        unsigned ph;
-        ull pv;
-        DBG_TS(0, tile, 1);
-        cs_lookback(status, tile, 0, (ull)wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3], ph, pv, err);
-        DBG_TS(0, tile, 2);
-        if (lane == 0) s_pre = pv;
-    }
-    __syncthreads();
-    unsigned base = (unsigned)s_pre;     // run starts before this wave's first point
-    for (int w = 0; w < wave; w++) base += wcnt[w];
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int W = wave * DBF_STEPS + s;
-        const int g0 = t0 + W * 64;
-        if (g0 >= n) break;
-        const int i = g0 + lane;
-        const ull cur = pm[1 + W], prev = pm[W], next = pm[2 + W];
-        const ull valid = n - g0 >= 64 ? ~0ull : dbf_lt(n - g0);
-        const ull st = cur & ~((cur << 1) | (prev >> 63));
-        const ull f = dbf_smear(cur, prev, m) & valid;     // label != -1: some p in [i-m+1, i]
-        const unsigned run = base + dbf_popc(st & dbf_le(lane));      // inclusive count of run starts at i
-        const bool found = (f >> lane) & 1ull;
-        if (i < n) xlab[i] = found ? (int)run - 1 : -1;
-        // neighbours: the point before the word and the point after it
-        const bool fprev = m >= 64 ? prev != 0 : (prev >> (64 - m)) != 0;                    // found(g0-1), g0 > 0
-        const bool nvalid = g0 + 64 < n;
-        const bool fnext = nvalid && ((next & 1ull) || (cur >> (65 - m)) != 0);              // found(g0+64)
-        const bool snext = (next & 1ull) && !(cur >> 63);                                    // start(g0+64)
-        const ull same_as_prev = ((f << 1) | (ull)(fprev && g0 > 0)) & ~st;      // point i-1 carries the same run id
-        const ull fn = (f >> 1) | ((ull)fnext << 63);
-        const ull sn = (st >> 1) | ((ull)snext << 63);
-        const ull headm = f & ~same_as_prev;
-        const ull tailm = f & ~(fn & ~sn);
-        if ((headm >> lane) & 1ull) seg0[run - 1] = i;
-        if ((tailm >> lane) & 1ull) seg1[run - 1] = i + 1;
-        // runs before every bucket (ids restart per bucket, tiddit_cluster.pyx:140-154)
-        if (nb == 1) {
-            if (i == n - 1) runbase[1] = run;
-        } else if (i < n) {
-            const int b = db_bucket(boff, nb, i);
-            if (i + 1 == boff[b + 1])
-                for (int bb = b + 1; bb <= nb && boff[bb] == i + 1; bb++) runbase[bb] = run;
-        }
-        base += dbf_popc(st);
-    }
-    if (wave == 0) DBG_TS(0, tile, 3);
-}
-
-// ------------------------------------------------------------------------------------------ y pass
-#define DBF_YSH (DBF_TILE + 65 + DBF_M_MAX)
-// window test on the sorted y (DBSCAN.py:90-99), sub-run starts (:101-110), relabel (:112-122), scatter.
-// Two chained scans in one kernel: (1) sub-run starts counted from the head of every x-cluster,
-// (2) "extra" sub-run starts (every start that is not the first of its cluster) counted from the start
-// of every bucket — the k-th extra start of a bucket owns the id (R-1)+k.
-__global__ __launch_bounds__(DBF_THREADS) void dbf_y(const int *__restrict__ xlab, const unsigned *__restrict__ ys,
-                                                     const unsigned *__restrict__ ord, int n, const int *__restrict__ boff, int nb,
-                                                     const unsigned *__restrict__ runbase, ull eps, int m, ull *status1, ull *status2,
-                                                     DbfCtl *ctl, int *err, double *__restrict__ labels, long long *__restrict__ last_id) {
-    __shared__ int lsh[DBF_YSH];        // xlab staged for [t0-65, t0+TILE+m)
-    __shared__ unsigned ysh[DBF_YSH];   // sorted y, same range
-    __shared__ ull pm[DBF_WORDS + 1];   // py masks, [0] = the word before the tile
-    __shared__ ull hm[DBF_WORDS];       // x-cluster heads (label differs from the previous point)
-    __shared__ ull bm[DBF_WORDS];       // bucket starts
-    __shared__ ull em[DBF_WORDS];       // extra sub-run starts
-    __shared__ ull s1m[DBF_WORDS];      // point belongs to sub-run 1 of its cluster
-    __shared__ ull fm[DBF_WORDS];       // point is labelled (some py in [i-m+1, i])
-    __shared__ unsigned whas[DBF_WAVES], wval[DBF_WAVES];
-    __shared__ int s_tile;
-    __shared__ ull s_pre;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_tile = (int)atomicAdd(&ctl->ticket[1], 1u);
-    __syncthreads();
-    const int tile = s_tile;
-    const int t0 = tile * DBF_TILE;
-    if (t0 >= n) return;
-
-    // stage labels and sorted y of the tile (+ halos) with independent coalesced loads
-    const int sh0 = t0 - 65;            // labels are needed from t0-64-1 (head test of the halo word)
-#pragma unroll
-    for (int k = 0; k < (DBF_YSH + DBF_THREADS - 1) / DBF_THREADS; k++) {
-        const int o = tid + k * DBF_THREADS;
-        const int g = sh0 + o;
-        if (o < DBF_YSH) {
-            const bool in = g >= 0 && g < n;
-            lsh[o] = in ? xlab[g] : -2;     // -2: outside the array (never equals a label)
-            ysh[o] = in ? ys[g] : 0u;
-        }
-    }
-    __syncthreads();
-    auto py_word = [&](int g0) -> ull {
-        const int i = g0 + lane;
-        bool p = false;
-        if (i >= 0 && i + m - 1 < n) {
-            const int l = lsh[i - sh0];
-            // next = y[i+1:i+m] must lie inside the same x-cluster (clusters are contiguous); sorted => max is the last
-            if (l >= 0 && lsh[i + m - 1 - sh0] == l) p = (ull)(ysh[i + m - 1 - sh0] - ysh[i - sh0]) < eps;
-        }
-        return __ballot(p);
-    };
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int W = wave * DBF_STEPS + s;
-        const int g0 = t0 + W * 64;
-        const int i = g0 + lane;
-        const ull w = py_word(g0);
-        bool head = false, bstart = false;
-        if (i < n) {
-            head = i == 0 || lsh[i - 1 - sh0] != lsh[i - sh0];
-            bstart = nb == 1 ? i == 0 : i == boff[db_bucket(boff, nb, i)];
-        }
-        const ull h = __ballot(head), b = __ballot(bstart);
-        if (lane == 0) {
-            pm[1 + W] = w;
-            hm[W] = h;
-            bm[W] = b;
-        }
-    }
-    if (wave == 0) {
-        const ull w = py_word(t0 - 64);
-        if (lane == 0) pm[0] = w;
-    }
-    __syncthreads();
-    // ---- scan 1: sub-run starts since the head of the x-cluster
-    unsigned has = 0, val = 0;
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int W = wave * DBF_STEPS + s;
-        const ull cur = pm[1 + W], prev = pm[W], h = hm[W];
-        const ull st = cur & (h | ~((cur << 1) | (prev >> 63)));   // sy = py && (head || !py[i-1])
-        if (h) {
-            has = 1;
-            val = dbf_popc(st & (~0ull << (63 - __clzll((long long)h))));
-        } else {
-            val += dbf_popc(st);
-        }
-    }
-    if (lane == 0) {
-        whas[wave] = has;
-        wval[wave] = val;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        unsigned th = 0;
-        ull tv = 0;
-        for (int w = 0; w < DBF_WAVES; w++) {
-            if (whas[w]) { th = 1; tv = wval[w]; } else tv += wval[w];
-        }
-        unsigned ph;
-        ull pv;
-        cs_lookback(status1, tile, th, tv, ph, pv, err);
-        if (lane == 0) s_pre = pv;
-    }
-    __syncthreads();
-    unsigned cin = (unsigned)s_pre;   // starts of the open x-cluster before this wave's first point
-    for (int w = 0; w < wave; w++) cin = whas[w] ? wval[w] : cin + wval[w];
-    __syncthreads();                  // whas/wval are reused by scan 2
-    unsigned has2 = 0, val2 = 0;
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int W = wave * DBF_STEPS + s;
-        const int g0 = t0 + W * 64;
-        const ull cur = pm[1 + W], prev = pm[W], h = hm[W], b = bm[W];
-        const ull st = cur & (h | ~((cur << 1) | (prev >> 63)));
-        const ull valid = g0 >= n ? 0ull : (n - g0 >= 64 ? ~0ull : dbf_lt(n - g0));
-        // count of starts of my cluster at positions <= lane
-        const ull hle = h & dbf_le(lane);
-        const unsigned ss = hle ? (unsigned)dbf_popc(st & dbf_le(lane) & (~0ull << (63 - __clzll((long long)hle))))
-                                : cin + (unsigned)dbf_popc(st & dbf_le(lane));
-        const bool is_st = (st >> lane) & 1ull;
-        const ull f = dbf_smear(cur, prev, m) & valid;
-        const bool found = (f >> lane) & 1ull;
-        const ull e = __ballot(is_st && ss >= 2);
-        const ull s1 = __ballot(found && ss == 1);
-        if (lane == 0) {
-            em[W] = e;
-            s1m[W] = s1;
-            fm[W] = f;
-        }
-        cin = h ? (unsigned)dbf_popc(st & (~0ull << (63 - __clzll((long long)h)))) : cin + (unsigned)dbf_popc(st);
-        // ---- scan 2 summary: extra starts since the start of the bucket
-        if (b) {
-            has2 = 1;
-            val2 = dbf_popc(e & (~0ull << (63 - __clzll((long long)b))));
-        } else {
-            val2 += dbf_popc(e);
-        }
-    }
-    if (lane == 0) {
-        whas[wave] = has2;
-        wval[wave] = val2;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        unsigned th = 0;
-        ull tv = 0;
-        for (int w = 0; w < DBF_WAVES; w++) {
-            if (whas[w]) { th = 1; tv = wval[w]; } else tv += wval[w];
-        }
-        unsigned ph;
-        ull pv;
-        cs_lookback(status2, tile, th, tv, ph, pv, err);
-        if (lane == 0) s_pre = pv;
-    }
-    __syncthreads();
-    unsigned ein = (unsigned)s_pre;   // extra starts of the open bucket before this wave's first point
-    for (int w = 0; w < wave; w++) ein = whas[w] ? wval[w] : ein + wval[w];
-    unsigned ordv[DBF_STEPS];         // destinations, fetched with independent loads ahead of the relabel loop
-#pragma unroll
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int i = t0 + (wave * DBF_STEPS + s) * 64 + lane;
-        ordv[s] = i < n ? ord[i] : 0u;
-    }
-#pragma unroll
-    for (int s = 0; s < DBF_STEPS; s++) {
-        const int W = wave * DBF_STEPS + s;
-        const int g0 = t0 + W * 64;
-        if (g0 >= n) break;
-        const int i = g0 + lane;
-        const ull e = em[W], b = bm[W], s1 = s1m[W], f = fm[W];
-        const ull ble = b & dbf_le(lane);
-        const unsigned E = ble ? (unsigned)dbf_popc(e & dbf_le(lane) & (~0ull << (63 - __clzll((long long)ble))))
-                               : ein + (unsigned)dbf_popc(e & dbf_le(lane));     // inclusive count of extra starts of my bucket
-        if (i < n) {
-            const int l = lsh[i - sh0];
-            const int bk = db_bucket(boff, nb, i);
-            const unsigned rb = runbase[bk];
-            const long long Rb = (long long)(runbase[bk + 1] - rb);
-            double lab = -1.0;
-            if ((f >> lane) & 1ull) lab = ((s1 >> lane) & 1ull) ? (double)((unsigned)l - rb) : (double)(Rb - 1 + (long long)E);
-            labels[l >= 0 ? ordv[s] : (unsigned)i] = lab;
-            if (last_id && i + 1 == boff[bk + 1]) last_id[bk] = Rb - 1 + (long long)E;
-        }
-        ein = b ? (unsigned)dbf_popc(e & (~0ull << (63 - __clzll((long long)b)))) : ein + (unsigned)dbf_popc(e);
-    }
 }
 
 __global__ void dbf_empty_buckets(const int *__restrict__ boff, int nb, long long *__restrict__ last_id) {
@@ -604,7 +211,23 @@ __device__ __forceinline__ ull dbf_starts_y(ull cur, ull prev, ull h) { return c
 // set bits of `bits` at or after the highest set bit of `marks` (marks != 0)
 __device__ __forceinline__ ull dbf_from_last(ull bits, ull marks) { return bits & (~0ull << (63 - __clzll((long long)marks))); }
 
+// Branch-free p word for the common configuration (one bucket, m <= 4: the reference default is 3): four
+// unconditional LDS reads (the staged range always covers o+4, zero filled past the array), selects instead
+// of exec-mask branches.  eps32 = min(eps, 2^32-1); wide == eps > 2^32-1 (every 32-bit distance qualifies).
+__device__ __forceinline__ ull dbf_px_word_fast(const unsigned *xsh, int sh0, int n, unsigned eps32, bool wide, int m, int g0, int lane) {
+    const int i = g0 + lane;
+    const int o = i - sh0;
+    const unsigned xi = xsh[o], v1 = xsh[o + 1], v2 = xsh[o + 2], v3 = xsh[o + 3], v4 = xsh[o + 4];
+    const int cnt = min(i + m, n - 1) - i;   // window members (data[i+1:i+m+1] truncated at the array end, :43)
+    unsigned maxd = db_absdiff(v1, xi);
+    maxd = cnt >= 2 ? max(maxd, db_absdiff(v2, xi)) : maxd;
+    maxd = cnt >= 3 ? max(maxd, db_absdiff(v3, xi)) : maxd;
+    maxd = cnt >= 4 ? max(maxd, db_absdiff(v4, xi)) : maxd;
+    return __ballot(i >= 0 && i + m <= n && (wide || maxd < eps32));   // i <= n-m (:39)
+}
+
 // p masks of one tile (+ the count of run starts)  — x staged with 16-byte loads
+template <bool FAST>
 __global__ __launch_bounds__(DBF_THREADS) void dbm_x_masks(const unsigned *__restrict__ x, int n, const int *__restrict__ boff, int nb,
                                                            ull eps, int m, ull *__restrict__ PM, ull *__restrict__ agg) {
     __shared__ __attribute__((aligned(16))) unsigned xsh[DBM_XSH4 * 4];
@@ -635,13 +258,18 @@ __global__ __launch_bounds__(DBF_THREADS) void dbm_x_masks(const unsigned *__res
         }
     }
     __syncthreads();
+    const unsigned eps32 = eps > 0xffffffffull ? 0xffffffffu : (unsigned)eps;
+    const bool wide = eps > 0xffffffffull;
+#pragma unroll 4
     for (int s = 0; s < DBF_STEPS; s++) {
         const int W = wave * DBF_STEPS + s;
-        const ull w = dbf_px_word(xsh, sh0, n, boff, nb, eps, m, t0 + W * 64, lane);
+        const ull w = FAST ? dbf_px_word_fast(xsh, sh0, n, eps32, wide, m, t0 + W * 64, lane)
+                           : dbf_px_word(xsh, sh0, n, boff, nb, eps, m, t0 + W * 64, lane);
         if (lane == 0) pm[1 + W] = w;
     }
     if (wave == 0) {
-        const ull w = dbf_px_word(xsh, sh0, n, boff, nb, eps, m, t0 - 64, lane);
+        const ull w = FAST ? dbf_px_word_fast(xsh, sh0, n, eps32, wide, m, t0 - 64, lane)
+                           : dbf_px_word(xsh, sh0, n, boff, nb, eps, m, t0 - 64, lane);
         if (lane == 0) pm[0] = w;
     }
     __syncthreads();
@@ -686,6 +314,7 @@ __global__ __launch_bounds__(DBF_THREADS) void dbm_x_labels(const ull *__restric
         baseS[lane] = enter;
     }
     __syncthreads();
+#pragma unroll 4
     for (int s = 0; s < DBF_STEPS; s++) {
         const int W = wave * DBF_STEPS + s;
         const int g0 = t0 + W * 64;
@@ -752,16 +381,17 @@ __global__ __launch_bounds__(DBF_THREADS) void dbm_y_masks(const int *__restrict
         }
     }
     __syncthreads();
-    auto py_word = [&](int g0) -> ull {
+    const unsigned eps32 = eps > 0xffffffffull ? 0xffffffffu : (unsigned)eps;
+    const bool wide = eps > 0xffffffffull;
+    auto py_word = [&](int g0) -> ull {   // branch free: the staged range always covers o and o+m-1
         const int i = g0 + lane;
-        bool p = false;
-        if (i >= 0 && i + m - 1 < n) {
-            const int l = lsh[i - sh0];
-            // next = y[i+1:i+m] must lie inside the same x-cluster (clusters are contiguous); sorted => max is the last
-            if (l >= 0 && lsh[i + m - 1 - sh0] == l) p = (ull)(ysh[i + m - 1 - sh0] - ysh[i - sh0]) < eps;
-        }
-        return __ballot(p);
+        const int o = i - sh0;
+        const int l = lsh[o], l2 = lsh[o + m - 1];
+        const unsigned d = ysh[o + m - 1] - ysh[o];
+        // next = y[i+1:i+m] must lie inside the same x-cluster (clusters are contiguous); sorted => max is the last
+        return __ballot(i >= 0 && i + m - 1 < n && l >= 0 && l2 == l && (wide || d < eps32));
     };
+#pragma unroll 4
     for (int s = 0; s < DBF_STEPS; s++) {
         const int W = wave * DBF_STEPS + s;
         const int g0 = t0 + W * 64;
@@ -822,6 +452,7 @@ __global__ __launch_bounds__(DBF_THREADS) void dbm_y_mid(const ull *__restrict__
         cinS[lane] = enter;      // starts of the open x-cluster before this word
     }
     __syncthreads();
+#pragma unroll 4
     for (int s = 0; s < DBF_STEPS; s++) {
         const int W = wave * DBF_STEPS + s;
         const ull st = dbf_uni(stS[W]), f = dbf_uni(fS[W]), h = dbf_uni(hS[W]);
@@ -882,6 +513,8 @@ __global__ __launch_bounds__(DBF_THREADS) void dbm_y_final(const int *__restrict
         einS[lane] = enter;     // extra starts of the open bucket before this word
     }
     __syncthreads();
+    const unsigned rb1 = runbase[0];                       // single-bucket constants (uniform loads, once)
+    const long long Rb1 = (long long)(runbase[1] - rb1);
 #pragma unroll
     for (int s = 0; s < DBF_STEPS; s++) {
         const int W = wave * DBF_STEPS + s;
@@ -895,8 +528,8 @@ __global__ __launch_bounds__(DBF_THREADS) void dbm_y_final(const int *__restrict
         if (i < n) {
             const int l = lv[s];
             const int bk = db_bucket(boff, nb, i);
-            const unsigned rb = runbase[bk];
-            const long long Rb = (long long)(runbase[bk + 1] - rb);
+            const unsigned rb = nb == 1 ? rb1 : runbase[bk];
+            const long long Rb = nb == 1 ? Rb1 : (long long)(runbase[bk + 1] - rb);
             double lab = -1.0;
             // sub-run 1 keeps the x id; the k-th extra start of the bucket owns id (R-1)+k   (DBSCAN.py:112-122)
             if ((f >> lane) & 1ull) lab = ((s1 >> lane) & 1ull) ? (double)((unsigned)l - rb) : (double)(Rb - 1 + (long long)E);
