@@ -129,6 +129,15 @@ int tdt_signal_select_device(tdt_ctx *ctx, const uint16_t *d_flag, const uint8_t
                              const int32_t *d_mate_tid, const int32_t *d_tlen, size_t n, const uint8_t *d_contig_ok, int n_contigs,
                              int min_q, int64_t max_ins, uint32_t *d_out_idx, uint64_t *d_count);
 
+/* ---- masked medians of the coverage bins -------------------------------------------------------- *
+ * Replaces the per-bin Python loop + numpy.median of determine_ploidy (tiddit_coverage_analysis.pyx:14-27).
+ * cov/gc are the concatenated float64 bins / int8 GC bins; segment s = [seg_off[2s], seg_off[2s+1]) (segments may
+ * overlap: per-contig segments plus one covering everything).  For every segment the selected values are
+ * { cov[i] : cov[i] > 0 and gc[i] != -1 }; count[s] = how many, lower[s]/upper[s] = the two middle order statistics
+ * (equal for odd counts) — numpy.median is their mean.  Radix select on the device, no sort. */
+int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t *gc, const int64_t *seg_off, int nseg, double *lower,
+                       double *upper, int64_t *count);
+
 /* ---- alignment-record decode (host) ---------------------------------------------------------- *
  * Replaces the per-read pysam attribute access that feeds the path (read.reference_start,
  * reference_end, mapq, flag, next_reference_id, next_reference_start, isize, cigartuples[0]/[-1],

@@ -525,3 +525,49 @@ def test_coverage_host_push_many_chunks(cov):
     got = h.finish("c")
     assert h.kept() == kept and np.array_equal(got, want)
     h.close()
+
+
+# --------------------------------------------------------------------------------------- ploidy
+def test_masked_medians_vs_numpy(ctx):
+    """determine_ploidy's masked medians (tiddit_coverage_analysis.pyx:14-27): numpy.median is the reference"""
+    from tiddit_amd import tiddit_coverage_analysis as ca
+    rng = np.random.default_rng(17)
+    pairs = []
+    for n in (0, 1, 2, 5, 1000, 250_001, 3_000_000, 7):
+        cov = np.round(rng.gamma(9.0, 3.3, n), 3) * (rng.random(n) > 0.1)          # many ties, 10 % empty bins
+        gc = np.where(rng.random(n) < 0.07, -1, rng.integers(0, 101, n)).astype(np.int8)
+        pairs.append((cov, gc))
+    pairs.append((np.zeros(50), np.zeros(50, np.int8)))                                  # nothing selected
+    pairs.append((np.array([2.5, 2.5, 2.5, 7.0]), np.array([10, 10, -1, 10], np.int8)))
+    med, overall = ca.masked_medians(pairs)
+    allv = []
+    for (cov, gc), m in zip(pairs, med):
+        sel = cov[(cov > 0) & (gc != -1)]
+        allv.append(sel)
+        if len(sel):
+            assert m == np.median(sel), len(cov)
+        else:
+            assert np.isnan(m)
+    assert overall == np.median(np.concatenate(allv))
+
+
+def test_determine_ploidy_table(ctx, tmp_path):
+    from tiddit_amd import tiddit_coverage_analysis as ca
+    rng = np.random.default_rng(2)
+    cov = {"chr1": rng.gamma(20, 1.5, 40000), "chrX": rng.gamma(10, 1.5, 20000), "chrEmpty": np.zeros(100)}
+    gc = {k: np.where(rng.random(len(v)) < 0.05, -1, 40).astype(np.int8) for k, v in cov.items()}
+    lib = ca.determine_ploidy(cov, ["chr1", "chrX", "chrEmpty", "chrMissing"], {}, 2, str(tmp_path / "p"), None, "ref.fa", 50, {}, gc)
+    # the reference's loop, literally
+    want, allc = {}, []
+    for ch in cov:
+        tmp = [cov[ch][i] for i in range(len(cov[ch])) if cov[ch][i] > 0 and gc[ch][i] != -1]
+        allc += tmp
+        m = np.median(tmp) if tmp else np.nan
+        want[ch] = 0 if np.isnan(m) else m
+    assert lib["avg_coverage"] == np.median(allc)
+    for ch in cov:
+        assert lib["avg_coverage_" + ch] == want[ch]
+        assert lib["contig_ploidy_" + ch] == int(round(2 * want[ch] / lib["avg_coverage"]))
+    rows = open(str(tmp_path / "p.ploidies.tab")).read().splitlines()
+    assert rows[0] == "Chromosome\tPloidy\tPloidy_rounded\tMean_coverage" and len(rows) == 4
+    assert rows[1] == "chr1\t{}\t{}\t{}".format(want["chr1"] / lib["avg_coverage"] * 2, lib["contig_ploidy_chr1"], want["chr1"])

@@ -57,6 +57,7 @@ SYMBOLS = {
     "tdt_sort_dbscan": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P]),
     "tdt_signal_select": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, ctypes.POINTER(_sz)]),
     "tdt_signal_select_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, _P]),
+    "tdt_masked_medians": (_i, [_P, _P, _P, _P, _i, _P, _P, _P]),
     "tdt_bam_decode": (_i, [_P, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)] + [_P] * 13),
 }
 

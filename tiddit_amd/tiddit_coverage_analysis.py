@@ -1,29 +1,47 @@
 """Drop-in for ``tiddit.tiddit_coverage_analysis.determine_ploidy`` (tiddit_coverage_analysis.pyx:9-41):
-per-contig median of the coverage bins that are covered and not N-masked, genome median, ploidy table.
-The reference walks every bin in Python; here the mask is one numpy expression per contig (host-side
-consumer of the two device histograms — SURVEY §8(f) row 1)."""
+per-contig median of the coverage bins that are covered and not N-masked, genome-wide median, ploidy table.
+The reference walks every bin in Python and calls numpy.median on the survivors; here the masked medians of all
+contigs and of the whole genome come from ONE device call (radix select on the float64 bit patterns,
+csrc/tdt_median.hip); the two middle values are averaged with numpy exactly like numpy.median does."""
 import numpy
+
+from . import _native
+
+
+def masked_medians(pairs, ctx=None):
+    """pairs: list of (coverage float64[], gc int8[]) -> (list of per-pair medians, median over all pairs).
+    median of { cov[i] : cov[i] > 0 and gc[i] != -1 }; nan for an empty selection (numpy.median([]))."""
+    ctx = ctx or _native.default_context()
+    covs, gcs, off, o = [], [], [], 0
+    for cov, gc in pairs:
+        n = len(cov)
+        if len(gc) < n:
+            raise IndexError("gc array shorter than its coverage array")     # the reference indexes gc[chromosome][i]
+        covs.append(numpy.ascontiguousarray(cov, dtype=numpy.float64))
+        gcs.append(numpy.ascontiguousarray(gc[:n], dtype=numpy.int8))
+        off += [o, o + n]
+        o += n
+    off += [0, o]
+    cov_all = numpy.concatenate(covs) if covs else numpy.zeros(0)
+    gc_all = numpy.concatenate(gcs) if gcs else numpy.zeros(0, dtype=numpy.int8)
+    seg = numpy.array(off, dtype=numpy.int64)
+    nseg = len(seg) // 2
+    lower, upper = numpy.empty(nseg), numpy.empty(nseg)
+    count = numpy.empty(nseg, dtype=numpy.int64)
+    _native.check(ctx.lib.tdt_masked_medians(ctx.handle, _native.ptr(cov_all), _native.ptr(gc_all), _native.ptr(seg), nseg,
+                                             _native.ptr(lower), _native.ptr(upper), _native.ptr(count)))
+    med = [numpy.mean([lower[s], upper[s]]) if count[s] else numpy.nan for s in range(nseg)]
+    return med[:-1], med[-1]
 
 
 def determine_ploidy(coverage_data, contigs, library, ploidy, prefix, c, reference_fasta, bin_size, bam_header, gc):
     f = open("{}.ploidies.tab".format(prefix), "w")
     f.write("Chromosome\tPloidy\tPloidy_rounded\tMean_coverage\n")
-    all_cov = []
-    for chromosome in coverage_data:
-        cov = coverage_data[chromosome]
-        g = gc[chromosome]
-        n = len(cov)
-        keep = cov[(cov > 0) & (numpy.asarray(g[:n]) != -1)] if len(g) >= n else None
-        if keep is None:
-            raise IndexError("gc array shorter than the coverage array of " + chromosome)
-        all_cov.append(keep)
-        med = numpy.median(keep) if len(keep) else numpy.nan
+    names = list(coverage_data)
+    per_contig, overall = masked_medians([(coverage_data[ch], gc[ch]) for ch in names])
+    for chromosome, med in zip(names, per_contig):
         library["avg_coverage_{}".format(chromosome)] = 0 if numpy.isnan(med) else med
-    if not c:
-        flat = numpy.concatenate(all_cov) if all_cov else numpy.zeros(0)
-        library["avg_coverage"] = numpy.median(flat) if len(flat) else numpy.nan
-    else:
-        library["avg_coverage"] = c
+    library["avg_coverage"] = c if c else overall
     for chromosome in contigs:
         if chromosome not in coverage_data:
             continue
