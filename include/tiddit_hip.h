@@ -138,6 +138,22 @@ int tdt_signal_select_device(tdt_ctx *ctx, const uint16_t *d_flag, const uint8_t
 int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t *gc, const int64_t *seg_off, int nseg, double *lower,
                        double *upper, int64_t *count);
 
+/* ---- regional evidence counts per SV candidate --------------------------------------------------- *
+ * Replaces the per-candidate BAM re-scan of tiddit_variant.get_region (tiddit_variant.pyx:54-151).  The arrays
+ * are ONE contig's coordinate-sorted alignment records (has_sa[i] != 0 iff the record carries an SA tag, tid = the
+ * contig's id for the `next_reference_name != reference_name` test).  Query q = (start, end, bp) as in the
+ * reference call get_region(samfile, chr, start, end, bp, min_q, max_ins, ...).  out[q*7 + ...] =
+ * bases, n_reads, low_q, n_discs, n_splits, crossing_f, crossing_r  (the reference then returns
+ * coverage = bases/(end-start+1) and frac_low_q = low_q/n_reads). */
+int tdt_region_counts(tdt_ctx *ctx, const int32_t *start, const int32_t *end, const uint8_t *mapq, const uint16_t *flag,
+                      const int32_t *mate_tid, const int32_t *mate_pos, const int32_t *tlen, const uint8_t *has_sa, size_t n, int tid,
+                      int64_t contig_length, const int32_t *q_start, const int32_t *q_end, const int32_t *q_bp, size_t nq, int min_q,
+                      int64_t max_ins, int64_t *out);
+int tdt_region_counts_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq, const uint16_t *d_flag,
+                             const int32_t *d_mate_tid, const int32_t *d_mate_pos, const int32_t *d_tlen, const uint8_t *d_has_sa,
+                             size_t n, int tid, int max_span, int64_t contig_length, const int32_t *d_q_start, const int32_t *d_q_end,
+                             const int32_t *d_q_bp, size_t nq, int min_q, int64_t max_ins, int64_t *d_out);
+
 /* ---- alignment-record decode (host) ---------------------------------------------------------- *
  * Replaces the per-read pysam attribute access that feeds the path (read.reference_start,
  * reference_end, mapq, flag, next_reference_id, next_reference_start, isize, cigartuples[0]/[-1],

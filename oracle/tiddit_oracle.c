@@ -247,3 +247,50 @@ int64_t orc_dbscan_main(const int64_t *data, int64_t n, int64_t stride, double e
     return literal ? orc_y_clustering_literal(data, n, stride, eps, m, id, clusters)
                    : orc_y_clustering_sweep(data, n, stride, eps, m, id, clusters);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * get_region — tiddit_variant.pyx:54-151, literal loop over ONE contig's coordinate-sorted records.
+ * PARITY UNPINNED at the fetch boundary (pysam absent): samfile.fetch(chr, q_start, q_end) is taken to
+ * return the records with pos < q_end and bam_endpos > q_start, in file order.
+ * out[7] = bases, n_reads, low_q, n_discs, n_splits, crossing_f, crossing_r.
+ * ---------------------------------------------------------------------------------------- */
+void orc_get_region(const int32_t *start, const int32_t *end, const uint8_t *mapq, const uint16_t *flag,
+                    const int32_t *mate_tid, const int32_t *mate_pos, const int32_t *tlen, const uint8_t *has_sa, int64_t n,
+                    int tid, int64_t contig_length, int64_t rstart, int64_t rend, int64_t bp, int min_q, int64_t max_ins,
+                    int64_t *out) {
+    int64_t low_q = 0, n_reads = 0, bases = 0, n_discs = 0, n_splits = 0, crossing_r = 0, crossing_f = 0;
+    int64_t q_start = rstart, q_end = rend + max_ins;
+    if (q_end > contig_length) q_end = contig_length;
+    if (q_start >= q_end) q_start = q_end - 10;
+    for (int64_t i = 0; i < n; i++) {
+        if (!((int64_t)start[i] < q_end && (int64_t)end[i] > q_start)) continue; /* region fetch */
+        if (flag[i] & 0x4) continue;
+        int64_t rs = start[i];
+        if (!(flag[i] & 0x8)) {
+            if (mate_pos[i] > rend && rs > rend) continue;
+        } else {
+            if (rs > rend) continue;
+        }
+        if (flag[i] & 0x400) continue;
+        if (!(rs > rend)) {
+            n_reads++;
+            if ((int)mapq[i] < min_q) low_q++;
+        }
+        if ((int)mapq[i] < min_q) continue;
+        int64_t re = end[i];
+        int64_t r_start = rs, r_end = re;
+        if (rs < bp - 20 && r_end > bp + 20) crossing_r++;
+        int mate_bp_read = (mate_pos[i] < bp - 50 && r_end > bp + 50);
+        int64_t isz = tlen[i] < 0 ? -(int64_t)tlen[i] : tlen[i];
+        int discordant = (isz > max_ins || mate_tid[i] != tid);
+        if (mate_bp_read && !discordant) crossing_f++;
+        if (re < rstart) continue;
+        else if (rs > rend) continue;
+        if (rs < rstart) r_start = rstart;
+        if (re > rend) r_end = rend;
+        bases += r_end - r_start + 1;
+        if (has_sa[i]) n_splits++;
+        if (discordant) n_discs++;
+    }
+    out[0] = bases; out[1] = n_reads; out[2] = low_q; out[3] = n_discs; out[4] = n_splits; out[5] = crossing_f; out[6] = crossing_r;
+}

@@ -139,3 +139,29 @@ def test_cli_sv_skip_assembly_end_to_end(sv_bam, tmp_path):
     assert found >= n_del - 1, (found, n_del)
     plo = open(out + ".ploidies.tab").read().splitlines()
     assert plo[0] == "Chromosome\tPloidy\tPloidy_rounded\tMean_coverage" and len(plo) >= 4
+
+
+def test_region_counts_vs_literal_loop(sv_bam):
+    """tiddit_variant.get_region's loop (row §8(f)3): one wavefront per candidate vs the per-read restatement"""
+    from tiddit_amd import tiddit_region
+    bam, fa, info, d = sv_bam
+    table = tiddit_region.ReadTable(bam)
+    rng = np.random.default_rng(4)
+    for chrom, LN in CONTIGS[:4]:
+        t = table.tid[chrom]
+        nq = 300
+        starts = rng.integers(0, LN - 10, nq)
+        ends = np.minimum(starts + rng.integers(0, 3000, nq), LN + 500)        # some regions run past the contig end
+        bps = np.where(rng.random(nq) < 0.5, starts, ends)
+        for ev in info["events"]:                                                # ... and the planted breakpoints
+            if ev.get("chrom") == chrom:
+                starts[0], ends[0], bps[0] = ev["start"] - 100, ev["start"] + 100, ev["start"]
+        for min_q, max_ins in ((5, 600), (20, 450)):
+            got = tiddit_region.region_counts(table, chrom, starts, ends, bps, min_q, max_ins)
+            for q in range(nq):
+                want = oracle.get_region_counts(table.contigs[t], t, LN, int(starts[q]), int(ends[q]), int(bps[q]), min_q, max_ins)
+                assert np.array_equal(got[q], want), (chrom, q, starts[q], ends[q], bps[q])
+        assert got[:, 1].sum() > 0 and got[:, 0].sum() > 0
+    cov, flq, nd, ns, cf, cr = tiddit_region.get_region(table, "chr1", 1000, 1500, 1200, 5, 600)
+    w = oracle.get_region_counts(table.contigs[0], 0, CONTIGS[0][1], 1000, 1500, 1200, 5, 600)
+    assert cov == w[0] / 501 and nd == w[3] and ns == w[4] and cf == w[5] and cr == w[6]
