@@ -19,14 +19,30 @@ struct RegionArrays {
     long long contig_length;
 };
 
-__device__ __forceinline__ int rg_lower_bound(const int32_t *__restrict__ a, int n, long long v) {   // first i with a[i] >= v
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((long long)a[mid] < v) lo = mid + 1;
-        else hi = mid;
+// Wave-cooperative 64-ary lower bounds (first i with a[i] >= v) for TWO keys in lock step: every round the 64 lanes probe 64
+// evenly spaced elements of each key's bracket, a ballot counts the probes below the key and the bracket shrinks 64x —
+// 5 dependent loads for 25 M reads instead of the 25 of a scalar binary search, with both chains in flight together.
+__device__ __forceinline__ void rg_lower_bound2(const int32_t *__restrict__ a, int n, long long v0, long long v1, int lane, int &r0,
+                                                int &r1) {
+    int lo0 = 0, hi0 = n, lo1 = 0, hi1 = n;
+    while (hi0 - lo0 > 64 || hi1 - lo1 > 64) {
+        const int c0 = (hi0 - lo0) >> 6, c1 = (hi1 - lo1) >> 6;               // chunk; 0 = this bracket is already narrow
+        const int x0 = c0 ? a[lo0 + (lane + 1) * c0 - 1] : 0, x1 = c1 ? a[lo1 + (lane + 1) * c1 - 1] : 0;
+        if (c0) {
+            const int k = __popcll(__ballot((long long)x0 < v0));
+            hi0 = k < 64 ? lo0 + (k + 1) * c0 - 1 : hi0;
+            lo0 += k * c0;
+        }
+        if (c1) {
+            const int k = __popcll(__ballot((long long)x1 < v1));
+            hi1 = k < 64 ? lo1 + (k + 1) * c1 - 1 : hi1;
+            lo1 += k * c1;
+        }
     }
-    return lo;
+    const bool b0 = lo0 + lane < hi0 && (long long)a[lo0 + lane] < v0;
+    const bool b1 = lo1 + lane < hi1 && (long long)a[lo1 + lane] < v1;
+    r0 = lo0 + __popcll(__ballot(b0));
+    r1 = lo1 + __popcll(__ballot(b1));
 }
 
 __global__ __launch_bounds__(256) void region_counts(RegionArrays R, const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
@@ -39,39 +55,36 @@ __global__ __launch_bounds__(256) void region_counts(RegionArrays R, const int32
     long long q_start = start, q_end = end + max_ins;          // :68-75
     if (q_end > R.contig_length) q_end = R.contig_length;
     if (q_start >= q_end) q_start = q_end - 10;
-    const int hi = rg_lower_bound(R.start, R.n, q_end);                         // pos < q_end
-    const int lo = rg_lower_bound(R.start, R.n, q_start - (long long)R.max_span);  // earlier reads cannot reach q_start
+    int lo, hi;   // pos < q_end  <=>  i < hi;   reads before lo end at or before q_start (start + max_span <= q_start)
+    rg_lower_bound2(R.start, R.n, q_start - (long long)R.max_span, q_end, lane, lo, hi);
     long long bases = 0;
     unsigned n_reads = 0, low_q = 0, n_discs = 0, n_splits = 0, cross_f = 0, cross_r = 0;
     for (int i0 = lo; i0 < hi; i0 += 64) {
-        const int i = i0 + lane;
-        if (i >= hi) continue;
-        const long long rs = R.start[i], re = R.end[i];
-        if (!(re > q_start)) continue;                                           // not returned by the region fetch
-        const unsigned f = R.flag[i];
-        if (f & 0x4u) continue;                                                  // :84
-        const long long mpos = R.mate_pos[i];
-        if (!(f & 0x8u)) {                                                       // :89-94
-            if (mpos > end && rs > end) continue;
-        } else if (rs > end) continue;
-        if (f & 0x400u) continue;                                                // :96
-        const bool lowq = (int)R.mapq[i] < min_q;
-        if (!(rs > end)) {                                                       // :99-102
-            n_reads++;
-            low_q += lowq ? 1u : 0u;
-        }
-        if (lowq) continue;                                                      // :104
-        if (rs < bp - 20 && re > bp + 20) cross_r++;                             // :114
-        const bool mate_bp_read = mpos < bp - 50 && re > bp + 50;                // :117
+        const bool in = i0 + lane < hi;
+        const int i = in ? i0 + lane : lo;                                       // all eight loads issue together, predicates after
+        const long long rs = R.start[i], re = R.end[i], mpos = R.mate_pos[i];
         long long isz = R.tlen[i];
+        const int mtid = R.mate_tid[i];
+        const unsigned f = R.flag[i];
+        const bool lowq = (int)R.mapq[i] < min_q, sa = R.has_sa[i] != 0;
+        bool live = in && re > q_start;                                          // returned by the region fetch
+        live = live && !(f & 0x4u);                                              // :84
+        live = live && !((f & 0x8u) ? rs > end : (mpos > end && rs > end));      // :89-94
+        live = live && !(f & 0x400u);                                            // :96
+        const bool counted = live && !(rs > end);                                // :99-102
+        n_reads += counted ? 1u : 0u;
+        low_q += (counted && lowq) ? 1u : 0u;
+        live = live && !lowq;                                                    // :104
+        cross_r += (live && rs < bp - 20 && re > bp + 20) ? 1u : 0u;             // :114
+        const bool mate_bp_read = mpos < bp - 50 && re > bp + 50;                // :117
         isz = isz < 0 ? -isz : isz;
-        const bool discordant = isz > max_ins || R.mate_tid[i] != R.tid;         // :118
-        if (mate_bp_read && !discordant) cross_f++;                              // :120
-        if (re < start || rs > end) continue;                                    // :123-126
+        const bool discordant = isz > max_ins || mtid != R.tid;                  // :118
+        cross_f += (live && mate_bp_read && !discordant) ? 1u : 0u;              // :120
+        live = live && !(re < start || rs > end);                                // :123-126
         const long long r_start = rs < start ? start : rs, r_end = re > end ? end : re;
-        bases += r_end - r_start + 1;                                            // :134
-        n_splits += R.has_sa[i] ? 1u : 0u;                                       // :136
-        n_discs += discordant ? 1u : 0u;                                         // :139
+        bases += live ? r_end - r_start + 1 : 0;                                 // :134
+        n_splits += (live && sa) ? 1u : 0u;                                      // :136
+        n_discs += (live && discordant) ? 1u : 0u;                               // :139
     }
     for (int d = 32; d > 0; d >>= 1) {
         bases += __shfl_xor(bases, d);
