@@ -154,6 +154,23 @@ int tdt_region_counts_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t
                              size_t n, int tid, int max_span, int64_t contig_length, const int32_t *d_q_start, const int32_t *d_q_end,
                              const int32_t *d_q_bp, size_t nq, int min_q, int64_t max_ins, int64_t *d_out);
 
+/* ---- BGZF inflate (host, threaded) ---------------------------------------------------------------- *
+ * Replaces pysam/htslib's block reader (`pysam.AlignmentFile(bam, "r", threads=n)`, tiddit_signal.pyx:159,
+ * __main__.py:224).  tdt_bgzf_scan hops the block headers of `comp[0..len)`: it reports how many WHOLE blocks are
+ * present, their compressed size (`consumed`) and what they inflate to (`produced`, never more than max_out).
+ * tdt_bgzf_inflate inflates exactly such a span (len = consumed, out_len = produced) on `threads` host threads
+ * (<= 0: tdt_host_threads' value), every block straight to its final offset, CRC32 and ISIZE verified.
+ * tdt_host_threads(n) sets the worker count for the host stages (n <= 0: query only) and returns the previous
+ * value; default min(hardware threads, 64) or $TIDDIT_HOST_THREADS. */
+int tdt_host_threads(int n);
+int tdt_bgzf_scan(const uint8_t *comp, size_t len, size_t max_out, size_t *n_blocks, size_t *consumed, size_t *produced);
+int tdt_bgzf_inflate(const uint8_t *comp, size_t len, uint8_t *out, size_t out_len, int threads);
+
+/* Same contract as tdt_bgzf_inflate, but the blocks are inflated ON THE DEVICE (one wavefront per block, CRC32 and ISIZE
+ * verified there): `comp` is a host pointer to whole BGZF blocks; `out` is a host buffer, or a device pointer when
+ * out_on_device != 0 (the record decode and the histogram kernels then read it in place). */
+int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t len, uint8_t *out, size_t out_len, int out_on_device);
+
 /* ---- alignment-record decode (host) ---------------------------------------------------------- *
  * Replaces the per-read pysam attribute access that feeds the path (read.reference_start,
  * reference_end, mapq, flag, next_reference_id, next_reference_start, isize, cigartuples[0]/[-1],

@@ -61,3 +61,41 @@ def test_fasta_reader(tmp_path):
         assert ff.get_reference_length(n) == len(s)
         assert np.array_equal(ff.fetch_array(n), s)
     assert ff.fetch("a", 100, 150) == seqs["a"][100:150].tobytes().decode()
+
+
+def test_native_bgzf_inflate_matches_zlib_and_checks_crc(bam, tmp_path):
+    """tdt_bgzf_scan / tdt_bgzf_inflate (threaded host inflate) vs Python zlib block by block; corrupt and truncated input fail loudly"""
+    import ctypes
+    from tiddit_amd import _native
+    path, _ = bam
+    lib = _native.load()
+    comp = np.fromfile(path, dtype=np.uint8)
+    want = b"".join(bamio.bgzf_blocks(open(path, "rb")))
+    nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _native.check(lib.tdt_bgzf_scan(_native.ptr(comp), len(comp), 1 << 40, ctypes.byref(nb), ctypes.byref(consumed), ctypes.byref(produced)))
+    assert consumed.value == len(comp) and produced.value == len(want) and nb.value > 3
+    for threads in (1, 3, 0):
+        out = np.zeros(produced.value, dtype=np.uint8)
+        _native.check(lib.tdt_bgzf_inflate(_native.ptr(comp), consumed.value, _native.ptr(out), len(out), threads))
+        assert out.tobytes() == want
+    # the scan stops at max_out and at a partial trailing block
+    _native.check(lib.tdt_bgzf_scan(_native.ptr(comp), len(comp) - 5, 100_000, ctypes.byref(nb), ctypes.byref(consumed), ctypes.byref(produced)))
+    assert 0 < produced.value <= 100_000 and nb.value >= 1
+    part = np.zeros(produced.value, dtype=np.uint8)
+    _native.check(lib.tdt_bgzf_inflate(_native.ptr(comp), consumed.value, _native.ptr(part), len(part), 2))
+    assert part.tobytes() == want[:produced.value]
+    # one flipped payload byte -> CRC/inflate failure, never silent
+    bad = comp.copy()
+    bad[consumed.value // 2] ^= 0x55
+    with pytest.raises(_native.TdtError):
+        _native.check(lib.tdt_bgzf_inflate(_native.ptr(bad), consumed.value, _native.ptr(part), len(part), 2))
+    with pytest.raises(_native.TdtError):                                    # wrong output size
+        _native.check(lib.tdt_bgzf_inflate(_native.ptr(comp), consumed.value, _native.ptr(part), len(part) - 1, 2))
+    with pytest.raises(_native.TdtError):                                    # not BGZF
+        _native.check(lib.tdt_bgzf_scan(_native.ptr(part), len(part), 1 << 30, ctypes.byref(nb), ctypes.byref(consumed), ctypes.byref(produced)))
+    trunc = str(tmp_path / "trunc.bam")
+    comp[:len(comp) - 40].tofile(trunc)                                       # cut inside the last data block (EOF marker is 28 bytes)
+    with pytest.raises(ValueError):
+        for _ in bamio.BamReader(trunc).batches():
+            pass
+    assert lib.tdt_host_threads(0) >= 1

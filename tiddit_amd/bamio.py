@@ -1,8 +1,8 @@
 """Minimal BGZF/BAM reader + writer (the reference reads alignments through pysam/htslib, which is not
 a dependency here).
 
-``BamReader.batches()`` inflates BGZF blocks with zlib and hands whole-record chunks to the C decoder
-``tdt_bam_decode`` (csrc/tdt_bam.hip), yielding struct-of-arrays batches: the packed
+``BamReader.batches()`` inflates BGZF blocks on the native host thread pool (``tdt_bgzf_inflate``, csrc/tdt_bgzf.hip)
+and hands whole-record pieces to the C decoder ``tdt_bam_decode`` (csrc/tdt_bam.hip), yielding struct-of-arrays batches: the packed
 start/end/mapq/flag arrays go straight to the coverage kernel, the mate fields drive the discordant-pair
 predicate, and the few reads that need string work (SA tags, clipped sequences, names) are pulled out of
 the raw record bytes with :class:`RecordView`.  ``BamWriter`` produces small coordinate-sorted BAMs for
@@ -112,7 +112,7 @@ class RecordView:
     @property
     def query_name(self):
         l = self._u("<B", 8)
-        return self.raw[self.off + 32:self.off + 32 + l - 1].decode()
+        return bytes(self.raw[self.off + 32:self.off + 32 + l - 1]).decode()
 
     @property
     def cigartuples(self):
@@ -135,8 +135,18 @@ class RecordView:
         o = int(self.batch.sa_off[self.i])
         if o < 0:
             raise KeyError("SA")
-        e = self.raw.index(b"\x00", o)
-        return self.raw[o:e].decode()
+        raw = self.raw
+        if isinstance(raw, np.ndarray):
+            w = 256
+            while True:
+                z = np.flatnonzero(raw[o:o + w] == 0)
+                if len(z) or o + w >= len(raw):
+                    break
+                w *= 4
+            e = o + int(z[0])
+        else:
+            e = raw.index(b"\x00", o)
+        return bytes(raw[o:e]).decode()
 
 
 class Batch:
@@ -151,19 +161,75 @@ class Batch:
         return RecordView(self, i)
 
 
+def inflate_pieces(f, chunk=32 << 20, max_out=192 << 20, gap=1 << 20, depth=2):
+    """The uncompressed byte stream of BGZF file object `f` in large pieces: uint8 arrays whose first `gap` bytes are
+    free (the caller parks the previous piece's partial record there).  The file is read `chunk` compressed bytes at a
+    time, whole blocks are found by ``tdt_bgzf_scan`` and inflated on the host thread pool by ``tdt_bgzf_inflate``
+    (CRC32/ISIZE checked); a helper thread keeps up to `depth` pieces ahead of the consumer."""
+    import queue
+    import threading
+    lib = _native.load()
+    q = queue.Queue(maxsize=depth)
+
+    def produce():
+        try:
+            comp = np.empty(chunk + (1 << 17), dtype=np.uint8)
+            have, eof = 0, False
+            while True:
+                if not eof:
+                    got = f.readinto(memoryview(comp)[have:have + chunk])
+                    eof = not got
+                    have += got or 0
+                if have == 0:
+                    break
+                nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+                _native.check(lib.tdt_bgzf_scan(_native.ptr(comp), have, max_out, ctypes.byref(nb), ctypes.byref(consumed),
+                                                ctypes.byref(produced)))
+                if nb.value == 0:
+                    if eof:
+                        raise ValueError("truncated BGZF block at end of file")
+                    if have >= len(comp) - chunk // 2 - 1:
+                        raise ValueError("BGZF block larger than the read window")
+                    continue
+                out = np.empty(gap + produced.value, dtype=np.uint8)
+                _native.check(lib.tdt_bgzf_inflate(_native.ptr(comp), consumed.value, _native.ptr(out[gap:]), produced.value, 0))
+                rest = have - consumed.value
+                comp[:rest] = comp[consumed.value:have].copy()
+                have = rest
+                if len(comp) < have + chunk:
+                    comp = np.concatenate([comp[:have], np.empty(chunk + (1 << 17), dtype=np.uint8)])
+                q.put(out)
+            q.put(None)
+        except BaseException as e:      # hand the failure to the consumer
+            q.put(e)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    while True:
+        item = q.get()
+        if item is None:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+    th.join()
+
+
 class BamReader:
-    def __init__(self, path, batch_bytes=64 << 20):
+    GAP = 1 << 20
+
+    def __init__(self, path, batch_bytes=None):
         self.path = path
-        self.batch_bytes = batch_bytes
-        self._f = open(path, "rb")
-        self._blocks = bgzf_blocks_parallel(self._f)
+        self._f = open(path, "rb", buffering=0)
+        kw = {} if not batch_bytes else {"chunk": max(1 << 16, batch_bytes // 2), "max_out": max(1 << 17, batch_bytes)}
+        self._pieces = inflate_pieces(self._f, gap=self.GAP, **kw)
         self._buf = bytearray()
         self._read_header()
 
     def _need(self, n):
         while len(self._buf) < n:
             try:
-                self._buf += next(self._blocks)
+                self._buf += memoryview(next(self._pieces))[self.GAP:]
             except StopIteration:
                 return False
         return True
@@ -198,19 +264,25 @@ class BamReader:
                 self.header.setdefault("RG", []).append(rg)
 
     def batches(self):
-        """yield :class:`Batch` objects of whole records, ~batch_bytes of record data each"""
+        """yield :class:`Batch` objects of whole records, one per inflated piece"""
         lib = _native.load()
-        done = False
+        pending = np.frombuffer(bytes(self._buf), dtype=np.uint8)        # what followed the header in its piece
+        self._buf = bytearray()
+        first, done = len(pending) > 0, False
         while not done:
-            while len(self._buf) < self.batch_bytes:
-                try:
-                    self._buf += next(self._blocks)
-                except StopIteration:
-                    done = True
+            if first:
+                raw, first = pending, False
+            else:
+                piece = next(self._pieces, None)
+                if piece is None:
+                    if len(pending):
+                        raise ValueError("truncated BAM record at end of file")
                     break
-            if not self._buf:
-                break
-            raw = bytes(self._buf)
+                if len(pending) <= self.GAP:                              # park the partial record in the piece's gap
+                    piece[self.GAP - len(pending):self.GAP] = pending
+                    raw = piece[self.GAP - len(pending):]
+                else:
+                    raw = np.concatenate([pending, piece[self.GAP:]])
             cap = len(raw) // 36 + 1
             b = Batch()
             b.raw = raw
@@ -220,17 +292,16 @@ class BamReader:
             for k, dt in arrs.items():
                 setattr(b, k, np.empty(cap, dtype=dt))
             consumed, nrec = ctypes.c_size_t(0), ctypes.c_size_t(0)
-            _native.check(lib.tdt_bam_decode(raw, len(raw), cap, ctypes.byref(consumed), ctypes.byref(nrec),
+            _native.check(lib.tdt_bam_decode(_native.ptr(raw), len(raw), cap, ctypes.byref(consumed), ctypes.byref(nrec),
                                              *[_native.ptr(getattr(b, k)) for k in arrs]))
             n = nrec.value
             for k in arrs:
                 setattr(b, k, getattr(b, k)[:n])
-            del self._buf[:consumed.value]
-            if n == 0:
-                if done and self._buf:
-                    raise ValueError("truncated BAM record at end of file")
-                continue
-            yield b
+            pending = raw[consumed.value:]
+            if len(pending) <= self.GAP:
+                pending = pending.copy()
+            if n:
+                yield b
 
     def close(self):
         self._f.close()

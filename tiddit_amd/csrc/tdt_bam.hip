@@ -5,6 +5,12 @@
 // reference_end follows htslib's bam_endpos(): pos + sum of M/D/N/=/X lengths, pos + 1 when that sum is 0.
 #include "tdt_common.h"
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
+int tdt_host_thread_count();   // tdt_bgzf.hip
+
 static inline uint32_t rd_u32(const uint8_t *p) {
     uint32_t v;
     memcpy(&v, p, 4);
@@ -52,6 +58,9 @@ extern "C" int tdt_bam_decode(const uint8_t *buf, size_t len, size_t max_records
         tdt_set_error("tdt_bam_decode: bad argument");
         return TDT_E_ARG;
     }
+    // phase 1 (serial): hop the block_size chain to find the whole records in the buffer
+    std::vector<size_t> offs;
+    offs.reserve(len / 200 + 16);
     size_t o = 0, n = 0;
     while (n < max_records && o + 4 <= len) {
         const uint32_t bs = rd_u32(buf + o);
@@ -60,54 +69,80 @@ extern "C" int tdt_bam_decode(const uint8_t *buf, size_t len, size_t max_records
             return TDT_E_ARG;
         }
         if (o + 4 + (size_t)bs > len) break;  // partial record: caller supplies more bytes
-        const uint8_t *r = buf + o + 4;
-        const int32_t p = rd_i32(r + 4);
-        const uint8_t l_name = r[8];
-        const uint16_t n_cig = rd_u16(r + 12);
-        const int32_t lseq = rd_i32(r + 16);
-        const size_t var = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)lseq + 1) / 2 + (size_t)lseq;
-        if (lseq < 0 || var > bs) {
-            tdt_set_error("tdt_bam_decode: record %zu is inconsistent (block_size %u < %zu)", n, bs, var);
-            return TDT_E_ARG;
-        }
-        const uint8_t *cig = r + 32 + l_name;
-        int64_t rlen = 0;
-        for (uint16_t k = 0; k < n_cig; k++) {
-            const uint32_t c = rd_u32(cig + 4 * k);
-            const uint32_t op = c & 0xf;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += c >> 4;  // M D N = X consume the reference
-        }
-        const uint16_t fl = rd_u16(r + 14);
-        if ((fl & 0x4) || rlen == 0) rlen = 1;  // bam_endpos
-        if (tid) tid[n] = rd_i32(r);
-        if (pos) pos[n] = p;
-        if (end) end[n] = (int32_t)(p + rlen);
-        if (mapq) mapq[n] = r[9];
-        if (flag) flag[n] = fl;
-        if (mate_tid) mate_tid[n] = rd_i32(r + 20);
-        if (mate_pos) mate_pos[n] = rd_i32(r + 24);
-        if (tlen) tlen[n] = rd_i32(r + 28);
-        if (l_seq) l_seq[n] = lseq;
-        if (cigar_first) cigar_first[n] = n_cig ? rd_u32(cig) : 0xffffffffu;
-        if (cigar_last) cigar_last[n] = n_cig ? rd_u32(cig + 4 * (n_cig - 1)) : 0xffffffffu;
-        if (rec_off) rec_off[n] = o;
-        if (sa_off) {  // offset (from buf) of the SA:Z value, -1 when absent   (read.has_tag("SA"), tiddit_signal.pyx:199)
-            int64_t found = -1;
-            const uint8_t *a = r + var, *aend = r + bs;
-            while (a + 3 <= aend) {
-                const uint8_t t = a[2];
-                const long sz = aux_size(t, a + 3, aend);
-                if (sz < 0 || a + 3 + sz > aend) break;
-                if (a[0] == 'S' && a[1] == 'A' && t == 'Z') {
-                    found = (int64_t)((a + 3) - buf);
-                    break;
-                }
-                a += 3 + sz;
-            }
-            sa_off[n] = found;
-        }
+        offs.push_back(o);
         o += 4 + (size_t)bs;
         n++;
+    }
+    // phase 2 (threads): field extraction, CIGAR walk and SA lookup per record
+    std::atomic<long> bad{-1};
+    auto work = [&](size_t r0, size_t r1) {
+        for (size_t i = r0; i < r1; i++) {
+            const size_t ro = offs[i];
+            const uint32_t bs = rd_u32(buf + ro);
+            const uint8_t *r = buf + ro + 4;
+            const int32_t p = rd_i32(r + 4);
+            const uint8_t l_name = r[8];
+            const uint16_t n_cig = rd_u16(r + 12);
+            const int32_t lseq = rd_i32(r + 16);
+            const size_t var = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)(lseq < 0 ? 0 : lseq) + 1) / 2 + (size_t)(lseq < 0 ? 0 : lseq);
+            if (lseq < 0 || var > bs) {
+                long exp = -1;
+                bad.compare_exchange_strong(exp, (long)i);
+                return;
+            }
+            const uint8_t *cig = r + 32 + l_name;
+            int64_t rlen = 0;
+            for (uint16_t k = 0; k < n_cig; k++) {
+                const uint32_t c = rd_u32(cig + 4 * k);
+                const uint32_t op = c & 0xf;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += c >> 4;  // M D N = X consume the reference
+            }
+            const uint16_t fl = rd_u16(r + 14);
+            if ((fl & 0x4) || rlen == 0) rlen = 1;  // bam_endpos
+            if (tid) tid[i] = rd_i32(r);
+            if (pos) pos[i] = p;
+            if (end) end[i] = (int32_t)(p + rlen);
+            if (mapq) mapq[i] = r[9];
+            if (flag) flag[i] = fl;
+            if (mate_tid) mate_tid[i] = rd_i32(r + 20);
+            if (mate_pos) mate_pos[i] = rd_i32(r + 24);
+            if (tlen) tlen[i] = rd_i32(r + 28);
+            if (l_seq) l_seq[i] = lseq;
+            if (cigar_first) cigar_first[i] = n_cig ? rd_u32(cig) : 0xffffffffu;
+            if (cigar_last) cigar_last[i] = n_cig ? rd_u32(cig + 4 * (n_cig - 1)) : 0xffffffffu;
+            if (rec_off) rec_off[i] = ro;
+            if (sa_off) {  // offset (from buf) of the SA:Z value, -1 when absent   (read.has_tag("SA"), tiddit_signal.pyx:199)
+                int64_t found = -1;
+                const uint8_t *a = r + var, *aend = r + bs;
+                while (a + 3 <= aend) {
+                    const uint8_t t = a[2];
+                    const long sz = aux_size(t, a + 3, aend);
+                    if (sz < 0 || a + 3 + sz > aend) break;
+                    if (a[0] == 'S' && a[1] == 'A' && t == 'Z') {
+                        found = (int64_t)((a + 3) - buf);
+                        break;
+                    }
+                    a += 3 + sz;
+                }
+                sa_off[i] = found;
+            }
+        }
+    };
+    int threads = tdt_host_thread_count();
+    if (n < 65536) threads = 1;
+    if (threads == 1) work(0, n);
+    else {
+        std::vector<std::thread> pool;
+        const size_t per = (n + threads - 1) / threads;
+        for (int t = 0; t < threads; t++) {
+            const size_t r0 = (size_t)t * per, r1 = r0 + per < n ? r0 + per : n;
+            if (r0 < r1) pool.emplace_back(work, r0, r1);
+        }
+        for (auto &t : pool) t.join();
+    }
+    if (bad.load() >= 0) {
+        tdt_set_error("tdt_bam_decode: record %ld is inconsistent (fixed + variable fields exceed block_size)", bad.load());
+        return TDT_E_ARG;
     }
     *consumed = o;
     *n_records = n;

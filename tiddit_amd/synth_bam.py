@@ -129,3 +129,70 @@ def write_synthetic_bam(path, contigs, depth=10, read_len=100, insert=350, inser
         w.write(**recs[i][2])
     w.close()
     return {"events": events, "n_records": len(recs)}
+
+
+def write_bulk_bam(path, contigs, depth=30, read_len=100, insert=350, seed=1, level=1, threads=8, chunk=1 << 20):
+    """Large plain paired-end BAM written with numpy (fixed-size records: 12-byte name, one M cigar op, no aux), for
+    end-to-end timing of the BGZF/BAM ingest.  ~10 M records/min.  -> number of records."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    from .bamio import _BGZF_EOF, _bgzf_block
+    rng = np.random.default_rng(seed)
+    rec = np.dtype([("block_size", "<i4"), ("tid", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"), ("bin", "<u2"),
+                    ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("mate_tid", "<i4"), ("mate_pos", "<i4"), ("tlen", "<i4"),
+                    ("name", "S12"), ("cigar", "<u4"), ("seq", "u1", ((read_len + 1) // 2,)), ("qual", "u1", (read_len,))])
+    text = ("@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in contigs)).encode()
+    head = b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(contigs))
+    for name, ln in contigs:
+        nb = name.encode() + b"\x00"
+        head += struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln)
+    total = 0
+    qual_lut = np.sort(np.minimum(40, 2 + (38 * np.sqrt(np.arange(256) / 255.0)).astype(np.int64)).astype(np.uint8))   # skewed to high quality
+    with open(path, "wb") as f, ThreadPoolExecutor(threads) as pool:
+        pend = bytearray(head)
+
+        def flush(final=False):
+            nonlocal pend
+            nblk = len(pend) // 0xff00 if not final else -(-len(pend) // 0xff00)
+            view = bytes(pend[:nblk * 0xff00])
+            for blk in pool.map(lambda o: _bgzf_block(view[o:o + 0xff00], level), range(0, len(view), 0xff00)):
+                f.write(blk)
+            del pend[:nblk * 0xff00]
+
+        for tid, (name, L) in enumerate(contigs):
+            n_pairs = int(L * depth / (2 * read_len))
+            posA = rng.integers(0, max(1, L - insert - 100), n_pairs).astype(np.int64)
+            ins = np.maximum(read_len + 1, rng.normal(insert, 30, n_pairs).astype(np.int64))
+            posB = np.minimum(posA + ins - read_len, L - read_len)
+            pos = np.concatenate([posA, posB])
+            mate = np.concatenate([posB, posA])
+            tl = np.concatenate([posB + read_len - posA, -(posB + read_len - posA)])
+            flag = np.concatenate([np.full(n_pairs, 0x1 | 0x2 | 0x40 | 0x20), np.full(n_pairs, 0x1 | 0x2 | 0x80 | 0x10)])
+            order = np.argsort(pos, kind="stable")
+            pos, mate, tl, flag = pos[order], mate[order], tl[order], flag[order]
+            for lo in range(0, len(pos), chunk):
+                hi = min(len(pos), lo + chunk)
+                m = hi - lo
+                a = np.zeros(m, dtype=rec)
+                a["block_size"] = rec.itemsize - 4
+                a["tid"], a["pos"], a["l_name"] = tid, pos[lo:hi], 12
+                u = rng.random(m)
+                a["mapq"] = np.where(u < 0.05, rng.integers(0, 20, m), 60)
+                a["n_cigar"], a["l_seq"] = 1, read_len
+                a["flag"] = flag[lo:hi] | np.where(rng.random(m) < 0.02, 0x400, 0)
+                a["mate_tid"], a["mate_pos"], a["tlen"] = tid, mate[lo:hi], tl[lo:hi]
+                a["bin"] = 4681 + (pos[lo:hi] >> 14)
+                ids = (total + order[lo:hi] % max(1, n_pairs)).astype(np.int64)
+                digits = (ids[:, None] // (10 ** np.arange(10, -1, -1, dtype=np.int64))[None, :] % 10 + 48).astype(np.uint8)
+                a["name"] = np.concatenate([digits, np.zeros((m, 1), np.uint8)], axis=1).view("S12")[:, 0]
+                a["cigar"] = (read_len << 4) | 0
+                nib = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, (m, read_len + (read_len & 1)), dtype=np.uint8)]
+                a["seq"] = (nib[:, 0::2] << 4) | nib[:, 1::2]
+                a["qual"] = qual_lut[rng.integers(0, 256, (m, read_len), dtype=np.uint8)]
+                pend += a.tobytes()
+                flush()
+            total += len(pos)
+        flush(final=True)
+        f.write(_BGZF_EOF)
+    return total
