@@ -171,6 +171,27 @@ int tdt_bgzf_inflate(const uint8_t *comp, size_t len, uint8_t *out, size_t out_l
  * out_on_device != 0 (the record decode and the histogram kernels then read it in place). */
 int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t len, uint8_t *out, size_t out_len, int out_on_device);
 
+/* ---- BAM ingest on the device ------------------------------------------------------------------------ *
+ * The per-read attribute access of the reference's loops (`for read in samfile.fetch(until_eof=True)`,
+ * __main__.py:229-240, tiddit_signal.pyx:169-221) as one call per batch of BGZF blocks: inflate, find the records,
+ * decode the packed arrays — all in HBM.  n_ref = number of @SQ contigs (record sanity check).
+ * tdt_ingest_push: `comp` = `len` bytes of WHOLE BGZF blocks (host memory, see tdt_bgzf_scan); `skip` = inflated bytes
+ * in front of the first record (the BAM header; first call only).  The incomplete record at the end of the batch is
+ * kept and prepended to the next call.  Returns TDT_E_UNSUPPORTED (state unchanged only in the sense that the object
+ * must then be discarded) when the record chain cannot be confirmed — decode that file with tdt_bgzf_inflate +
+ * tdt_bam_decode instead.  tdt_ingest_arrays: device pointers, valid until the next push, in tdt_bam_decode's
+ * output order (tid, pos, end, mapq, flag, mate_tid, mate_pos, tlen, l_seq, cigar_first, cigar_last, rec_off, sa_off)
+ * followed by the batch's raw record bytes (rec_off / sa_off index into them).  tdt_ingest_edges: record indices
+ * where the contig id changes.  tdt_ingest_carry: bytes of the pending partial record (0 after a well-formed file). */
+typedef struct tdt_ingest tdt_ingest;
+int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out);
+int tdt_ingest_destroy(tdt_ingest *g);
+int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t *n_records);
+int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len);
+int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n);
+int tdt_ingest_carry(tdt_ingest *g, size_t *bytes);
+int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+
 /* ---- alignment-record decode (host) ---------------------------------------------------------- *
  * Replaces the per-read pysam attribute access that feeds the path (read.reference_start,
  * reference_end, mapq, flag, next_reference_id, next_reference_start, isize, cigartuples[0]/[-1],

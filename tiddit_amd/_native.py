@@ -64,6 +64,13 @@ SYMBOLS = {
     "tdt_bgzf_scan": (_i, [_P, _sz, _sz, _P, _P, _P]),
     "tdt_bgzf_inflate": (_i, [_P, _sz, _P, _sz, _i]),
     "tdt_bgzf_inflate_hbm": (_i, [_P, _P, _sz, _P, _sz, _i]),
+    "tdt_ingest_create": (_i, [_P, _i, _PP]),
+    "tdt_ingest_destroy": (_i, [_P]),
+    "tdt_ingest_push": (_i, [_P, _P, _sz, _sz, ctypes.POINTER(_sz)]),
+    "tdt_ingest_arrays": (_i, [_P, _PP, ctypes.POINTER(_sz)]),
+    "tdt_ingest_edges": (_i, [_P, _P, _sz, ctypes.POINTER(_sz)]),
+    "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz)]),
+    "tdt_copy_to_host": (_i, [_P, _P, _P, _sz]),
     "tdt_bam_decode": (_i, [_P, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)] + [_P] * 13),
 }
 

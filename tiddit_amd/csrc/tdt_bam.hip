@@ -9,7 +9,6 @@
 #include <thread>
 #include <vector>
 
-int tdt_host_thread_count();   // tdt_bgzf.hip
 
 static inline uint32_t rd_u32(const uint8_t *p) {
     uint32_t v;

@@ -53,3 +53,15 @@ static inline int tdt_ceil_log2_u64(uint64_t v) {
     while ((1ull << l) < v) l++;
     return l;
 }
+
+// ---- BGZF block table shared by the host scan (tdt_bgzf.hip), the device inflate (tdt_inflate.hip) and the ingest (tdt_ingest.hip)
+struct BzDesc {
+    unsigned long long in_off, out_off;   // payload offset in the compressed buffer, block offset in the output
+    unsigned in_len, isize, crc, pad;
+};
+int tdt_host_thread_count();
+int tdt_bz_hop(const uint8_t *p, size_t avail, size_t *bsize, size_t *pay_off, size_t *pay_len, uint32_t *isize);
+int tdt_bz_block_table(const uint8_t *comp, size_t len, std::vector<BzDesc> &blocks, size_t *produced);
+int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out, bool check_crc,
+                  unsigned *d_status, unsigned *d_summary);
+const char *tdt_bz_err_name(unsigned e);

@@ -32,72 +32,81 @@
 enum { BZ_OK = 0, BZ_E_BTYPE = 1, BZ_E_STORED = 2, BZ_E_TABLE = 3, BZ_E_SYMBOL = 4, BZ_E_DIST = 5, BZ_E_OVERRUN = 6, BZ_E_INPUT = 7,
        BZ_E_SIZE = 8, BZ_E_CRC = 9 };
 
-struct BzDesc {
-    unsigned long long in_off, out_off;   // payload offset in the compressed buffer, block offset in the output
-    unsigned in_len, isize, crc, pad;
-};
-
 typedef unsigned long long u64;
 
 __device__ __forceinline__ unsigned bz_rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+
+#ifdef BZ_STATS
+__device__ unsigned long long bz_stats[64];   // [0] literals [1] matches [2] match bytes [3] deflate blocks, [8+k] matches with dist < 2^k, [32+k] len < 2^k
+extern "C" int tdt_debug_bz_stats(unsigned long long *out, int reset) {
+    if (reset) {
+        unsigned long long z[64] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(bz_stats), z, sizeof z) == hipSuccess ? 0 : -2;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bz_stats), 64 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
 
 __constant__ unsigned char bz_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // Canonical Huffman tables for `n` code lengths in LDS.  lut: (symbol << 4 | length) indexed by the next `tb` stream bits
 // (0 = longer code or unused), sorted: symbols ordered by (length, symbol), meta: first code / count / offset per length.
-// Returns false when the lengths over-subscribe the code space.
+// Lane k carries the running state of code length k (counts, first code, output cursor), so nothing is unrolled into
+// registers.  Returns false when the lengths over-subscribe the code space.
 __device__ __forceinline__ bool bz_build(const unsigned char *lens, int n, int tb, unsigned short *lut, unsigned short *sorted,
                                          unsigned short *meta, int lane) {
     for (int i = lane; i < (1 << tb) / 2; i += 64) ((unsigned *)lut)[i] = 0;
-    unsigned cnt[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) cnt[k] = 0;
+    unsigned cntv = 0;                                           // lane k: number of codes of length k
+#pragma nounroll
     for (int c = 0; c < n; c += 64) {
         const int s = c + lane;
         const unsigned l = s < n ? lens[s] : 0;
-#pragma unroll
-        for (int k = 1; k < 16; k++) cnt[k] += (unsigned)__popcll(__ballot(l == (unsigned)k));
+#pragma nounroll
+        for (int k = 1; k < 16; k++) {
+            const unsigned m = (unsigned)__popcll(__ballot(l == (unsigned)k));
+            cntv += lane == k ? m : 0;
+        }
     }
     int left = 1;
     bool over = false;
-    unsigned first[16], off[16], run[16];
-    unsigned code = 0, o = 0;
-    first[0] = off[0] = run[0] = 0;
-#pragma unroll
+    unsigned code = 0, o = 0, prev = 0, firstv = 0, offv = 0;
+#pragma nounroll
     for (int k = 1; k < 16; k++) {
-        left <<= 1;
-        left -= (int)cnt[k];
+        const unsigned ck = (unsigned)__builtin_amdgcn_readlane((int)cntv, k);
+        left = (left << 1) - (int)ck;
         over = over || left < 0;
-        code = (code + cnt[k - 1]) << 1;
-        first[k] = code;
-        off[k] = run[k] = o;
-        o += cnt[k];
+        code = (code + prev) << 1;
+        firstv = lane == k ? code : firstv;
+        offv = lane == k ? o : offv;
+        o += ck;
+        prev = ck;
     }
     if (over) return false;
-#pragma unroll
-    for (int k = 1; k < 16; k++)
-        if (lane == k) {
-            meta[k] = (unsigned short)first[k];
-            meta[16 + k] = (unsigned short)cnt[k];
-            meta[32 + k] = (unsigned short)off[k];
-        }
+    if (lane < 16) {
+        meta[lane] = (unsigned short)firstv;
+        meta[16 + lane] = (unsigned short)cntv;
+        meta[32 + lane] = (unsigned short)offv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned runv = offv;                                        // lane k: next slot of `sorted` for length k
     const u64 below = (1ull << lane) - 1ull;
+#pragma nounroll
     for (int c = 0; c < n; c += 64) {
         const int s = c + lane;
         const unsigned l = s < n ? lens[s] : 0;
-        unsigned rank = 0, fc = 0;
-#pragma unroll
+        unsigned rank = 0;
+#pragma nounroll
         for (int k = 1; k < 16; k++) {
             const u64 m = __ballot(l == (unsigned)k);
-            if (l == (unsigned)k) {
-                rank = run[k] + (unsigned)__popcll(m & below);
-                fc = first[k] + (rank - off[k]);
-            }
-            run[k] += (unsigned)__popcll(m);
+            const unsigned rk = (unsigned)__builtin_amdgcn_readlane((int)runv, k);
+            rank = l == (unsigned)k ? rk + (unsigned)__popcll(m & below) : rank;
+            runv += lane == k ? (unsigned)__popcll(m) : 0;
         }
         if (l) {
             sorted[rank] = (unsigned short)s;
             if ((int)l <= tb) {
+                const unsigned fc = (unsigned)meta[l] + (rank - (unsigned)meta[32 + l]);
                 const unsigned rev = __brev(fc) >> (32 - l);
                 const unsigned short e = (unsigned short)((s << 4) | l);
                 for (unsigned k = rev; k < (1u << tb); k += 1u << l) lut[k] = e;
@@ -143,8 +152,8 @@ __global__ __launch_bounds__(64 * BZ_WAVES) void bgzf_inflate(const unsigned cha
     const unsigned *const base = (const unsigned *)(comp + (D.in_off & ~3ull));
     const unsigned lead = (unsigned)(D.in_off & 3ull);          // bytes of the first dword that precede the payload
     const unsigned in_dwords = (lead + in_len + 3) / 4;
-    unsigned wi = 0;                                           // window held in w0
-    unsigned w0 = base[lane], w1 = base[64 + lane];
+    unsigned wi = 0;                                           // current window; even windows live in wa, odd ones in wb
+    unsigned wa = base[lane], wb = base[64 + lane];
     unsigned di = 0;                                           // next dword to enter the bit buffer
     u64 bb = 0;
     unsigned bc = 0;
@@ -155,13 +164,17 @@ __global__ __launch_bounds__(64 * BZ_WAVES) void bgzf_inflate(const unsigned cha
 #define BZ_FETCH(dst_)                                                                   \
     do {                                                                                 \
         const unsigned win_ = di >> 6;                                                   \
-        if (win_ != wi) {                                                                \
-            if (win_ == wi + 1) w0 = w1;                                                 \
-            else w0 = base[(size_t)win_ * 64 + lane];                                    \
-            w1 = base[(size_t)(win_ + 1) * 64 + lane];                                   \
+        if (win_ != wi) {                   /* sequential: win_ was prefetched; fetch win_+1 into the register it vacates */ \
+            if (di > in_dwords + 2) err = BZ_E_INPUT;   /* sticky; decoding runs dry against ISIZE, nothing more is loaded */ \
+            else if (win_ & 1) wa = base[(size_t)(win_ + 1) * 64 + lane];                \
+            else wb = base[(size_t)(win_ + 1) * 64 + lane];                              \
             wi = win_;                                                                   \
         }                                                                                \
-        dst_ = (unsigned)__builtin_amdgcn_readlane((int)w0, (int)(di & 63));             \
+        {                                                                                \
+            const unsigned a_ = (unsigned)__builtin_amdgcn_readlane((int)wa, (int)(di & 63)); \
+            const unsigned b_ = (unsigned)__builtin_amdgcn_readlane((int)wb, (int)(di & 63)); \
+            dst_ = (win_ & 1) ? b_ : a_;                                                 \
+        }                                                                                \
         di++;                                                                            \
     } while (0)
 #define BZ_REFILL()                                                                      \
@@ -193,10 +206,6 @@ __global__ __launch_bounds__(64 * BZ_WAVES) void bgzf_inflate(const unsigned cha
         last = bb & 1;
         const unsigned btype = (unsigned)(bb >> 1) & 3;
         BZ_TAKE(3);
-        if (di > in_dwords + 2) {
-            err = BZ_E_INPUT;
-            break;
-        }
         if (btype == 0) {  // stored: byte-align, LEN, NLEN, raw bytes
             BZ_TAKE(bc & 7);
             BZ_REFILL();
@@ -219,7 +228,12 @@ __global__ __launch_bounds__(64 * BZ_WAVES) void bgzf_inflate(const unsigned cha
             di = np >> 2;
             bb = 0;
             bc = 0;
-            wi = 0xffffffffu - 1;                               // force a window reload
+            wi = di >> 6;                                       // reload both windows at the new position
+            {
+                const unsigned ea = (wi & 1) ? wi + 1 : wi, eb = (wi & 1) ? wi : wi + 1;
+                wa = base[(size_t)ea * 64 + lane];
+                wb = base[(size_t)eb * 64 + lane];
+            }
             BZ_REFILL();
             BZ_TAKE(8 * (np & 3));
             continue;
@@ -341,6 +355,9 @@ __global__ __launch_bounds__(64 * BZ_WAVES) void bgzf_inflate(const unsigned cha
             BZ_TAKE(e & 15);
             const unsigned sym = e >> 4;
             if (sym < 256) {
+#ifdef BZ_STATS
+                if (lane == 0) atomicAdd(&bz_stats[0], 1ull);
+#endif
                 litv = (unsigned)lane == nlit ? sym : litv;
                 nlit++;
                 if (nlit == 64) {
@@ -390,6 +407,14 @@ __global__ __launch_bounds__(64 * BZ_WAVES) void bgzf_inflate(const unsigned cha
                 dist = 1 + ((2 + (dc & 1)) << eb) + ((unsigned)bb & ((1u << eb) - 1));
                 BZ_TAKE(eb);
             }
+#ifdef BZ_STATS
+            if (lane == 0) {
+                atomicAdd(&bz_stats[1], 1ull);
+                atomicAdd(&bz_stats[2], (unsigned long long)len);
+                atomicAdd(&bz_stats[8 + (32 - __clz(dist))], 1ull);
+                atomicAdd(&bz_stats[32 + (32 - __clz(len))], 1ull);
+            }
+#endif
             BZ_FLUSH_LITS();
             if (dist > op) {
                 err = BZ_E_DIST;
@@ -409,12 +434,7 @@ __global__ __launch_bounds__(64 * BZ_WAVES) void bgzf_inflate(const unsigned cha
                 for (unsigned i = lane; i < len; i += 64) dst[op + i] = src[i % dist];
             }
             op += len;
-            if (di > in_dwords + 2) {
-                err = BZ_E_INPUT;
-                break;
-            }
         }
-        if (di > in_dwords + 2 && err == BZ_OK) err = BZ_E_INPUT;
     }
     if (err == BZ_OK) {
         BZ_FLUSH_LITS();
@@ -498,7 +518,7 @@ __global__ void bgzf_status_reduce(const unsigned *__restrict__ status, int nblo
     }
 }
 
-static const char *bz_err_name(unsigned e) {
+const char *tdt_bz_err_name(unsigned e) {
     static const char *names[] = {"ok", "reserved block type", "stored-block length check", "invalid Huffman table", "invalid literal/length code",
                                   "invalid distance", "output exceeds ISIZE", "input exhausted", "output shorter than ISIZE", "CRC32 mismatch"};
     return e < 10 ? names[e] : "unknown";
@@ -506,7 +526,7 @@ static const char *bz_err_name(unsigned e) {
 
 // Device-resident form: d_comp holds `comp_len` bytes of whole BGZF blocks followed by >= 1024 readable bytes of padding,
 // d_blocks the block table; inflates into d_out and verifies CRC32.  Leaves the per-block status in scratch.
-static int bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out, bool check_crc,
+int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out, bool check_crc,
                      unsigned *d_status, unsigned *d_summary) {
     hipStream_t st = ctx->stream;
     TDT_HIP(hipMemsetAsync(d_summary, 0xff, 4, st));
@@ -523,9 +543,8 @@ static int bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_
     return TDT_OK;
 }
 
-int tdt_bz_hop(const uint8_t *p, size_t avail, size_t *bsize, size_t *pay_off, size_t *pay_len, uint32_t *isize);   // tdt_bgzf.hip
 
-static int tdt_bgzf_block_table(const uint8_t *comp, size_t len, std::vector<BzDesc> &blocks, size_t *produced) {
+int tdt_bz_block_table(const uint8_t *comp, size_t len, std::vector<BzDesc> &blocks, size_t *produced) {
     size_t o = 0, uo = 0;
     while (o < len) {
         size_t bs, po, pl;
@@ -550,7 +569,7 @@ extern "C" int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t le
     }
     std::vector<BzDesc> blocks;
     size_t produced = 0;
-    int rc = tdt_bgzf_block_table(comp, len, blocks, &produced);
+    int rc = tdt_bz_block_table(comp, len, blocks, &produced);
     if (rc) return rc;
     if (produced != out_len) {
         tdt_set_error("tdt_bgzf_inflate_hbm: blocks inflate to %zu bytes, caller gave %zu", produced, out_len);
@@ -578,7 +597,7 @@ extern "C" int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t le
     TDT_HIP(hipMemcpyAsync(d_comp, comp, len, hipMemcpyHostToDevice, st));
     TDT_HIP(hipMemsetAsync(d_comp + len, 0, comp_pad - len, st));
     TDT_HIP(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
-    rc = bz_launch(ctx, d_comp, d_blocks, nb, d_out, true, d_status, d_summary);
+    rc = tdt_bz_launch(ctx, d_comp, d_blocks, nb, d_out, true, d_status, d_summary);
     if (rc) return rc;
     unsigned summary[2] = {0, 0};
     TDT_HIP(hipMemcpyAsync(summary, d_summary, 8, hipMemcpyDeviceToHost, st));
@@ -587,7 +606,7 @@ extern "C" int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t le
     if (summary[1]) {
         unsigned code = 0;
         TDT_HIP(hipMemcpy(&code, d_status + summary[0], 4, hipMemcpyDeviceToHost));
-        tdt_set_error("tdt_bgzf_inflate_hbm: %u of %zu blocks failed; first is block %u: %s", summary[1], nb, summary[0], bz_err_name(code));
+        tdt_set_error("tdt_bgzf_inflate_hbm: %u of %zu blocks failed; first is block %u: %s", summary[1], nb, summary[0], tdt_bz_err_name(code));
         return TDT_E_ARG;
     }
     return TDT_OK;

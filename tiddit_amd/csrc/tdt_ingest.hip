@@ -1,0 +1,449 @@
+// BAM ingest on the MI355X: compressed BGZF blocks in, packed per-read arrays out — everything between the file and
+// the histogram / signal kernels stays in HBM.
+//
+// The reference iterates `samfile.fetch(until_eof=True)` and reads one attribute at a time (__main__.py:229-240,
+// tiddit_signal.pyx:169-221); csrc/tdt_bam.hip does that walk in host C.  Here, per batch of blocks:
+//   1. bgzf_inflate / bgzf_crc32 (tdt_inflate.hip) inflate the blocks behind the carried partial record;
+//   2. bam_find_records: the block_size chain is a serial pointer chase, so the stream is cut into 16 KiB segments and
+//      ONE LANE per segment looks for the first offset that passes the record sanity checks and whose chain runs
+//      cleanly to the end of the segment (what BAM split guessers do), recording first / exit / count;
+//   3. the host walks the segment table from the known first record: the chain is accepted only if every segment's
+//      guess equals the exit of its predecessor — then it is exactly the sequential decode, not a heuristic.  Any
+//      disagreement reports TDT_E_UNSUPPORTED and the caller decodes that batch with the host path;
+//   4. bam_decode_fields: one lane per accepted segment re-walks its records and writes the same thirteen arrays as
+//      tdt_bam_decode (bam_endpos for `end`, the SA:Z offset, first/last CIGAR op, ...).
+#include "tdt_common.h"
+
+#include <algorithm>
+
+#define ING_SEG 16384
+#define ING_NONE 0xffffffffu
+
+__device__ __forceinline__ unsigned ld_u32(const unsigned char *p) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ unsigned ld_u16(const unsigned char *p) { return (unsigned)p[0] | ((unsigned)p[1] << 8); }
+
+// Sanity of the record that would start at p.  0 = complete and plausible (bs set), 1 = runs past the end of the batch,
+// 2 = not a record.
+__device__ __forceinline__ int rec_check(const unsigned char *buf, long long p, long long T, int n_ref, unsigned *bs_out) {
+    if (p + 4 > T) return 1;
+    const unsigned bs = ld_u32(buf + p);
+    if (bs < 32 || bs > (1u << 28)) return 2;
+    if (p + 36 > T) return 1;
+    const unsigned char *r = buf + p + 4;
+    const int tid = (int)ld_u32(r), pos = (int)ld_u32(r + 4), lseq = (int)ld_u32(r + 16), mtid = (int)ld_u32(r + 20), mpos = (int)ld_u32(r + 24);
+    const unsigned l_name = r[8], n_cig = ld_u16(r + 12);
+    if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1 || lseq < 0 || l_name == 0) return 2;
+    const unsigned long long var = 32ull + l_name + 4ull * n_cig + ((unsigned long long)lseq + 1) / 2 + (unsigned long long)lseq;
+    if (var > bs) return 2;
+    if (p + 36 + (long long)l_name <= T) {                      // read name: [!-~]* NUL  (SAM spec 1.4)
+        if (r[32 + l_name - 1] != 0) return 2;
+        for (unsigned k = 0; k + 1 < l_name; k++) {
+            const unsigned char ch = r[32 + k];
+            if (ch < 33 || ch > 126) return 2;
+        }
+    }
+    if (p + 4 + (long long)bs > T) return 1;
+    if (n_cig && lseq) {                                       // query-consuming CIGAR ops spell out l_seq
+        const unsigned char *cig = r + 32 + l_name;
+        unsigned long long qlen = 0;
+        for (unsigned k = 0; k < n_cig; k++) {
+            const unsigned cw = ld_u32(cig + 4 * k), op = cw & 0xf;
+            if (op > 8) return 2;
+            if (op == 0 || op == 1 || op == 4 || op == 7 || op == 8) qlen += cw >> 4;   // M I S = X
+        }
+        if (qlen != (unsigned long long)lseq) return 2;
+    }
+    *bs_out = bs;
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__restrict__ buf, long long T, long long s0, int n_ref, int nseg,
+                                                       unsigned *__restrict__ first, unsigned *__restrict__ exitp,
+                                                       unsigned *__restrict__ count) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nseg) return;
+    const long long lo = (long long)g * ING_SEG;
+    const long long hi = lo + ING_SEG < T ? lo + ING_SEG : T;
+    unsigned f = ING_NONE, e = 0, c = 0;
+    bool weak = false;                                          // a candidate that is only "a record running past the batch end"
+    long long p = lo;
+    if (s0 >= hi) p = hi;                                       // segment lies inside the header
+    else if (s0 > lo) p = s0;
+    const bool forced = s0 >= lo && s0 < hi;                    // the first record's offset is known, not guessed
+    for (; p < hi; p++) {
+        unsigned bs;
+        int rc = rec_check(buf, p, T, n_ref, &bs);
+        if (rc == 2 && !forced) continue;
+        long long q = p;
+        unsigned n = 0;
+        while (rc == 0 && q < hi) {
+            q += 4 + (long long)bs;
+            n++;
+            if (q >= T) break;                                  // the batch ends exactly on a record boundary
+            rc = rec_check(buf, q, T, n_ref, &bs);              // also where the chain LANDS beyond the segment: must look like a record
+        }
+        if (rc != 2 || forced) {                                // chain ran to the segment end (or into the batch tail)
+            if (n == 0 && !forced) {                            // nothing complete: remember the first such offset, keep looking
+                if (!weak) {
+                    weak = true;
+                    f = e = (unsigned)p;
+                }
+                continue;
+            }
+            f = (unsigned)p;
+            e = (unsigned)q;
+            c = n;
+            if (forced && rc == 2) f = ING_NONE - 1;            // corrupt record on the true chain: never matches the walk
+            break;
+        }
+    }
+    first[g] = f;
+    exitp[g] = e;
+    count[g] = c;
+}
+
+struct IngestOut {
+    int32_t *tid, *pos, *end, *mate_tid, *mate_pos, *tlen, *l_seq;
+    uint8_t *mapq;
+    uint16_t *flag;
+    uint32_t *cigar_first, *cigar_last;
+    uint64_t *rec_off;
+    int64_t *sa_off;
+};
+
+__device__ __forceinline__ long long aux_value_size(unsigned char t, const unsigned char *p, const unsigned char *end) {
+    switch (t) {
+        case 'A': case 'c': case 'C': return 1;
+        case 's': case 'S': return 2;
+        case 'i': case 'I': case 'f': return 4;
+        case 'd': return 8;
+        case 'Z': case 'H': {
+            const unsigned char *q = p;
+            while (q < end && *q) q++;
+            return q < end ? (long long)(q - p) + 1 : -1;
+        }
+        case 'B': {
+            if (p + 5 > end) return -1;
+            const unsigned char st = p[0];
+            const long long es = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : -1;
+            return es < 0 ? -1 : 5 + es * (long long)ld_u32(p + 1);
+        }
+        default: return -1;
+    }
+}
+
+__global__ __launch_bounds__(64) void bam_decode_fields(const unsigned char *__restrict__ buf, long long T, int nseg,
+                                                        const unsigned *__restrict__ first, const unsigned *__restrict__ base,
+                                                        const unsigned *__restrict__ count, IngestOut O) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= nseg) return;
+    const unsigned n = count[g];
+    if (base[g] == ING_NONE || n == 0) return;
+    long long p = first[g];
+    size_t i = base[g];
+    for (unsigned k = 0; k < n; k++, i++) {
+        const unsigned bs = ld_u32(buf + p);
+        const unsigned char *r = buf + p + 4;
+        const int pos = (int)ld_u32(r + 4), lseq = (int)ld_u32(r + 16);
+        const unsigned l_name = r[8], n_cig = ld_u16(r + 12), fl = ld_u16(r + 14);
+        const unsigned char *cig = r + 32 + l_name;
+        long long rlen = 0;
+        for (unsigned j = 0; j < n_cig; j++) {
+            const unsigned cw = ld_u32(cig + 4 * j), op = cw & 0xf;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cw >> 4;   // M D N = X consume the reference
+        }
+        if ((fl & 0x4) || rlen == 0) rlen = 1;                                          // bam_endpos
+        O.tid[i] = (int)ld_u32(r);
+        O.pos[i] = pos;
+        O.end[i] = (int)(pos + rlen);
+        O.mapq[i] = r[9];
+        O.flag[i] = (uint16_t)fl;
+        O.mate_tid[i] = (int)ld_u32(r + 20);
+        O.mate_pos[i] = (int)ld_u32(r + 24);
+        O.tlen[i] = (int)ld_u32(r + 28);
+        O.l_seq[i] = lseq;
+        O.cigar_first[i] = n_cig ? ld_u32(cig) : 0xffffffffu;
+        O.cigar_last[i] = n_cig ? ld_u32(cig + 4 * (n_cig - 1)) : 0xffffffffu;
+        O.rec_off[i] = (uint64_t)p;
+        long long found = -1;                                                           // SA:Z value offset (tiddit_signal.pyx:199)
+        const unsigned char *a = r + 32 + l_name + 4 * n_cig + ((size_t)lseq + 1) / 2 + (size_t)lseq, *aend = r + bs;
+        while (a + 3 <= aend) {
+            const unsigned char t = a[2];
+            const long long sz = aux_value_size(t, a + 3, aend);
+            if (sz < 0 || a + 3 + sz > aend) break;
+            if (a[0] == 'S' && a[1] == 'A' && t == 'Z') {
+                found = (long long)((a + 3) - buf);
+                break;
+            }
+            a += 3 + sz;
+        }
+        O.sa_off[i] = found;
+        p += 4 + (long long)bs;
+    }
+}
+
+// positions where tid changes (i = 0 included): the per-contig runs of a coordinate-sorted batch
+__global__ void bam_tid_edges(const int32_t *__restrict__ tid, size_t n, unsigned *__restrict__ edges, unsigned cap, unsigned *__restrict__ n_edges) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || tid[i] != tid[i - 1]) {
+        const unsigned k = atomicAdd(n_edges, 1u);
+        if (k < cap) edges[k] = (unsigned)i;
+    }
+}
+
+struct tdt_ingest {
+    tdt_ctx *ctx = nullptr;
+    int n_ref = 0;
+    tdt_buf comp, table, out, seg, soa;            // device buffers (grow only)
+    tdt_buf pin;                                   // pinned staging for the segment table / edges
+    size_t carry = 0, tail_off = 0;                // bytes of the partial record at out[tail_off..), moved to the front by the next push
+    size_t out_len = 0;                            // carry + inflated bytes of the current batch
+    size_t n_records = 0, rec_cap = 0;
+    IngestOut O{};
+    std::vector<unsigned> edges;
+};
+
+static int ing_grow(tdt_ingest *g, tdt_buf &b, size_t bytes, bool keep = false) {
+    if (b.cap >= bytes) return TDT_OK;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    void *p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) {
+        tdt_set_error("tdt_ingest: device allocation of %zu bytes failed", cap);
+        return TDT_E_NOMEM;
+    }
+    if (keep && b.p) {
+        if (hipMemcpyAsync(p, b.p, b.cap, hipMemcpyDeviceToDevice, g->ctx->stream) != hipSuccess || hipStreamSynchronize(g->ctx->stream) != hipSuccess) {
+            (void)hipFree(p);
+            tdt_set_error("tdt_ingest: device copy failed");
+            return TDT_E_HIP;
+        }
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = p;
+    b.cap = cap;
+    return TDT_OK;
+}
+
+extern "C" int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out) {
+    if (!ctx || !out || n_ref < 0) {
+        tdt_set_error("tdt_ingest_create: bad argument");
+        return TDT_E_ARG;
+    }
+    tdt_ingest *g = new tdt_ingest();
+    g->ctx = ctx;
+    g->n_ref = n_ref;
+    *out = g;
+    return TDT_OK;
+}
+
+extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
+    if (!g) return TDT_OK;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    for (tdt_buf *b : {&g->comp, &g->table, &g->out, &g->seg, &g->soa})
+        if (b->p) (void)hipFree(b->p);
+    if (g->pin.p) (void)hipHostFree(g->pin.p);
+    delete g;
+    return TDT_OK;
+}
+
+extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t *n_records) {
+    if (!g || (!comp && len) || !n_records) {
+        tdt_set_error("tdt_ingest_push: bad argument");
+        return TDT_E_ARG;
+    }
+    tdt_ctx *ctx = g->ctx;
+    TDT_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<BzDesc> blocks;
+    size_t produced = 0;
+    int rc = tdt_bz_block_table(comp, len, blocks, &produced);
+    if (rc) return rc;
+    const size_t carry = g->carry;
+    const size_t T = carry + produced;
+    if (T >= 0xfffffff0ull) {
+        tdt_set_error("tdt_ingest_push: batch inflates to %zu bytes; feed at most 3 GiB of records per call", T);
+        return TDT_E_RANGE;
+    }
+    for (auto &b : blocks) b.out_off += carry;
+    if (carry && g->tail_off) TDT_HIP(hipMemcpyAsync(g->out.p, (char *)g->out.p + g->tail_off, carry, hipMemcpyDeviceToDevice, st));
+    g->tail_off = 0;
+    rc = ing_grow(g, g->out, T + 256, true);                      // keeps the carried bytes at the front
+    if (rc) return rc;
+    unsigned char *d_out = (unsigned char *)g->out.p;
+    const size_t nb = blocks.size();
+    if (nb) {
+        const size_t comp_pad = (len + 4096 + 255) & ~(size_t)255;
+        rc = ing_grow(g, g->comp, comp_pad);
+        if (rc) return rc;
+        const size_t tab = (nb * sizeof(BzDesc) + 255) & ~(size_t)255, stb = (nb * 4 + 255) & ~(size_t)255;
+        rc = ing_grow(g, g->table, tab + stb + 256);
+        if (rc) return rc;
+        unsigned char *d_comp = (unsigned char *)g->comp.p;
+        BzDesc *d_blocks = (BzDesc *)g->table.p;
+        unsigned *d_status = (unsigned *)((char *)g->table.p + tab), *d_summary = (unsigned *)((char *)d_status + stb);
+        TDT_HIP(hipMemcpyAsync(d_comp, comp, len, hipMemcpyHostToDevice, st));
+        TDT_HIP(hipMemsetAsync(d_comp + len, 0, comp_pad - len, st));
+        TDT_HIP(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
+        rc = tdt_bz_launch(ctx, d_comp, d_blocks, nb, d_out, true, d_status, d_summary);
+        if (rc) return rc;
+        unsigned summary[2] = {0, 0};
+        TDT_HIP(hipMemcpyAsync(summary, d_summary, 8, hipMemcpyDeviceToHost, st));
+        TDT_HIP(hipStreamSynchronize(st));
+        if (summary[1]) {
+            unsigned code = 0;
+            TDT_HIP(hipMemcpy(&code, d_status + summary[0], 4, hipMemcpyDeviceToHost));
+            tdt_set_error("tdt_ingest_push: %u of %zu BGZF blocks failed; first is block %u: %s", summary[1], nb, summary[0], tdt_bz_err_name(code));
+            return TDT_E_ARG;
+        }
+    }
+    g->out_len = T;
+    g->n_records = 0;
+    g->edges.clear();
+    *n_records = 0;
+    if (skip > T) {
+        tdt_set_error("tdt_ingest_push: skip (%zu) exceeds the inflated bytes (%zu)", skip, T);
+        return TDT_E_ARG;
+    }
+    if (T == skip) {
+        g->carry = 0;
+        g->tail_off = 0;
+        return TDT_OK;
+    }
+    // ---- find the records: per-segment guesses on the device, chain check on the host
+    const int nseg = (int)((T + ING_SEG - 1) / ING_SEG);
+    const size_t segb = ((size_t)nseg * 4 + 255) & ~(size_t)255;
+    rc = ing_grow(g, g->seg, 4 * segb);
+    if (rc) return rc;
+    unsigned *d_first = (unsigned *)g->seg.p, *d_exit = (unsigned *)((char *)g->seg.p + segb), *d_count = (unsigned *)((char *)g->seg.p + 2 * segb),
+             *d_base = (unsigned *)((char *)g->seg.p + 3 * segb);
+    if (g->pin.cap < 4 * segb + 65536) {
+        if (g->pin.p) (void)hipHostFree(g->pin.p);
+        g->pin.cap = 4 * segb + 65536 + segb;
+        TDT_HIP(hipHostMalloc(&g->pin.p, g->pin.cap));
+    }
+    unsigned *h_first = (unsigned *)g->pin.p, *h_exit = (unsigned *)((char *)g->pin.p + segb), *h_count = (unsigned *)((char *)g->pin.p + 2 * segb),
+             *h_base = (unsigned *)((char *)g->pin.p + 3 * segb);
+    hipLaunchKernelGGL(bam_find_records, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, (long long)skip, g->n_ref, nseg, d_first,
+                       d_exit, d_count);
+    TDT_CHECK_LAUNCH();
+    TDT_HIP(hipMemcpyAsync(h_first, d_first, 3 * segb, hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipStreamSynchronize(st));
+    for (int s = 0; s < nseg; s++) h_base[s] = ING_NONE;
+    size_t cur = skip, n = 0;
+    while (cur < T) {
+        const int s = (int)(cur / ING_SEG);
+        if (h_first[s] != (unsigned)cur) {
+            tdt_set_error("tdt_ingest_push: record chain could not be confirmed at offset %zu (segment %d guessed %u); decode this batch on the host",
+                          cur, s, h_first[s]);
+            return TDT_E_UNSUPPORTED;
+        }
+        h_base[s] = (unsigned)n;
+        n += h_count[s];
+        if (h_exit[s] == (unsigned)cur) break;                    // the record at `cur` is incomplete: it is the tail
+        cur = h_exit[s];
+        if (cur < (size_t)(s + 1) * ING_SEG && cur < T) break;     // chain stopped inside the segment: tail reached
+    }
+    const size_t tail = cur < T ? cur : T;
+    // ---- decode the fields
+    if (n) {
+        const size_t N = n;
+        const size_t a4 = (N * 4 + 255) & ~(size_t)255, a2 = (N * 2 + 255) & ~(size_t)255, a1 = (N + 255) & ~(size_t)255, a8 = (N * 8 + 255) & ~(size_t)255;
+        rc = ing_grow(g, g->soa, 9 * a4 + a2 + a1 + 2 * a8 + 4096);
+        if (rc) return rc;
+        char *p = (char *)g->soa.p;
+        IngestOut &O = g->O;
+        O.rec_off = (uint64_t *)p; p += a8;
+        O.sa_off = (int64_t *)p; p += a8;
+        O.tid = (int32_t *)p; p += a4;
+        O.pos = (int32_t *)p; p += a4;
+        O.end = (int32_t *)p; p += a4;
+        O.mate_tid = (int32_t *)p; p += a4;
+        O.mate_pos = (int32_t *)p; p += a4;
+        O.tlen = (int32_t *)p; p += a4;
+        O.l_seq = (int32_t *)p; p += a4;
+        O.cigar_first = (uint32_t *)p; p += a4;
+        O.cigar_last = (uint32_t *)p; p += a4;
+        O.flag = (uint16_t *)p; p += a2;
+        O.mapq = (uint8_t *)p; p += a1;
+        unsigned *d_edges = (unsigned *)p;                         // 1023 edges + counter
+        TDT_HIP(hipMemcpyAsync(d_base, h_base, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(bam_decode_fields, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, nseg, d_first, d_base, d_count, O);
+        TDT_CHECK_LAUNCH();
+        TDT_HIP(hipMemsetAsync(d_edges + 1023, 0, 4, st));
+        hipLaunchKernelGGL(bam_tid_edges, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, O.tid, N, d_edges, 1023u, d_edges + 1023);
+        TDT_CHECK_LAUNCH();
+        unsigned *h_edges = (unsigned *)((char *)g->pin.p + 4 * segb);
+        TDT_HIP(hipMemcpyAsync(h_edges, d_edges, 4096, hipMemcpyDeviceToHost, st));
+        TDT_HIP(hipStreamSynchronize(st));
+        const unsigned ne = h_edges[1023];
+        if (ne > 1023) {
+            tdt_set_error("tdt_ingest_push: more than 1023 contig changes in one batch (unsorted input?)");
+            return TDT_E_UNSUPPORTED;
+        }
+        g->edges.assign(h_edges, h_edges + ne);
+        std::sort(g->edges.begin(), g->edges.end());
+    }
+    g->n_records = n;
+    *n_records = n;
+    // ---- the partial record stays where it is (the batch's raw bytes remain readable); the next push moves it to the front
+    const size_t left = T - tail;
+    if (left > tail && left) {
+        tdt_set_error("tdt_ingest_push: a single record (%zu bytes) is larger than the rest of the batch; feed more blocks per call", left);
+        return TDT_E_UNSUPPORTED;
+    }
+    g->tail_off = tail;
+    g->carry = left;
+    return TDT_OK;
+}
+
+// device pointers of the current batch, in the order of tdt_bam_decode's output arguments, then the raw record bytes
+extern "C" int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len) {
+    if (!g || !out14) {
+        tdt_set_error("tdt_ingest_arrays: bad argument");
+        return TDT_E_ARG;
+    }
+    const IngestOut &O = g->O;
+    const void *p[14] = {O.tid, O.pos, O.end, O.mapq, O.flag, O.mate_tid, O.mate_pos, O.tlen, O.l_seq, O.cigar_first, O.cigar_last, O.rec_off,
+                         O.sa_off, g->out.p};
+    for (int i = 0; i < 14; i++) out14[i] = g->n_records || i == 13 ? p[i] : nullptr;
+    if (raw_len) *raw_len = g->out_len;
+    return TDT_OK;
+}
+
+// record indices at which the contig id changes (ascending, index 0 included)
+extern "C" int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n) {
+    if (!g || !n || (cap && !edges)) {
+        tdt_set_error("tdt_ingest_edges: bad argument");
+        return TDT_E_ARG;
+    }
+    *n = g->edges.size();
+    for (size_t i = 0; i < g->edges.size() && i < cap; i++) edges[i] = g->edges[i];
+    return TDT_OK;
+}
+
+extern "C" int tdt_ingest_carry(tdt_ingest *g, size_t *bytes) {
+    if (!g || !bytes) {
+        tdt_set_error("tdt_ingest_carry: bad argument");
+        return TDT_E_ARG;
+    }
+    *bytes = g->carry;
+    return TDT_OK;
+}
+
+extern "C" int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !d_src))) {
+        tdt_set_error("tdt_copy_to_host: bad argument");
+        return TDT_E_ARG;
+    }
+    if (!bytes) return TDT_OK;
+    TDT_HIP(hipSetDevice(ctx->device));
+    TDT_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TDT_HIP(hipStreamSynchronize(ctx->stream));
+    return TDT_OK;
+}

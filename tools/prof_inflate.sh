@@ -1,0 +1,20 @@
+#!/bin/bash
+# kernel-trace stats (+ optional PMC passes) of the device inflate: tools/prof_inflate.sh <tag> [Mb] [level] [pmc]
+TAG=${1:-inf}; MB=${2:-16}; LV=${3:-1}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $R/tools/time_inflate_gpu.py $MB $LV --check > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/tools/time_inflate_gpu.py $MB $LV > $OUT/trace.log 2>&1
+if [ -n "$4" ]; then
+i=0
+for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -o p -- python $R/tools/time_inflate_gpu.py $MB $LV > $OUT/pmc$i.log 2>&1
+done
+fi
+cat $OUT/run.log | tail -5
+cat $(find $OUT/trace -name "*kernel_stats.csv" | head -1) | head -6
