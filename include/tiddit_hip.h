@@ -177,19 +177,20 @@ int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t len, uint8_t 
  * decode the packed arrays — all in HBM.  n_ref = number of @SQ contigs (record sanity check).
  * tdt_ingest_push: `comp` = `len` bytes of WHOLE BGZF blocks (host memory, see tdt_bgzf_scan); `skip` = inflated bytes
  * in front of the first record (the BAM header; first call only).  The incomplete record at the end of the batch is
- * kept and prepended to the next call.  Returns TDT_E_UNSUPPORTED (state unchanged only in the sense that the object
- * must then be discarded) when the record chain cannot be confirmed — decode that file with tdt_bgzf_inflate +
- * tdt_bam_decode instead.  tdt_ingest_arrays: device pointers, valid until the next push, in tdt_bam_decode's
+ * kept and prepended to the next call.  Records are located by parallel per-segment guesses that the host confirms
+ * against the block_size chain; a batch that cannot be confirmed is chased serially on the host instead (counted in
+ * tdt_ingest_carry's host_chases) — the result is the sequential decode either way.  tdt_ingest_arrays: device pointers, valid until the next push, in tdt_bam_decode's
  * output order (tid, pos, end, mapq, flag, mate_tid, mate_pos, tlen, l_seq, cigar_first, cigar_last, rec_off, sa_off)
  * followed by the batch's raw record bytes (rec_off / sa_off index into them).  tdt_ingest_edges: record indices
- * where the contig id changes.  tdt_ingest_carry: bytes of the pending partial record (0 after a well-formed file). */
+ * where the contig id changes (*n = (size_t)-1 when there are more than 1023, i.e. the input is not coordinate
+ * sorted).  tdt_ingest_carry: bytes of the pending partial record (0 after a well-formed file). */
 typedef struct tdt_ingest tdt_ingest;
 int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out);
 int tdt_ingest_destroy(tdt_ingest *g);
 int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t *n_records);
 int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len);
 int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n);
-int tdt_ingest_carry(tdt_ingest *g, size_t *bytes);
+int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 
 /* ---- alignment-record decode (host) ---------------------------------------------------------- *

@@ -67,16 +67,23 @@ def _cov_parser():
 
 def run_cov(args):
     from . import tiddit_coverage
-    from .bamio import BamReader
+    from .bamio import BamReader, DeviceBamReader
     if not os.path.isfile(args.bam):
         print("error,  could not find the bam file")
         quit()
-    reader = BamReader(args.bam)
+    host = os.environ.get("TIDDIT_HOST_INGEST") == "1"                 # default: inflate + decode on the device
+    reader = BamReader(args.bam) if host else DeviceBamReader(args.bam)
     bam_header = reader.header
     coverage_data, end_bin_size = tiddit_coverage.create_coverage(bam_header, args.z)
     hist = tiddit_coverage.CoverageHistogram(bam_header, args.z)
     import numpy
     for b in reader.batches():
+        if not host:
+            d = b.dev
+            items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in b.runs if t >= 0]
+            if items:
+                hist.push_device_multi(items, args.q)
+            continue
         tid = b.tid
         edges = numpy.flatnonzero(numpy.diff(tid)) + 1
         for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):

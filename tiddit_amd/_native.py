@@ -69,7 +69,7 @@ SYMBOLS = {
     "tdt_ingest_push": (_i, [_P, _P, _sz, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_arrays": (_i, [_P, _PP, ctypes.POINTER(_sz)]),
     "tdt_ingest_edges": (_i, [_P, _P, _sz, ctypes.POINTER(_sz)]),
-    "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz)]),
+    "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "tdt_copy_to_host": (_i, [_P, _P, _P, _sz]),
     "tdt_bam_decode": (_i, [_P, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)] + [_P] * 13),
 }

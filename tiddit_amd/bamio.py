@@ -237,6 +237,7 @@ class BamReader:
     def _take(self, n):
         if not self._need(n):
             raise ValueError("truncated BAM")
+        self.header_bytes = getattr(self, "header_bytes", 0) + n      # after _read_header: inflated bytes before record 0
         out = bytes(self._buf[:n])
         del self._buf[:n]
         return out
@@ -304,6 +305,156 @@ class BamReader:
                 yield b
 
     def close(self):
+        self._f.close()
+
+
+# ------------------------------------------------------------------------------------ device reader
+_FIELDS = (("tid", np.int32), ("pos", np.int32), ("end", np.int32), ("mapq", np.uint8), ("flag", np.uint16), ("mate_tid", np.int32),
+           ("mate_pos", np.int32), ("tlen", np.int32), ("l_seq", np.int32), ("cigar_first", np.uint32), ("cigar_last", np.uint32),
+           ("rec_off", np.uint64), ("sa_off", np.int64))
+
+
+class DeviceBatch:
+    """One ingest batch resident in HBM (csrc/tdt_ingest.hip).  ``dev[name]`` is the device pointer of a field array,
+    ``runs`` the per-contig record ranges ``[(tid, lo, hi)]``; reading a field attribute (``b.pos``, ``b.raw`` ...)
+    copies that array to the host once.  Valid until the reader produces the next batch."""
+
+    def __init__(self, reader, n, ptrs, raw_len, runs):
+        self._reader, self._n, self._raw_len, self.runs = reader, n, raw_len, runs
+        self.dev = {k: int(ptrs[i] or 0) for i, (k, _) in enumerate(_FIELDS)}
+        self.dev["raw"] = int(ptrs[13] or 0)
+        self._host = {}
+        self._live = True
+
+    def __len__(self):
+        return self._n
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name not in self.dev:
+            raise AttributeError(name)
+        if name not in self._host:
+            if not self._live:
+                raise RuntimeError("DeviceBatch used after the reader moved on to the next batch")
+            if name == "raw":
+                a = np.empty(self._raw_len, dtype=np.uint8)
+            else:
+                a = np.empty(self._n, dtype=dict(_FIELDS)[name])
+            ctx = self._reader.ctx
+            _native.check(ctx.lib.tdt_copy_to_host(ctx.handle, _native.ptr(a), self.dev[name], a.nbytes))
+            self._host[name] = a
+        return self._host[name]
+
+    def record(self, i):
+        return RecordView(self, i)
+
+
+class DeviceBamReader:
+    """BAM reader whose inflate, record finding and field decode run on the MI355X (``tdt_ingest_*``): the file's BGZF
+    blocks are read into pinned host memory by a helper thread, pushed as they are, and come back as :class:`DeviceBatch`.
+    Same ``header`` / ``references`` / ``lengths`` / ``batches()`` interface as :class:`BamReader`."""
+
+    def __init__(self, path, ctx=None, chunk=512 << 20):
+        host = BamReader(path, batch_bytes=1 << 20)                 # the header is parsed on the host
+        self.header, self.references, self.lengths, self.text = host.header, host.references, host.lengths, host.text
+        self._skip = host.header_bytes
+        host.close()
+        self.path, self.chunk = path, chunk
+        self.ctx = ctx or _native.default_context()
+        self._f = open(path, "rb", buffering=0)
+        h = ctypes.c_void_p()
+        _native.check(self.ctx.lib.tdt_ingest_create(self.ctx.handle, len(self.references), ctypes.byref(h)))
+        self._h = h
+        self.host_chases = 0
+
+    def _spans(self):
+        """(buffer, consumed) spans of whole BGZF blocks, read ahead by a helper thread into rotating pinned buffers"""
+        import queue
+        import threading
+        import torch
+        lib = self.ctx.lib
+        chunk = self.chunk
+        bufs = [torch.empty(chunk + (1 << 17), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(3)]
+        q = queue.Queue(maxsize=1)
+
+        def produce():
+            try:
+                k, carry = 0, np.zeros(0, dtype=np.uint8)
+                eof = False
+                while True:
+                    buf = bufs[k % 3]
+                    have = len(carry)
+                    buf[:have] = carry
+                    while not eof and have < chunk:
+                        got = self._f.readinto(memoryview(buf)[have:chunk + (1 << 16)])
+                        eof = not got
+                        have += got or 0
+                    if have == 0:
+                        break
+                    nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+                    _native.check(lib.tdt_bgzf_scan(_native.ptr(buf), have, 3 << 30, ctypes.byref(nb), ctypes.byref(consumed), ctypes.byref(produced)))
+                    if nb.value == 0:
+                        raise ValueError("truncated BGZF block at end of file" if eof else "BGZF block larger than the read window")
+                    carry = buf[consumed.value:have].copy()
+                    q.put((buf, consumed.value))
+                    k += 1
+                q.put(None)
+            except BaseException as e:
+                q.put(e)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+        th.join()
+
+    def batches(self):
+        lib, ctx = self.ctx.lib, self.ctx
+        prev = None
+        first = True
+        for buf, consumed in self._spans():
+            if prev is not None:
+                prev._live = False
+            n = ctypes.c_size_t(0)
+            _native.check(lib.tdt_ingest_push(self._h, _native.ptr(buf), consumed, self._skip if first else 0, ctypes.byref(n)))
+            first = False
+            if not n.value:
+                continue
+            ptrs = (ctypes.c_void_p * 14)()
+            raw_len = ctypes.c_size_t(0)
+            _native.check(lib.tdt_ingest_arrays(self._h, ptrs, ctypes.byref(raw_len)))
+            edges = np.empty(1024, dtype=np.uint32)
+            ne = ctypes.c_size_t(0)
+            _native.check(lib.tdt_ingest_edges(self._h, _native.ptr(edges), 1024, ctypes.byref(ne)))
+            b = DeviceBatch(self, n.value, ptrs, raw_len.value, None)
+            if ne.value == ctypes.c_size_t(-1).value:                   # not coordinate sorted: runs from the tid column
+                tid = b.tid
+                lo = np.concatenate([[0], np.flatnonzero(np.diff(tid)) + 1])
+            else:
+                lo = edges[:ne.value].astype(np.int64)
+            hi = np.concatenate([lo[1:], [n.value]])
+            tids = np.empty(len(lo), dtype=np.int32)
+            for j, l in enumerate(lo):                                   # one 4-byte read per run
+                t = np.empty(1, dtype=np.int32)
+                _native.check(lib.tdt_copy_to_host(ctx.handle, _native.ptr(t), b.dev["tid"] + 4 * int(l), 4))
+                tids[j] = t[0]
+            b.runs = [(int(t), int(l), int(h)) for t, l, h in zip(tids, lo, hi)]
+            prev = b
+            yield b
+        c, hc = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        _native.check(lib.tdt_ingest_carry(self._h, ctypes.byref(c), ctypes.byref(hc)))
+        self.host_chases = hc.value
+        if c.value:
+            raise ValueError("truncated BAM record at end of file")
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.tdt_ingest_destroy(self._h)
+            self._h = None
         self._f.close()
 
 

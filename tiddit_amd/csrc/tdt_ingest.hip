@@ -8,8 +8,8 @@
 //      ONE LANE per segment looks for the first offset that passes the record sanity checks and whose chain runs
 //      cleanly to the end of the segment (what BAM split guessers do), recording first / exit / count;
 //   3. the host walks the segment table from the known first record: the chain is accepted only if every segment's
-//      guess equals the exit of its predecessor — then it is exactly the sequential decode, not a heuristic.  Any
-//      disagreement reports TDT_E_UNSUPPORTED and the caller decodes that batch with the host path;
+//      guess equals the exit of its predecessor — then it is exactly the sequential decode, not a heuristic.  On any
+//      disagreement the batch is copied back once and the chain is chased serially on the host (still exact);
 //   4. bam_decode_fields: one lane per accepted segment re-walks its records and writes the same thirteen arrays as
 //      tdt_bam_decode (bam_endpos for `end`, the SA:Z offset, first/last CIGAR op, ...).
 #include "tdt_common.h"
@@ -27,7 +27,9 @@ __device__ __forceinline__ unsigned ld_u32(const unsigned char *p) {
 __device__ __forceinline__ unsigned ld_u16(const unsigned char *p) { return (unsigned)p[0] | ((unsigned)p[1] << 8); }
 
 // Sanity of the record that would start at p.  0 = complete and plausible (bs set), 1 = runs past the end of the batch,
-// 2 = not a record.
+// 2 = not a record.  DEEP adds the per-character name check and the CIGAR/l_seq identity (used on a guessed first record and
+// on the record the chain lands on; records in between are pinned by the chain itself).
+template <bool DEEP>
 __device__ __forceinline__ int rec_check(const unsigned char *buf, long long p, long long T, int n_ref, unsigned *bs_out) {
     if (p + 4 > T) return 1;
     const unsigned bs = ld_u32(buf + p);
@@ -41,13 +43,13 @@ __device__ __forceinline__ int rec_check(const unsigned char *buf, long long p, 
     if (var > bs) return 2;
     if (p + 36 + (long long)l_name <= T) {                      // read name: [!-~]* NUL  (SAM spec 1.4)
         if (r[32 + l_name - 1] != 0) return 2;
-        for (unsigned k = 0; k + 1 < l_name; k++) {
+        for (unsigned k = 0; DEEP && k + 1 < l_name; k++) {
             const unsigned char ch = r[32 + k];
             if (ch < 33 || ch > 126) return 2;
         }
     }
     if (p + 4 + (long long)bs > T) return 1;
-    if (n_cig && lseq) {                                       // query-consuming CIGAR ops spell out l_seq
+    if (DEEP && n_cig && lseq) {                               // query-consuming CIGAR ops spell out l_seq
         const unsigned char *cig = r + 32 + l_name;
         unsigned long long qlen = 0;
         for (unsigned k = 0; k < n_cig; k++) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__re
     const bool forced = s0 >= lo && s0 < hi;                    // the first record's offset is known, not guessed
     for (; p < hi; p++) {
         unsigned bs;
-        int rc = rec_check(buf, p, T, n_ref, &bs);
+        int rc = rec_check<true>(buf, p, T, n_ref, &bs);
         if (rc == 2 && !forced) continue;
         long long q = p;
         unsigned n = 0;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__re
             q += 4 + (long long)bs;
             n++;
             if (q >= T) break;                                  // the batch ends exactly on a record boundary
-            rc = rec_check(buf, q, T, n_ref, &bs);              // also where the chain LANDS beyond the segment: must look like a record
+            if (q < hi) rc = rec_check<false>(buf, q, T, n_ref, &bs);
+            else rc = rec_check<true>(buf, q, T, n_ref, &bs);   // where the chain LANDS beyond the segment: must look like a record
         }
         if (rc != 2 || forced) {                                // chain ran to the segment end (or into the batch tail)
             if (n == 0 && !forced) {                            // nothing complete: remember the first such offset, keep looking
@@ -206,6 +209,8 @@ struct tdt_ingest {
     size_t n_records = 0, rec_cap = 0;
     IngestOut O{};
     std::vector<unsigned> edges;
+    bool edges_overflow = false;
+    size_t host_chases = 0;                        // batches whose record chain had to be chased on the host
 };
 
 static int ing_grow(tdt_ingest *g, tdt_buf &b, size_t bytes, bool keep = false) {
@@ -305,6 +310,7 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
     g->out_len = T;
     g->n_records = 0;
     g->edges.clear();
+    g->edges_overflow = false;
     *n_records = 0;
     if (skip > T) {
         tdt_set_error("tdt_ingest_push: skip (%zu) exceeds the inflated bytes (%zu)", skip, T);
@@ -336,18 +342,52 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
     TDT_HIP(hipStreamSynchronize(st));
     for (int s = 0; s < nseg; s++) h_base[s] = ING_NONE;
     size_t cur = skip, n = 0;
-    while (cur < T) {
+    bool confirmed = getenv("TIDDIT_INGEST_HOST_CHASE") == nullptr;
+    while (confirmed && cur < T) {
         const int s = (int)(cur / ING_SEG);
         if (h_first[s] != (unsigned)cur) {
-            tdt_set_error("tdt_ingest_push: record chain could not be confirmed at offset %zu (segment %d guessed %u); decode this batch on the host",
-                          cur, s, h_first[s]);
-            return TDT_E_UNSUPPORTED;
+            confirmed = false;
+            break;
         }
         h_base[s] = (unsigned)n;
         n += h_count[s];
         if (h_exit[s] == (unsigned)cur) break;                    // the record at `cur` is incomplete: it is the tail
         cur = h_exit[s];
         if (cur < (size_t)(s + 1) * ING_SEG && cur < T) break;     // chain stopped inside the segment: tail reached
+    }
+    bool table_dirty = false;
+    if (!confirmed) {
+        // A guess disagreed with the chain (or the record sanity checks are stricter than this writer): chase the
+        // block_size chain serially on the host over a copy of the batch and rebuild the segment table from it.
+        g->host_chases++;
+        std::vector<unsigned char> raw(T);
+        TDT_HIP(hipMemcpyAsync(raw.data(), d_out, T, hipMemcpyDeviceToHost, st));
+        TDT_HIP(hipStreamSynchronize(st));
+        for (int s = 0; s < nseg; s++) {
+            h_base[s] = ING_NONE;
+            h_first[s] = ING_NONE;
+            h_count[s] = 0;
+        }
+        cur = skip;
+        n = 0;
+        while (cur + 4 <= T) {
+            uint32_t bs;
+            memcpy(&bs, raw.data() + cur, 4);
+            if (bs < 32) {
+                tdt_set_error("tdt_ingest_push: record %zu has block_size %u < 32 (corrupt stream)", n, bs);
+                return TDT_E_ARG;
+            }
+            if (cur + 4 + (size_t)bs > T) break;
+            const int s = (int)(cur / ING_SEG);
+            if (h_first[s] == ING_NONE) {
+                h_first[s] = (unsigned)cur;
+                h_base[s] = (unsigned)n;
+            }
+            h_count[s]++;
+            n++;
+            cur += 4 + (size_t)bs;
+        }
+        table_dirty = true;
     }
     const size_t tail = cur < T ? cur : T;
     // ---- decode the fields
@@ -373,6 +413,10 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
         O.mapq = (uint8_t *)p; p += a1;
         unsigned *d_edges = (unsigned *)p;                         // 1023 edges + counter
         TDT_HIP(hipMemcpyAsync(d_base, h_base, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+        if (table_dirty) {
+            TDT_HIP(hipMemcpyAsync(d_first, h_first, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+            TDT_HIP(hipMemcpyAsync(d_count, h_count, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+        }
         hipLaunchKernelGGL(bam_decode_fields, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, nseg, d_first, d_base, d_count, O);
         TDT_CHECK_LAUNCH();
         TDT_HIP(hipMemsetAsync(d_edges + 1023, 0, 4, st));
@@ -382,12 +426,11 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
         TDT_HIP(hipMemcpyAsync(h_edges, d_edges, 4096, hipMemcpyDeviceToHost, st));
         TDT_HIP(hipStreamSynchronize(st));
         const unsigned ne = h_edges[1023];
-        if (ne > 1023) {
-            tdt_set_error("tdt_ingest_push: more than 1023 contig changes in one batch (unsorted input?)");
-            return TDT_E_UNSUPPORTED;
+        g->edges_overflow = ne > 1023;                              // not coordinate sorted: the caller derives runs from tid itself
+        if (!g->edges_overflow) {
+            g->edges.assign(h_edges, h_edges + ne);
+            std::sort(g->edges.begin(), g->edges.end());
         }
-        g->edges.assign(h_edges, h_edges + ne);
-        std::sort(g->edges.begin(), g->edges.end());
     }
     g->n_records = n;
     *n_records = n;
@@ -422,17 +465,18 @@ extern "C" int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size
         tdt_set_error("tdt_ingest_edges: bad argument");
         return TDT_E_ARG;
     }
-    *n = g->edges.size();
+    *n = g->edges_overflow ? (size_t)-1 : g->edges.size();
     for (size_t i = 0; i < g->edges.size() && i < cap; i++) edges[i] = g->edges[i];
     return TDT_OK;
 }
 
-extern "C" int tdt_ingest_carry(tdt_ingest *g, size_t *bytes) {
+extern "C" int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases) {
     if (!g || !bytes) {
         tdt_set_error("tdt_ingest_carry: bad argument");
         return TDT_E_ARG;
     }
     *bytes = g->carry;
+    if (host_chases) *host_chases = g->host_chases;
     return TDT_OK;
 }
 

@@ -89,8 +89,11 @@ def device_all(path, chunk):
         assert np.array_equal(ed[:ne.value], want_ed), (ed[:ne.value], want_ed)
         nedges += ne.value
     c = ctypes.c_size_t(0)
-    _native.check(lib.tdt_ingest_carry(h, ctypes.byref(c)))
+    hc = ctypes.c_size_t(0)
+    _native.check(lib.tdt_ingest_carry(h, ctypes.byref(c), ctypes.byref(hc)))
     assert c.value == 0, c.value
+    global HOST_CHASES
+    HOST_CHASES += hc.value
     lib.tdt_ingest_destroy(h)
     return {k: np.concatenate(v) for k, v in out.items()}, sa
 
@@ -112,6 +115,7 @@ def compare(path, chunk):
     return ok
 
 
+HOST_CHASES = 0
 d = "/tmp/ingest_t"; os.makedirs(d, exist_ok=True)
 sv = d + "/sv.bam"
 synth_bam.write_synthetic_bam(sv, [("chr1", 300000), ("chr2", 200000), ("chrM", 3000), ("tiny", 500)], depth=8, seed=5)
@@ -121,4 +125,4 @@ allok = True
 for path in (sv, bulk):
     for chunk in (1 << 30, 3_000_000, 400_000):
         allok &= compare(path, chunk)
-print("ALL OK" if allok else "FAILURES")
+print("ALL OK" if allok else "FAILURES", "host chases:", HOST_CHASES)

@@ -33,10 +33,20 @@ r.close()
 t_dec = time.perf_counter() - t0
 assert k == n, (k, n)
 print("inflate + decode: %.2f s (%.1f M records/s)" % (t_dec, n / t_dec / 1e6))
-# stage 3: the whole --cov command
+# stage 3: the whole --cov command, host ingest vs device ingest
 from tiddit_amd import __main__ as cli
+for mode in ("host", "device", "device"):
+    os.environ["TIDDIT_HOST_INGEST"] = "1" if mode == "host" else "0"
+    t0 = time.perf_counter()
+    args = cli._cov_parser().parse_args(["--cov", "--bam", path, "-o", "/tmp/bulk_cov_" + mode, "-z", "500"])
+    cli.run_cov(args)
+    t_all = time.perf_counter() - t0
+    print("tiddit --cov end to end, %s ingest: %.2f s (%.1f M records/s, %.0f MB/s of BAM)" % (mode, t_all, n / t_all / 1e6, os.path.getsize(path) / t_all / 1e6))
+print("identical .bed:", open("/tmp/bulk_cov_host.bed").read() == open("/tmp/bulk_cov_device.bed").read())
 t0 = time.perf_counter()
-args = cli._cov_parser().parse_args(["--cov", "--bam", path, "-o", "/tmp/bulk_cov", "-z", "500"])
-cli.run_cov(args)
-t_all = time.perf_counter() - t0
-print("tiddit --cov end to end: %.2f s (%.1f M records/s, %.0f MB/s of BAM)" % (t_all, n / t_all / 1e6, os.path.getsize(path) / t_all / 1e6))
+r = bamio.DeviceBamReader(path)
+k = 0
+for b in r.batches():
+    k += len(b)
+r.close()
+print("device ingest only: %.2f s (%.1f M records/s), host chases %d" % (time.perf_counter() - t0, k / (time.perf_counter() - t0) / 1e6, r.host_chases))
