@@ -1,0 +1,193 @@
+"""GPU parity of the device ingest: BGZF inflate (one wavefront per block) against zlib, record finding + field decode
+against the host decoder (tdt_bam_decode, itself checked against the independent parser in test_bamio_cpu.py), and the
+pipeline (tiddit --cov / signal scan) with device ingest against the host-thread ingest."""
+import ctypes
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from tiddit_amd import _native, bamio, synth_bam
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return _native.default_context()
+
+
+def _bgzf(data, level, strategy=zlib.Z_DEFAULT_STRATEGY, block=0xff00):
+    out = b""
+    for o in range(0, max(1, len(data)), block):
+        d = data[o:o + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        comp = c.compress(d) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(comp) + 25) + comp +
+                struct.pack("<II", zlib.crc32(d) & 0xffffffff, len(d)))
+    return out + bamio._BGZF_EOF
+
+
+def _inflate_hbm(ctx, comp, n):
+    comp = np.frombuffer(comp, dtype=np.uint8)
+    out = np.zeros(n, dtype=np.uint8)
+    _native.check(ctx.lib.tdt_bgzf_inflate_hbm(ctx.handle, _native.ptr(comp), len(comp), _native.ptr(out), n, 0))
+    return out.tobytes()
+
+
+def _cases():
+    rng = np.random.default_rng(1)
+    return {
+        "empty": b"", "one": b"A", "three": b"abc", "zeros": bytes(200000),
+        "text": b"the quick brown fox jumps over the lazy dog. " * 5000,
+        "random": rng.integers(0, 256, 150000, dtype=np.uint8).tobytes(),
+        "dna": np.array(list(b"ACGT"), np.uint8)[rng.integers(0, 4, 300000)].tobytes(),
+        "skew": np.minimum(255, rng.geometric(0.05, 300000)).astype(np.uint8).tobytes(),
+        "runs": b"".join(bytes([int(v)]) * int(n) for v, n in zip(rng.integers(0, 256, 3000), rng.integers(1, 400, 3000))),
+        "period": (b"abcdefg" * 30000) + (b"xy" * 20000) + (b"0123456789ABCDEF" * 9000),
+    }
+
+
+@pytest.mark.parametrize("name", list(_cases()))
+def test_device_inflate_matches_zlib(ctx, name):
+    """stored / fixed / dynamic DEFLATE blocks, long codes, overlapping matches, 0..64 KiB blocks; CRC32 checked on the device"""
+    data = _cases()[name]
+    for level in (0, 1, 6, 9):
+        assert _inflate_hbm(ctx, _bgzf(data, level), len(data)) == data, (name, level)
+    for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+        assert _inflate_hbm(ctx, _bgzf(data, 6, strategy), len(data)) == data, (name, strategy)
+    assert _inflate_hbm(ctx, _bgzf(data, 6, block=777), len(data)) == data          # many small blocks
+
+
+def test_device_inflate_rejects_damage(ctx):
+    data = _cases()["text"]
+    comp = bytearray(_bgzf(data, 6))
+    good = bytes(comp)
+    comp[len(comp) // 3] ^= 0x40                                  # payload bit flip
+    with pytest.raises(_native.TdtError):
+        _inflate_hbm(ctx, bytes(comp), len(data))
+    bad_crc = bytearray(good)
+    first_bsize = struct.unpack_from("<H", good, 16)[0] + 1
+    bad_crc[first_bsize - 8] ^= 1                                 # CRC32 field of the first block
+    with pytest.raises(_native.TdtError) as e:
+        _inflate_hbm(ctx, bytes(bad_crc), len(data))
+    assert "CRC32" in str(e.value)
+    with pytest.raises(_native.TdtError):                         # caller's size disagrees with ISIZE
+        _inflate_hbm(ctx, good, len(data) - 1)
+    with pytest.raises(_native.TdtError):                         # not a whole number of blocks
+        _inflate_hbm(ctx, good[:-40], len(data))
+    assert _inflate_hbm(ctx, good, len(data)) == data             # the context still works afterwards
+
+
+FIELDS = [k for k, _ in bamio._FIELDS]
+
+
+def _host_records(path):
+    r = bamio.BamReader(path)
+    cols = {k: [] for k in FIELDS}
+    sa, names = [], []
+    for b in r.batches():
+        for k in FIELDS:
+            cols[k].append(getattr(b, k))
+        sa.extend(b.record(int(i)).get_tag_sa() for i in np.flatnonzero(b.sa_off >= 0))
+        names.extend(b.record(int(i)).query_name for i in range(0, len(b), 997))
+    r.close()
+    return {k: np.concatenate(v) for k, v in cols.items()}, sa, names
+
+
+def _device_records(path, ctx, chunk):
+    r = bamio.DeviceBamReader(path, ctx=ctx, chunk=chunk)
+    cols = {k: [] for k in FIELDS}
+    sa, runs_ok, nb = [], True, 0
+    for b in r.batches():
+        nb += 1
+        for k in FIELDS:
+            cols[k].append(getattr(b, k))
+        sa.extend(b.record(int(i)).get_tag_sa() for i in np.flatnonzero(b.sa_off >= 0))
+        lo = np.concatenate([[0], np.flatnonzero(np.diff(b.tid)) + 1])
+        want = [(int(b.tid[l]), int(l), int(h)) for l, h in zip(lo, np.concatenate([lo[1:], [len(b)]]))]
+        runs_ok &= want == b.runs
+        i = len(b) // 2                                            # rec_off points at the record inside the batch's raw bytes
+        assert b.raw[int(b.rec_off[i]) + 4:int(b.rec_off[i]) + 8].view(np.int32)[0] == b.tid[i]
+    hc = r.host_chases
+    r.close()
+    return {k: np.concatenate(v) for k, v in cols.items()}, sa, runs_ok, nb, hc
+
+
+@pytest.fixture(scope="module")
+def bams(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ingest")
+    sv = str(d / "sv.bam")
+    synth_bam.write_synthetic_bam(sv, [("chr1", 300000), ("chr2", 200000), ("chrM", 3000), ("tiny", 500)], depth=8, seed=5)
+    bulk = str(d / "bulk.bam")
+    synth_bam.write_bulk_bam(bulk, [("chr1", 1_500_000), ("chr2", 1_000_000)], depth=30, threads=8)
+    return sv, bulk
+
+
+@pytest.mark.parametrize("which,chunk", [(0, 1 << 28), (0, 300_000), (1, 1 << 28), (1, 2_000_000), (1, 200_000)])
+def test_device_ingest_matches_host_decode(ctx, bams, which, chunk):
+    """all thirteen field arrays, the SA strings and the contig runs; records and BGZF blocks straddle every push boundary"""
+    path = bams[which]
+    want, sa_w, _ = _host_records(path)
+    got, sa_g, runs_ok, nb, hc = _device_records(path, ctx, chunk)
+    for k in FIELDS:
+        if k in ("rec_off", "sa_off"):                            # batch-relative; checked through the strings / raw bytes
+            continue
+        assert np.array_equal(want[k], got[k]), k
+    assert np.array_equal(want["sa_off"] >= 0, got["sa_off"] >= 0) and sa_w == sa_g and runs_ok
+    assert hc == 0                                                # every record chain was confirmed from the device guesses
+    if chunk < 1 << 20:
+        assert nb > 3
+
+
+def test_device_ingest_host_chase_fallback(ctx, bams, monkeypatch):
+    """the serial host chase that backs up the per-segment guesses gives the same records"""
+    want, sa_w, _ = _host_records(bams[0])
+    monkeypatch.setenv("TIDDIT_INGEST_HOST_CHASE", "1")
+    got, sa_g, runs_ok, nb, hc = _device_records(bams[0], ctx, 300_000)
+    assert hc == nb and nb > 3 and runs_ok and sa_w == sa_g
+    for k in ("tid", "pos", "end", "mapq", "flag", "mate_tid", "mate_pos", "tlen", "l_seq", "cigar_first", "cigar_last"):
+        assert np.array_equal(want[k], got[k]), k
+
+
+def test_device_ingest_truncated_file(ctx, bams, tmp_path):
+    raw = open(bams[0], "rb").read()
+    blocks, o = [], 0
+    while o < len(raw):
+        bs = struct.unpack_from("<H", raw, o + 16)[0] + 1
+        blocks.append(raw[o:o + bs])
+        o += bs
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(b"".join(blocks[:len(blocks) // 2]))     # ends on a block boundary, in the middle of a record
+    with pytest.raises(ValueError):
+        for _ in bamio.DeviceBamReader(cut, ctx=ctx).batches():
+            pass
+
+
+def test_cli_cov_device_ingest_equals_host_ingest(bams, tmp_path, monkeypatch):
+    """tiddit --cov: BGZF inflate + decode + histogram in HBM vs host-thread inflate/decode + device histogram: same bytes"""
+    from tiddit_amd import __main__ as cli
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TIDDIT_HOST_INGEST", mode)
+        for z, wig in ((500, False), (50, True)):
+            o = str(tmp_path / ("cov_%s_%d" % (mode, z)))
+            cli.run_cov(cli._cov_parser().parse_args(["--cov", "--bam", bams[1], "-o", o, "-z", str(z)] + (["-w"] if wig else [])))
+            outs[(mode, z)] = open(o + (".wig" if wig else ".bed")).read()
+    assert outs[("1", 500)] == outs[("0", 500)] and outs[("1", 50)] == outs[("0", 50)] and len(outs[("0", 500)]) > 1000
+
+
+def test_signal_scan_device_ingest_equals_host_ingest(bams, monkeypatch):
+    """tiddit_signal.scan_signals (coverage, discordant pairs, splits, clips) is the same through either reader"""
+    from tiddit_amd import tiddit_signal
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TIDDIT_HOST_INGEST", mode)
+        res[mode] = tiddit_signal.scan_signals(bams[0], 5, 600, 10000, 30, 20)
+    h, d = res["1"], res["0"]
+    assert h[1] == d[1] and h[3] == d[3] and h[4] == d[4] and h[5] == d[5]
+    assert sum(len(v) for v in d[3].values()) > 0 and sum(len(v) for v in d[4].values()) > 0
+    for c in h[2]:
+        assert np.array_equal(h[2][c], d[2][c])

@@ -67,18 +67,17 @@ def _cov_parser():
 
 def run_cov(args):
     from . import tiddit_coverage
-    from .bamio import BamReader, DeviceBamReader
+    from .bamio import DeviceBatch, open_bam
     if not os.path.isfile(args.bam):
         print("error,  could not find the bam file")
         quit()
-    host = os.environ.get("TIDDIT_HOST_INGEST") == "1"                 # default: inflate + decode on the device
-    reader = BamReader(args.bam) if host else DeviceBamReader(args.bam)
+    reader = open_bam(args.bam)                                        # inflate + record decode on the device by default
     bam_header = reader.header
     coverage_data, end_bin_size = tiddit_coverage.create_coverage(bam_header, args.z)
     hist = tiddit_coverage.CoverageHistogram(bam_header, args.z)
     import numpy
     for b in reader.batches():
-        if not host:
+        if isinstance(b, DeviceBatch):
             d = b.dev
             items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in b.runs if t >= 0]
             if items:

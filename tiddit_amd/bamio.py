@@ -365,6 +365,8 @@ class DeviceBamReader:
         _native.check(self.ctx.lib.tdt_ingest_create(self.ctx.handle, len(self.references), ctypes.byref(h)))
         self._h = h
         self.host_chases = 0
+        import threading
+        self._stop = threading.Event()
 
     def _spans(self):
         """(buffer, consumed) spans of whole BGZF blocks, read ahead by a helper thread into rotating pinned buffers"""
@@ -375,6 +377,16 @@ class DeviceBamReader:
         chunk = self.chunk
         bufs = [torch.empty(chunk + (1 << 17), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(3)]
         q = queue.Queue(maxsize=1)
+        stop = self._stop
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
@@ -395,22 +407,26 @@ class DeviceBamReader:
                     if nb.value == 0:
                         raise ValueError("truncated BGZF block at end of file" if eof else "BGZF block larger than the read window")
                     carry = buf[consumed.value:have].copy()
-                    q.put((buf, consumed.value))
+                    if not put((buf, consumed.value)):
+                        return
                     k += 1
-                q.put(None)
+                put(None)
             except BaseException as e:
-                q.put(e)
+                put(e)
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            yield item
-        th.join()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()                                           # a consumer that stops early releases the reader thread
+            th.join()
 
     def batches(self):
         lib, ctx = self.ctx.lib, self.ctx
@@ -452,10 +468,20 @@ class DeviceBamReader:
             raise ValueError("truncated BAM record at end of file")
 
     def close(self):
+        self._stop.set()
         if self._h:
             self.ctx.lib.tdt_ingest_destroy(self._h)
             self._h = None
         self._f.close()
+
+
+def open_bam(path, ctx=None):
+    """The reader the pipeline uses: inflate + decode on the device (:class:`DeviceBamReader`); ``TIDDIT_HOST_INGEST=1``
+    selects the host-thread reader (:class:`BamReader`), whose batches are numpy-backed."""
+    import os
+    if os.environ.get("TIDDIT_HOST_INGEST") == "1":
+        return BamReader(path)
+    return DeviceBamReader(path, ctx=ctx)
 
 
 # ------------------------------------------------------------------------------------ writer

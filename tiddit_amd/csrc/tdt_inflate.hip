@@ -459,13 +459,22 @@ __device__ __forceinline__ unsigned crc_mulmod(unsigned a, unsigned b) {   // a*
     return r;
 }
 
+struct __attribute__((packed, aligned(1))) BzU128 {
+    unsigned w[4];
+};
+
 __global__ __launch_bounds__(256) void bgzf_crc32(const BzDesc *__restrict__ blocks, int nblocks, const unsigned char *__restrict__ out,
                                                   unsigned *__restrict__ status) {
-    __shared__ unsigned table[256];
+    __shared__ unsigned table[4][256];                        // slicing-by-4: table[k][b] = CRC of byte b followed by k zero bytes
     {
         unsigned c = threadIdx.x;
         for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xEDB88320u : 0);
-        table[threadIdx.x] = c;
+        table[0][threadIdx.x] = c;
+        __syncthreads();
+        for (int k = 1; k < 4; k++) {
+            c = (c >> 8) ^ table[0][c & 0xff];
+            table[k][threadIdx.x] = c;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -474,18 +483,31 @@ __global__ __launch_bounds__(256) void bgzf_crc32(const BzDesc *__restrict__ blo
     const BzDesc D = blocks[b];
     if (status[b] != BZ_OK) return;
     const unsigned n = D.isize;
-    const unsigned seg = (n + 63) / 64;                       // bytes per lane; the leading lanes of a short block are empty
-    const unsigned pad = seg * 64 - n;                        // virtual zero bytes in FRONT: crc state 0 is a fixed point of them
+    // Lane l owns virtual bytes [l*seg, (l+1)*seg) of (pad zero bytes ++ data): a raw CRC register that starts at 0 is a
+    // fixed point of leading zeros, and the register is set to ~0 on reaching data byte 0 (the standard initial value).
+    const unsigned seg = ((n + 63) / 64 + 15) & ~15u;          // bytes per lane, a multiple of 16: whole 16-byte loads
+    const long long pad = (long long)seg * 64 - n;
     const unsigned char *p = out + D.out_off;
-    // lane l covers virtual bytes [l*seg, (l+1)*seg) of (pad zero bytes ++ data); raw CRC register, no pre/post inversion
     unsigned c = 0;
     const long long v0 = (long long)lane * seg - pad;
-    for (unsigned i = 0; i < seg; i++) {
+    for (unsigned i = 0; i < seg; i += 16) {
         const long long j = v0 + i;
+        if (j + 16 <= 0) continue;
         if (j >= 0) {
-            unsigned byte = p[j];
-            if (j < 4) byte ^= 0xffu;                         // pre-inversion = xor of the first four data bytes with 0xff
-            c = table[(c ^ byte) & 0xff] ^ (c >> 8);
+            if (j == 0) c = 0xffffffffu;
+            const BzU128 v = *(const BzU128 *)(p + j);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                c ^= v.w[k];
+                c = table[3][c & 0xff] ^ table[2][(c >> 8) & 0xff] ^ table[1][(c >> 16) & 0xff] ^ table[0][c >> 24];
+            }
+        } else {                                               // the group that contains data byte 0
+            for (int k = 0; k < 16; k++) {
+                const long long jj = j + k;
+                if (jj < 0) continue;
+                if (jj == 0) c = 0xffffffffu;
+                c = table[0][(c ^ p[jj]) & 0xff] ^ (c >> 8);
+            }
         }
     }
     // x^(8*seg) by square-and-multiply, then the tree: crc(A||B) = crc(A) * x^(8|B|) + crc(B)
@@ -500,12 +522,7 @@ __global__ __launch_bounds__(256) void bgzf_crc32(const BzDesc *__restrict__ blo
         pw = crc_mulmod(pw, pw);
     }
     if (lane == 0) {
-        unsigned crc = ~c;
-        if (n < 4) {   // fewer than four bytes: the pre-inversion reaches past the data; do it serially
-            unsigned r = 0xffffffffu;
-            for (unsigned i = 0; i < n; i++) r = table[(r ^ p[i]) & 0xff] ^ (r >> 8);
-            crc = ~r;
-        }
+        const unsigned crc = n ? ~c : 0u;
         if (crc != D.crc) status[b] = BZ_E_CRC;
     }
 }

@@ -9,7 +9,7 @@ answered by one kernel launch, one wavefront per candidate (csrc/tdt_region.hip)
 import numpy
 
 from . import _native
-from .bamio import BamReader
+from .bamio import open_bam
 
 _FIELDS = (("start", "pos", numpy.int32), ("end", "end", numpy.int32), ("mapq", "mapq", numpy.uint8), ("flag", "flag", numpy.uint16),
            ("mate_tid", "mate_tid", numpy.int32), ("mate_pos", "mate_pos", numpy.int32), ("tlen", "tlen", numpy.int32))
@@ -19,7 +19,7 @@ class ReadTable:
     """Per-contig packed alignment records of a coordinate-sorted BAM (what a region fetch iterates over)."""
 
     def __init__(self, bam_file_name):
-        reader = BamReader(bam_file_name)
+        reader = open_bam(bam_file_name)
         self.references, self.lengths = reader.references, reader.lengths
         self.tid = {n: i for i, n in enumerate(self.references)}
         parts = {i: {k: [] for k, _, _ in _FIELDS} for i in range(len(self.references))}

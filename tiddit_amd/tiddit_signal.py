@@ -21,7 +21,7 @@ import numpy
 import ctypes
 
 from . import _native, tiddit_coverage
-from .bamio import BamReader
+from .bamio import DeviceBatch, open_bam
 
 _SA_OPS = {"M": 0, "S": 4, "H": 5, "D": 2, "I": 1}   # :23 — any other CIGAR letter raises KeyError, like the reference
 
@@ -121,9 +121,22 @@ def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
     """indices (ascending) of the reads of a decoded batch that are discordant-pair signals"""
     ctx = ctx or _native.default_context()
     n = len(batch)
+    ok = numpy.ascontiguousarray(contig_ok, dtype=numpy.uint8)
+    if isinstance(batch, DeviceBatch):                      # fields already in HBM: predicate + compaction without a re-upload
+        import torch
+        dev = torch.device("cuda", ctx.device)
+        d_ok = torch.from_numpy(ok).to(dev)
+        d_out = torch.empty(n, dtype=torch.int32, device=dev)
+        d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        d = batch.dev
+        _native.check(ctx.lib.tdt_signal_select_device(ctx.handle, d["flag"], d["mapq"], d["tid"], d["mate_tid"], d["tlen"], n,
+                                                       d_ok.data_ptr(), len(ok), int(min_q), int(max_ins), d_out.data_ptr(), d_cnt.data_ptr()))
+        ctx.sync()
+        k = int(d_cnt.item())
+        return d_out[:k].cpu().numpy().view(numpy.uint32)
     out = numpy.empty(n, dtype=numpy.uint32)
     cnt = ctypes.c_size_t(0)
-    ok = numpy.ascontiguousarray(contig_ok, dtype=numpy.uint8)
     _native.check(ctx.lib.tdt_signal_select(ctx.handle, _native.ptr(batch.flag), _native.ptr(batch.mapq), _native.ptr(batch.tid),
                                             _native.ptr(batch.mate_tid), _native.ptr(batch.tlen), n, _native.ptr(ok), len(ok),
                                             int(min_q), int(max_ins), _native.ptr(out), ctypes.byref(cnt)))
@@ -133,7 +146,7 @@ def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
 def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50):
     """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
     split rows, clip FASTA entries).  Rows are exactly what ``worker`` returns (:228)."""
-    reader = BamReader(bam_file_name)
+    reader = open_bam(bam_file_name)
     header = reader.header
     names, lengths = reader.references, reader.lengths
     big = numpy.array([ln >= min_contig for ln in lengths], dtype=bool)
@@ -148,11 +161,18 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         ok_contig = numpy.zeros(len(tid), dtype=bool)
         ok_contig[placed] = big[tid[placed]]
         # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
-        edges = numpy.flatnonzero(numpy.diff(tid)) + 1
-        for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
-            t = int(tid[lo])
-            if t >= 0 and big[t]:
-                hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
+        if isinstance(b, DeviceBatch):                      # the decoded arrays are already in HBM
+            d = b.dev
+            items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo)
+                     for t, lo, hi in b.runs if t >= 0 and big[t]]
+            if items:
+                hist.push_device_multi(items, min_q)
+        else:
+            edges = numpy.flatnonzero(numpy.diff(tid)) + 1
+            for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
+                t = int(tid[lo])
+                if t >= 0 and big[t]:
+                    hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
         primary = ok_contig & ((flag & 0x404) == 0) & ((flag & 0x900) == 0) & (b.mapq >= min_q)   # :171,:184,:188
         same_chr = b.mate_tid == tid
         abs_isize = numpy.abs(b.tlen.astype(numpy.int64))

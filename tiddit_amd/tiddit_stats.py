@@ -5,13 +5,13 @@ import time
 
 import numpy
 
-from .bamio import BamReader
+from .bamio import open_bam
 
 
 def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     library = {}
     t = time.time()
-    reader = BamReader(bam_file_name)
+    reader = open_bam(bam_file_name)
     read_length, insert_size = [], []
     is_innie = is_outtie = 0
     n_sampled = 0
