@@ -281,7 +281,7 @@ def test_dbscan_unsorted_x_golden(db, golden_dir):
 
 def test_dbscan_gen_golden(db, golden_dir):
     g = json.load(open(os.path.join(golden_dir, "dbscan_gen.json")))
-    for n in ("100000", "1000000"):
+    for n in ("100000", "1000000", "5000000"):     # reference runs of 31 s, 5 min and 2 h 10 min
         if n not in g:
             continue
         lab = db.main(synth.gen_points(int(n)), g[n]["eps"], g[n]["m"])

@@ -353,7 +353,7 @@ class DeviceBamReader:
     blocks are read into pinned host memory by a helper thread, pushed as they are, and come back as :class:`DeviceBatch`.
     Same ``header`` / ``references`` / ``lengths`` / ``batches()`` interface as :class:`BamReader`."""
 
-    def __init__(self, path, ctx=None, chunk=512 << 20):
+    def __init__(self, path, ctx=None, chunk=448 << 20):
         host = BamReader(path, batch_bytes=1 << 20)                 # the header is parsed on the host
         self.header, self.references, self.lengths, self.text = host.header, host.references, host.lengths, host.text
         self._skip = host.header_bytes
@@ -389,6 +389,10 @@ class DeviceBamReader:
             return False
 
         def produce():
+            import os
+            from concurrent.futures import ThreadPoolExecutor
+            fd, fsize, fo = self._f.fileno(), os.fstat(self._f.fileno()).st_size, 0
+            pool = ThreadPoolExecutor(4)
             try:
                 k, carry = 0, np.zeros(0, dtype=np.uint8)
                 eof = False
@@ -396,10 +400,23 @@ class DeviceBamReader:
                     buf = bufs[k % 3]
                     have = len(carry)
                     buf[:have] = carry
-                    while not eof and have < chunk:
-                        got = self._f.readinto(memoryview(buf)[have:chunk + (1 << 16)])
-                        eof = not got
-                        have += got or 0
+                    if not eof:                                  # parallel positional reads into the pinned buffer
+                        want = min(chunk + (1 << 16) - have, fsize - fo)
+                        piece = 8 << 20
+                        mv = memoryview(buf)
+
+                        def rd(o):
+                            n, end = 0, min(want, o + piece)
+                            while o + n < end:
+                                g = os.preadv(fd, [mv[have + o + n:have + end]], fo + o + n)
+                                if g <= 0:
+                                    raise ValueError("short read")
+                                n += g
+                            return n
+                        got = sum(pool.map(rd, range(0, want, piece)))
+                        fo += got
+                        have += got
+                        eof = fo >= fsize
                     if have == 0:
                         break
                     nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
@@ -413,6 +430,8 @@ class DeviceBamReader:
                 put(None)
             except BaseException as e:
                 put(e)
+            finally:
+                pool.shutdown(wait=False)
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()

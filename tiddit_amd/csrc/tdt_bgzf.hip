@@ -20,6 +20,14 @@ int tdt_host_thread_count() {
         if (t <= 0) {
             t = (int)std::thread::hardware_concurrency();
             if (t > 64) t = 64;
+            if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {   // container CPU quota: more threads than that only throttle
+                long long quota = 0, period = 0;
+                if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+                    const int q = (int)((quota + period - 1) / period);
+                    if (q >= 1 && q < t) t = q;
+                }
+                fclose(f);
+            }
         }
         if (t < 1) t = 1;
     }
