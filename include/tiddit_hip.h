@@ -188,6 +188,14 @@ typedef struct tdt_ingest tdt_ingest;
 int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out);
 int tdt_ingest_destroy(tdt_ingest *g);
 int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t *n_records);
+/* Sharded reads (one process per GPU on one file).  skip = (size_t)-1: the stream starts at a BGZF block somewhere
+ * inside the file and the first record is located by the guess (*first_off = its inflated offset).  own_bytes: the
+ * first own_bytes inflated bytes of this call belong to this shard, the blocks after them only complete its last
+ * record; records starting at or beyond own_bytes are left to the next shard and *next_off = offset of the first of
+ * them from that boundary.  The caller checks next_off of shard r against first_off of shard r+1: shard 0 starts from
+ * the header (exact), so agreement at every seam makes the whole decode exact.  A bounded push ends the stream. */
+int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records,
+                            size_t *first_off, size_t *next_off);
 int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len);
 int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n);
 int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);

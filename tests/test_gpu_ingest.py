@@ -191,3 +191,51 @@ def test_signal_scan_device_ingest_equals_host_ingest(bams, monkeypatch):
     assert sum(len(v) for v in d[3].values()) > 0 and sum(len(v) for v in d[4].values()) > 0
     for c in h[2]:
         assert np.array_equal(h[2][c], d[2][c])
+
+
+@pytest.mark.parametrize("which,world,chunk", [(0, 2, 1 << 28), (0, 5, 200_000), (1, 3, 1 << 28), (1, 8, 1_000_000), (0, 64, 1 << 28)])
+def test_sharded_device_ingest_is_the_sequential_decode(ctx, bams, which, world, chunk):
+    """one BAM read as `world` byte-range shards (mid-file starts found by the record guess): the shards' records, in rank
+    order, are exactly the unsharded decode, and every seam agrees (what dist.check_seams enforces across ranks)"""
+    path = bams[which]
+    want, _, _ = _host_records(path)
+    cols = {k: [] for k in FIELDS}
+    seams = []
+    for r in range(world):
+        rd = bamio.DeviceBamReader(path, ctx=ctx, chunk=chunk, shard=(r, world))
+        for b in rd.batches():
+            for k in FIELDS:
+                cols[k].append(getattr(b, k))
+        seams.append((rd.first_off, rd.next_off))
+        assert rd.host_chases == 0
+        rd.close()
+    for k in FIELDS:
+        if k in ("rec_off", "sa_off"):
+            continue
+        assert np.array_equal(want[k], np.concatenate(cols[k])), k
+    live = [s for s in seams if s[0] is not None]
+    assert len(live) >= min(world, 2) and live[-1][1] == 0
+    for a, b in zip(live, live[1:]):
+        assert a[1] == b[0]
+
+
+def test_coverage_sharded_single_rank_group_equals_cli(bams, tmp_path, monkeypatch):
+    """dist.coverage_sharded (sharded ingest + seam check + all-reduce) in a 1-rank process group vs the plain CLI path"""
+    import socket
+    import torch.distributed as dist
+    from tiddit_amd import __main__ as cli
+    from tiddit_amd import dist as tdist
+    from tiddit_amd import tiddit_coverage
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        header, cov, n = tdist.coverage_sharded(bams[1], 500, 20)
+    finally:
+        dist.destroy_process_group()
+    o = str(tmp_path / "a")
+    tiddit_coverage.print_coverage(cov, header, 500, "bed", o + ".bed")
+    cli.run_cov(cli._cov_parser().parse_args(["--cov", "--bam", bams[1], "-o", str(tmp_path / "b"), "-z", "500"]))
+    assert open(o + ".bed").read() == open(str(tmp_path / "b.bed")).read() and n > 100000

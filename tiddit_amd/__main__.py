@@ -71,27 +71,39 @@ def run_cov(args):
     if not os.path.isfile(args.bam):
         print("error,  could not find the bam file")
         quit()
-    reader = open_bam(args.bam)                                        # inflate + record decode on the device by default
-    bam_header = reader.header
-    coverage_data, end_bin_size = tiddit_coverage.create_coverage(bam_header, args.z)
-    hist = tiddit_coverage.CoverageHistogram(bam_header, args.z)
-    import numpy
-    for b in reader.batches():
-        if isinstance(b, DeviceBatch):
-            d = b.dev
-            items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in b.runs if t >= 0]
-            if items:
-                hist.push_device_multi(items, args.q)
-            continue
-        tid = b.tid
-        edges = numpy.flatnonzero(numpy.diff(tid)) + 1
-        for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
-            if tid[lo] >= 0:
-                hist.push(int(tid[lo]), b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], args.q)
-    reader.close()
-    for contig in coverage_data:
-        coverage_data[contig] = hist.finish(contig)
-    hist.close()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                                      # one process per GPU on ONE file: sharded ingest + all-reduce
+        import torch
+        import torch.distributed as dist
+        from . import dist as tdist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group("nccl")
+        bam_header, coverage_data, _ = tdist.coverage_sharded(args.bam, args.z, args.q)
+        if dist.get_rank() != 0:
+            return
+    else:
+        reader = open_bam(args.bam)                                        # inflate + record decode on the device by default
+        bam_header = reader.header
+        coverage_data, end_bin_size = tiddit_coverage.create_coverage(bam_header, args.z)
+        hist = tiddit_coverage.CoverageHistogram(bam_header, args.z)
+        import numpy
+        for b in reader.batches():
+            if isinstance(b, DeviceBatch):
+                d = b.dev
+                items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in b.runs if t >= 0]
+                if items:
+                    hist.push_device_multi(items, args.q)
+                continue
+            tid = b.tid
+            edges = numpy.flatnonzero(numpy.diff(tid)) + 1
+            for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
+                if tid[lo] >= 0:
+                    hist.push(int(tid[lo]), b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], args.q)
+        reader.close()
+        for contig in coverage_data:
+            coverage_data[contig] = hist.finish(contig)
+        hist.close()
     if args.w:
         tiddit_coverage.print_coverage(coverage_data, bam_header, args.z, "wig", args.o + ".wig")
     else:

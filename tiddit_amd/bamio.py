@@ -308,6 +308,50 @@ class BamReader:
         self._f.close()
 
 
+def find_block_start(path, offset):
+    """File offset of the first BGZF block that starts at or after `offset` (how a shard of a BAM finds its feet):
+    the gzip/BGZF magic with a BC subfield whose BSIZE leads to another block header (or to the end of the file)."""
+    import os
+    fsize = os.path.getsize(path)
+    if offset <= 0:
+        return 0
+    if offset >= fsize:
+        return fsize
+
+    def header_at(buf, p):
+        if p + 18 > len(buf) or buf[p:p + 4] != b"\x1f\x8b\x08\x04":
+            return None
+        xlen = struct.unpack_from("<H", buf, p + 10)[0]
+        o = p + 12
+        while o + 4 <= p + 12 + xlen and o + 4 <= len(buf):
+            slen = struct.unpack_from("<H", buf, o + 2)[0]
+            if buf[o] == 66 and buf[o + 1] == 67 and slen == 2 and o + 6 <= len(buf):
+                return struct.unpack_from("<H", buf, o + 4)[0] + 1
+            o += 4 + slen
+        return None
+
+    with open(path, "rb") as f:
+        f.seek(offset)
+        buf = f.read(4 << 16)
+    p = buf.find(b"\x1f\x8b\x08\x04")
+    while p >= 0:
+        q, ok = p, True
+        for _ in range(3):                                    # three consecutive headers (or a clean end of file)
+            bs = header_at(buf, q)
+            if bs is None:
+                ok = offset + q == fsize
+                break
+            q += bs
+            if offset + q == fsize:
+                break
+            if q + 18 > len(buf):
+                break
+        if ok:
+            return offset + p
+        p = buf.find(b"\x1f\x8b\x08\x04", p + 1)
+    raise ValueError("no BGZF block found after offset %d" % offset)
+
+
 # ------------------------------------------------------------------------------------ device reader
 _FIELDS = (("tid", np.int32), ("pos", np.int32), ("end", np.int32), ("mapq", np.uint8), ("flag", np.uint16), ("mate_tid", np.int32),
            ("mate_pos", np.int32), ("tlen", np.int32), ("l_seq", np.int32), ("cigar_first", np.uint32), ("cigar_last", np.uint32),
@@ -353,7 +397,10 @@ class DeviceBamReader:
     blocks are read into pinned host memory by a helper thread, pushed as they are, and come back as :class:`DeviceBatch`.
     Same ``header`` / ``references`` / ``lengths`` / ``batches()`` interface as :class:`BamReader`."""
 
-    def __init__(self, path, ctx=None, chunk=448 << 20):
+    def __init__(self, path, ctx=None, chunk=448 << 20, shard=None):
+        """shard = (rank, world): read only the BGZF blocks that start in this rank's byte range of the file; the records
+        that start in them are this shard's.  After ``batches()`` is exhausted, ``first_off`` / ``next_off`` hold the seam
+        offsets that neighbouring shards must agree on (``dist.check_seams``)."""
         host = BamReader(path, batch_bytes=1 << 20)                 # the header is parsed on the host
         self.header, self.references, self.lengths, self.text = host.header, host.references, host.lengths, host.text
         self._skip = host.header_bytes
@@ -365,8 +412,26 @@ class DeviceBamReader:
         _native.check(self.ctx.lib.tdt_ingest_create(self.ctx.handle, len(self.references), ctypes.byref(h)))
         self._h = h
         self.host_chases = 0
+        import os
         import threading
         self._stop = threading.Event()
+        fsize = os.path.getsize(path)
+        self.shard = shard
+        self.first_off = self.next_off = None
+        if shard is None:
+            self._b_lo, self._b_hi, self._x_hi = 0, fsize, fsize
+        else:
+            r, w = shard
+            self._b_lo = find_block_start(path, fsize * r // w)
+            self._b_hi = fsize if r == w - 1 else find_block_start(path, fsize * (r + 1) // w)
+            x = self._b_hi                                          # a few blocks past the shard complete its last record
+            with open(path, "rb") as f:
+                for _ in range(8):
+                    if x >= fsize:
+                        break
+                    f.seek(x + 16)
+                    x += struct.unpack("<H", f.read(2))[0] + 1
+            self._x_hi = min(x, fsize)
 
     def _spans(self):
         """(buffer, consumed) spans of whole BGZF blocks, read ahead by a helper thread into rotating pinned buffers"""
@@ -375,7 +440,9 @@ class DeviceBamReader:
         import torch
         lib = self.ctx.lib
         chunk = self.chunk
-        bufs = [torch.empty(chunk + (1 << 17), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(3)]
+        b_lo, x_hi = self._b_lo, self._x_hi
+        chunk = max(1 << 16, min(chunk, x_hi - b_lo))
+        bufs = [torch.empty(chunk + (2 << 20), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(3)]
         q = queue.Queue(maxsize=1)
         stop = self._stop
 
@@ -391,7 +458,7 @@ class DeviceBamReader:
         def produce():
             import os
             from concurrent.futures import ThreadPoolExecutor
-            fd, fsize, fo = self._f.fileno(), os.fstat(self._f.fileno()).st_size, 0
+            fd, fsize, fo = self._f.fileno(), x_hi, b_lo           # this reader's byte range of the file
             pool = ThreadPoolExecutor(4)
             try:
                 k, carry = 0, np.zeros(0, dtype=np.uint8)
@@ -401,7 +468,7 @@ class DeviceBamReader:
                     have = len(carry)
                     buf[:have] = carry
                     if not eof:                                  # parallel positional reads into the pinned buffer
-                        want = min(chunk + (1 << 16) - have, fsize - fo)
+                        want = fsize - fo if fsize - fo <= chunk + (1 << 20) - have else chunk - have   # the tail rides along
                         piece = 8 << 20
                         mv = memoryview(buf)
 
@@ -424,7 +491,7 @@ class DeviceBamReader:
                     if nb.value == 0:
                         raise ValueError("truncated BGZF block at end of file" if eof else "BGZF block larger than the read window")
                     carry = buf[consumed.value:have].copy()
-                    if not put((buf, consumed.value)):
+                    if not put((buf, consumed.value, fo - have)):
                         return
                     k += 1
                 put(None)
@@ -451,11 +518,35 @@ class DeviceBamReader:
         lib, ctx = self.ctx.lib, self.ctx
         prev = None
         first = True
-        for buf, consumed in self._spans():
+        nothing = ctypes.c_size_t(-1).value
+        if self.shard is not None and self._b_lo >= self._b_hi:      # an empty shard: the seam passes straight through
+            return
+        for buf, consumed, abs0 in self._spans():
             if prev is not None:
                 prev._live = False
             n = ctypes.c_size_t(0)
-            _native.check(lib.tdt_ingest_push(self._h, _native.ptr(buf), consumed, self._skip if first else 0, ctypes.byref(n)))
+            skip = (self._skip if self._b_lo == 0 else nothing) if first else 0
+            final = self.shard is not None and abs0 + consumed >= self._x_hi
+            if self.shard is not None and not final and abs0 + consumed > self._b_hi:
+                raise RuntimeError("shard tail split across reads")
+            if final:
+                own_c = max(0, min(consumed, self._b_hi - abs0))
+                nb_, c_, own = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+                _native.check(lib.tdt_bgzf_scan(_native.ptr(buf), own_c, 3 << 30, ctypes.byref(nb_), ctypes.byref(c_), ctypes.byref(own)))
+                if c_.value != own_c:
+                    raise RuntimeError("shard boundary is not a block boundary")
+                fo, no = ctypes.c_size_t(0), ctypes.c_size_t(0)
+                _native.check(lib.tdt_ingest_push_bounded(self._h, _native.ptr(buf), consumed, skip, own.value, ctypes.byref(n),
+                                                          ctypes.byref(fo), ctypes.byref(no)))
+                if first:
+                    self.first_off = fo.value
+                self.next_off = no.value
+            elif first and self.shard is not None:
+                fo = ctypes.c_size_t(0)
+                _native.check(lib.tdt_ingest_push_bounded(self._h, _native.ptr(buf), consumed, skip, nothing, ctypes.byref(n), ctypes.byref(fo), None))
+                self.first_off = fo.value
+            else:
+                _native.check(lib.tdt_ingest_push(self._h, _native.ptr(buf), consumed, skip, ctypes.byref(n)))
             first = False
             if not n.value:
                 continue
@@ -484,6 +575,8 @@ class DeviceBamReader:
         _native.check(lib.tdt_ingest_carry(self._h, ctypes.byref(c), ctypes.byref(hc)))
         self.host_chases = hc.value
         if c.value:
+            raise ValueError("truncated BAM record at end of file")
+        if self.shard is not None and self.shard[0] == self.shard[1] - 1 and self.next_off not in (None, 0):
             raise ValueError("truncated BAM record at end of file")
 
     def close(self):

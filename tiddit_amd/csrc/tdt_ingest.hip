@@ -63,8 +63,11 @@ __device__ __forceinline__ int rec_check(const unsigned char *buf, long long p, 
     return 0;
 }
 
-__global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__restrict__ buf, long long T, long long s0, int n_ref, int nseg,
-                                                       unsigned *__restrict__ first, unsigned *__restrict__ exitp,
+// s0 = offset of the first record when it is known (after the header / a carried record), -1 when the batch starts
+// somewhere inside a file (sharded read).  limit = records starting at or beyond it belong to the next shard: a chain
+// stops at the first such offset (reported as the segment's exit) and they are not counted.
+__global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__restrict__ buf, long long T, long long s0, long long limit,
+                                                       int n_ref, int nseg, unsigned *__restrict__ first, unsigned *__restrict__ exitp,
                                                        unsigned *__restrict__ count) {
     const int g = blockIdx.x * 64 + threadIdx.x;
     if (g >= nseg) return;
@@ -73,20 +76,21 @@ __global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__re
     unsigned f = ING_NONE, e = 0, c = 0;
     bool weak = false;                                          // a candidate that is only "a record running past the batch end"
     long long p = lo;
-    if (s0 >= hi) p = hi;                                       // segment lies inside the header
+    if (s0 >= hi || lo >= limit) p = hi;                        // segment lies inside the header / wholly in the next shard
     else if (s0 > lo) p = s0;
     const bool forced = s0 >= lo && s0 < hi;                    // the first record's offset is known, not guessed
-    for (; p < hi; p++) {
+    const long long stop = hi < limit ? hi : limit;
+    for (; p < stop; p++) {
         unsigned bs;
         int rc = rec_check<true>(buf, p, T, n_ref, &bs);
         if (rc == 2 && !forced) continue;
         long long q = p;
         unsigned n = 0;
-        while (rc == 0 && q < hi) {
+        while (rc == 0 && q < stop) {
             q += 4 + (long long)bs;
             n++;
             if (q >= T) break;                                  // the batch ends exactly on a record boundary
-            if (q < hi) rc = rec_check<false>(buf, q, T, n_ref, &bs);
+            if (q < stop) rc = rec_check<false>(buf, q, T, n_ref, &bs);
             else rc = rec_check<true>(buf, q, T, n_ref, &bs);   // where the chain LANDS beyond the segment: must look like a record
         }
         if (rc != 2 || forced) {                                // chain ran to the segment end (or into the batch tail)
@@ -258,10 +262,23 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
 }
 
 extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t *n_records) {
+    return tdt_ingest_push_bounded(g, comp, len, skip, (size_t)-1, n_records, nullptr, nullptr);
+}
+
+extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records,
+                                       size_t *first_off, size_t *next_off) {
     if (!g || (!comp && len) || !n_records) {
         tdt_set_error("tdt_ingest_push: bad argument");
         return TDT_E_ARG;
     }
+    const bool unknown_start = skip == (size_t)-1;
+    if (unknown_start && g->carry) {
+        tdt_set_error("tdt_ingest_push_bounded: an unknown start is only possible on a fresh stream");
+        return TDT_E_ARG;
+    }
+    if (unknown_start) skip = 0;
+    if (first_off) *first_off = (size_t)-1;
+    if (next_off) *next_off = (size_t)-1;
     tdt_ctx *ctx = g->ctx;
     TDT_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -321,6 +338,12 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
         g->tail_off = 0;
         return TDT_OK;
     }
+    const bool bounded = own_bytes != (size_t)-1;
+    const size_t limit = bounded ? carry + own_bytes : T;         // records starting at or after it are the next shard's
+    if (limit > T) {
+        tdt_set_error("tdt_ingest_push_bounded: own_bytes (%zu) exceeds the inflated bytes (%zu)", own_bytes, produced);
+        return TDT_E_ARG;
+    }
     // ---- find the records: per-segment guesses on the device, chain check on the host
     const int nseg = (int)((T + ING_SEG - 1) / ING_SEG);
     const size_t segb = ((size_t)nseg * 4 + 255) & ~(size_t)255;
@@ -335,15 +358,31 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
     }
     unsigned *h_first = (unsigned *)g->pin.p, *h_exit = (unsigned *)((char *)g->pin.p + segb), *h_count = (unsigned *)((char *)g->pin.p + 2 * segb),
              *h_base = (unsigned *)((char *)g->pin.p + 3 * segb);
-    hipLaunchKernelGGL(bam_find_records, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, (long long)skip, g->n_ref, nseg, d_first,
-                       d_exit, d_count);
+    hipLaunchKernelGGL(bam_find_records, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, unknown_start ? -1ll : (long long)skip,
+                       (long long)limit, g->n_ref, nseg, d_first, d_exit, d_count);
     TDT_CHECK_LAUNCH();
     TDT_HIP(hipMemcpyAsync(h_first, d_first, 3 * segb, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipStreamSynchronize(st));
     for (int s = 0; s < nseg; s++) h_base[s] = ING_NONE;
     size_t cur = skip, n = 0;
     bool confirmed = getenv("TIDDIT_INGEST_HOST_CHASE") == nullptr;
-    while (confirmed && cur < T) {
+    if (unknown_start) {
+        // sharded read: the first record is the first guess of the batch; the caller cross-checks it against the
+        // neighbouring shard's chain (first_off / next_off), and every later segment must agree with the chain as usual
+        cur = T;
+        for (int s = 0; s < nseg && (size_t)s * ING_SEG < limit; s++)
+            if (h_first[s] < ING_NONE - 1) {
+                cur = h_first[s];
+                break;
+            }
+        if (cur >= limit) {
+            tdt_set_error("tdt_ingest_push_bounded: no record start found in the shard's first %zu bytes", limit);
+            return TDT_E_UNSUPPORTED;
+        }
+        confirmed = true;                                         // there is no known start a host chase could use instead
+    }
+    const size_t start = cur;
+    while (confirmed && cur < limit) {
         const int s = (int)(cur / ING_SEG);
         if (h_first[s] != (unsigned)cur) {
             confirmed = false;
@@ -353,7 +392,11 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
         n += h_count[s];
         if (h_exit[s] == (unsigned)cur) break;                    // the record at `cur` is incomplete: it is the tail
         cur = h_exit[s];
-        if (cur < (size_t)(s + 1) * ING_SEG && cur < T) break;     // chain stopped inside the segment: tail reached
+        if (cur < (size_t)(s + 1) * ING_SEG && cur < limit) break;  // chain stopped inside the segment: tail reached
+    }
+    if (!confirmed && unknown_start) {
+        tdt_set_error("tdt_ingest_push_bounded: the record chain from the guessed start %zu could not be confirmed", start);
+        return TDT_E_UNSUPPORTED;
     }
     bool table_dirty = false;
     if (!confirmed) {
@@ -370,7 +413,7 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
         }
         cur = skip;
         n = 0;
-        while (cur + 4 <= T) {
+        while (cur + 4 <= T && cur < limit) {
             uint32_t bs;
             memcpy(&bs, raw.data() + cur, 4);
             if (bs < 32) {
@@ -390,6 +433,14 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
         table_dirty = true;
     }
     const size_t tail = cur < T ? cur : T;
+    if (first_off) *first_off = start;
+    if (bounded) {
+        if (cur < limit) {                                        // the shard's last record runs past the blocks that were supplied
+            tdt_set_error("tdt_ingest_push_bounded: the record at %zu is incomplete; supply more blocks after the shard's own", cur);
+            return TDT_E_RANGE;
+        }
+        if (next_off) *next_off = cur - limit;                    // where the next shard's first record starts, from its boundary
+    }
     // ---- decode the fields
     if (n) {
         const size_t N = n;
@@ -435,7 +486,7 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
     g->n_records = n;
     *n_records = n;
     // ---- the partial record stays where it is (the batch's raw bytes remain readable); the next push moves it to the front
-    const size_t left = T - tail;
+    const size_t left = bounded ? 0 : T - tail;                   // a bounded push ends the shard: nothing is carried
     if (left > tail && left) {
         tdt_set_error("tdt_ingest_push: a single record (%zu bytes) is larger than the rest of the batch; feed more blocks per call", left);
         return TDT_E_UNSUPPORTED;

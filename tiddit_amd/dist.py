@@ -74,3 +74,79 @@ def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None, wire_dt
             labels[b] = parts[r][off:off + int(bucket_sizes[b])]
             off += int(bucket_sizes[b])
     return labels
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# One BAM, N GPUs: every rank ingests the BGZF blocks of its byte range of the file (bamio.DeviceBamReader(shard=...)),
+# accumulates its reads into a full-genome histogram, and ONE all-reduce of the float64 bins assembles the result.
+# The bins are exact multiples of 2^-S far below 2^53, so the sum is exact and order independent:
+# the reduced array is bit-identical to the single-GPU one.
+
+def check_seams(first_off, next_off, empty, group=None):
+    """Exactness of a sharded read.  Shard 0 starts at the header (known offset); shard r > 0 guessed its first record
+    `first_off` bytes into its range, and shard r-1 — following the true block_size chain across the seam — reports
+    where that record must start (`next_off`).  Agreement at every seam (empty shards pass the value through) makes
+    every shard's decode the sequential one.  Raises ValueError on any disagreement; returns the gathered table."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    mine = torch.tensor([-1 if first_off is None else int(first_off), -1 if next_off is None else int(next_off), 1 if empty else 0],
+                        dtype=torch.int64, device=dev)
+    world = dist.get_world_size(group)
+    table = torch.empty(3 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(table, mine, group=group)
+    table = table.cpu().view(world, 3).tolist()
+    expect = None
+    for r, (fo, no, emp) in enumerate(table):
+        if emp:
+            continue
+        if expect is not None and fo != expect:
+            raise ValueError("sharded BAM read: shard %d starts its records at +%d, the chain of shard before it says +%d" % (r, fo, expect))
+        expect = no
+    return table
+
+
+def allreduce_bins(bins, group=None):
+    """In-place SUM all-reduce of a float64 tensor of bins (RCCL over xGMI with the nccl backend)."""
+    import torch.distributed as dist
+    dist.all_reduce(bins, op=dist.ReduceOp.SUM, group=group)
+    return bins
+
+
+def coverage_sharded(bam_file_name, bin_size, min_q, group=None, ctx=None, chunk=448 << 20):
+    """`tiddit --cov` on one BAM with one process per GPU.  -> (header, {contig: float64 bins}) on every rank."""
+    import torch
+    import torch.distributed as dist
+    from . import _native, tiddit_coverage
+    from .bamio import DeviceBamReader
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ctx = ctx or _native.default_context()
+    reader = DeviceBamReader(bam_file_name, ctx=ctx, chunk=chunk, shard=(rank, world))
+    header = reader.header
+    hist = tiddit_coverage.CoverageHistogram(header, bin_size, ctx=ctx)
+    n = 0
+    for b in reader.batches():
+        d = b.dev
+        items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in b.runs if t >= 0]
+        if items:
+            hist.push_device_multi(items, min_q)
+        n += len(b)
+    empty = reader.first_off is None
+    first_off, next_off = reader.first_off, reader.next_off
+    reader.close()
+    check_seams(first_off, next_off, empty, group)
+    dev = torch.device("cuda", ctx.device)
+    bins = torch.zeros(hist.total_bins(), dtype=torch.float64, device=dev)
+    hist.finish_all_device(bins.data_ptr())
+    ctx.sync()
+    if dist.get_backend(group) != "nccl":
+        bins = allreduce_bins(bins.cpu(), group)
+    else:
+        allreduce_bins(bins, group)
+    host = bins.cpu().numpy()
+    out = {}
+    for i, c in enumerate(header["SQ"]):
+        o = hist.offset(i)
+        out[c["SN"]] = host[o:o + hist.nbins(i)[0]].copy()
+    hist.close()
+    return header, out, n

@@ -12,7 +12,7 @@ for rep in range(2):
     r = bamio.DeviceBamReader(path)
     t1 = time.perf_counter()
     n = 0
-    for buf, consumed in r._spans():
+    for buf, consumed, _abs in r._spans():
         n += consumed
     t2 = time.perf_counter()
     r.close()
@@ -21,7 +21,7 @@ for rep in range(2):
     r = bamio.DeviceBamReader(path)
     tp = 0.0; k = 0; first = True
     t0 = time.perf_counter()
-    for buf, consumed in r._spans():
+    for buf, consumed, _abs in r._spans():
         ta = time.perf_counter()
         nn = ctypes.c_size_t(0)
         _native.check(lib.tdt_ingest_push(r._h, _native.ptr(buf), consumed, r._skip if first else 0, ctypes.byref(nn)))
