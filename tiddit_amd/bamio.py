@@ -175,9 +175,11 @@ def inflate_pieces(f, chunk=32 << 20, max_out=192 << 20, gap=1 << 20, depth=2):
         try:
             comp = np.empty(chunk + (1 << 17), dtype=np.uint8)
             have, eof = 0, False
+            step = min(chunk, 1 << 20)                              # a small first piece: the header is wanted right away
             while True:
                 if not eof:
-                    got = f.readinto(memoryview(comp)[have:have + chunk])
+                    got = f.readinto(memoryview(comp)[have:have + step])
+                    step = chunk
                     eof = not got
                     have += got or 0
                 if have == 0:
