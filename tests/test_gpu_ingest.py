@@ -239,3 +239,61 @@ def test_coverage_sharded_single_rank_group_equals_cli(bams, tmp_path, monkeypat
     tiddit_coverage.print_coverage(cov, header, 500, "bed", o + ".bed")
     cli.run_cov(cli._cov_parser().parse_args(["--cov", "--bam", bams[1], "-o", str(tmp_path / "b"), "-z", "500"]))
     assert open(o + ".bed").read() == open(str(tmp_path / "b.bed")).read() and n > 100000
+
+
+def _write_odd_bam(path, kind, seed=11):
+    """BAMs that stress the record finder: 'long' = reads far larger than a BGZF block / a 16 KiB segment between short
+    ones, 'aligned' = htslib-style blocks that never split a record, 'unsorted' = contig ids change on almost every record"""
+    rng = np.random.default_rng(seed)
+    refs = [("c%d" % i, 2_000_000) for i in range(6)]
+    w = bamio.BamWriter(path, refs, level=1, align_records=(kind == "aligned"))
+    n = 0
+    recs = []
+    for i in range(3000):
+        tid = int(rng.integers(0, len(refs))) if kind == "unsorted" else min(len(refs) - 1, i // 500)
+        pos = int(rng.integers(0, 1_000_000)) if kind == "unsorted" else (i % 500) * 1500
+        if kind == "long" and i % 40 == 7:
+            ln = int(rng.integers(20_000, 150_000))
+            seq = "".join(rng.choice(list("ACGT"), ln))
+            cig = "%dS%dM%dI%dM" % (5, ln // 2, 3, ln - 5 - 3 - ln // 2)
+        else:
+            ln = int(rng.integers(30, 152))
+            seq = "".join(rng.choice(list("ACGT"), ln))
+            cig = "%dM" % ln
+        tags = (("SA", "Z", "c1,%d,+,50M50S,30,0;" % (pos + 7)),) if i % 97 == 0 else ()
+        if i % 5 == 0:
+            tags = tags + (("NM", "i", int(i % 7)), ("RG", "Z", "grp"))
+        recs.append(dict(qname="r%d/%s" % (i, "x" * int(rng.integers(0, 40))), flag=int(rng.choice([99, 147, 83, 163, 1024 + 99, 4])), tid=tid, pos=pos,
+                         mapq=int(rng.integers(0, 61)), cigar=cig, mate_tid=tid, mate_pos=pos + 200, tlen=300, seq=seq, tags=tags))
+    for r in recs:
+        w.write(**r)
+        n += 1
+    w.close()
+    return n
+
+
+@pytest.mark.parametrize("kind,chunk", [("long", 1 << 28), ("long", 150_000), ("aligned", 1 << 28), ("aligned", 90_000), ("unsorted", 1 << 28)])
+def test_device_ingest_odd_files(ctx, tmp_path, kind, chunk):
+    path = str(tmp_path / (kind + ".bam"))
+    n = _write_odd_bam(path, kind)
+    want, sa_w, _ = _host_records(path)
+    got, sa_g, runs_ok, nb, hc = _device_records(path, ctx, chunk)
+    assert len(want["tid"]) == n == len(got["tid"])
+    for k in FIELDS:
+        if k not in ("rec_off", "sa_off"):
+            assert np.array_equal(want[k], got[k]), k
+    assert sa_w == sa_g and runs_ok and hc == 0
+
+
+def test_cli_cov_unsorted_bam_device_equals_host(tmp_path, monkeypatch):
+    """contig id changes on nearly every record: the device reader derives the runs from the tid column"""
+    from tiddit_amd import __main__ as cli
+    path = str(tmp_path / "u.bam")
+    _write_odd_bam(path, "unsorted")
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TIDDIT_HOST_INGEST", mode)
+        o = str(tmp_path / ("cov" + mode))
+        cli.run_cov(cli._cov_parser().parse_args(["--cov", "--bam", path, "-o", o, "-z", "1000", "-q", "10"]))
+        outs[mode] = open(o + ".bed").read()
+    assert outs["0"] == outs["1"] and len(outs["0"]) > 1000

@@ -621,10 +621,13 @@ def parse_cigar(cigar):
 class BamWriter:
     """Write a BAM from Python values (test / synthetic-config tooling)."""
 
-    def __init__(self, path, references, text=None, level=1):
+    def __init__(self, path, references, text=None, level=1, align_records=False):
+        """align_records: start a new BGZF block rather than split a record across two (what htslib's writer does);
+        the default packs blocks to 0xff00 bytes regardless of record boundaries (htsjdk style)."""
         self._f = open(path, "wb")
         self._buf = bytearray()
         self.level = level
+        self.align_records = align_records
         self.references = [r[0] for r in references]
         if text is None:
             text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in references)
@@ -657,6 +660,9 @@ class BamWriter:
         body = (struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, _reg2bin(pos, pos + rlen), len(cig), flag, lseq, mate_tid,
                             mate_pos, tlen) + name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig) + packed +
                 b"\xff" * lseq + aux)
+        if self.align_records and self._buf and len(self._buf) + 4 + len(body) > 0xff00:
+            self._f.write(_bgzf_block(bytes(self._buf), self.level))
+            self._buf = bytearray()
         self._buf += struct.pack("<i", len(body)) + body
         while len(self._buf) >= 0xff00:
             self._f.write(_bgzf_block(bytes(self._buf[:0xff00]), self.level))
