@@ -1,0 +1,501 @@
+// BGZF inflate, lane-parallel symbol decode (the default kernel; tdt_inflate.hip keeps the one-symbol-at-a-time version).
+//
+// Still one wavefront per BGZF block, but inside a Huffman-coded DEFLATE block the 64 lanes decode SPECULATIVELY: lane i
+// decodes the symbol that would start i bits into the current window — literal/length LUT, and for a length code its
+// extra bits, the distance LUT and the distance extra bits — which yields next[i] = i + bits consumed.  The true symbol
+// sequence is the chain 0 -> next[0] -> next[next[0]] ... ; a short scalar walk (one v_readlane per symbol) marks the
+// lanes on it, a DPP prefix sum of their output lengths gives every symbol its output offset, all literals of the window
+// leave in ONE predicated store and only the matches (LZ77 copies, which depend on earlier output) are replayed in
+// order.  A 64-bit window holds ~7 symbols, so the per-symbol scalar work — what bounds the sequential kernel — drops
+// about threefold, and the table lookups/bit arithmetic move to the otherwise idle vector pipe.
+//   * input: the compressed stream is staged through a 512-byte LDS ring (two 256-byte windows, one coalesced load each);
+//     lanes gather their three dwords from it;
+//   * tables: canonical Huffman LUTs in LDS, 32-bit entries with RFC 1951's base value / extra-bit count folded in
+//     (10 bits literal/length, 9 bits distance); a symbol whose code is longer than the LUT stops the chain and is decoded
+//     by the scalar canonical walk;
+//   * every loop is bounded by ISIZE / the compressed length; damage sets the block's status.
+#include "tdt_common.h"
+
+#define B2_TB_LL 10
+#define B2_TB_D 9
+#define B2_WAVES 4
+// LDS bytes per wave: lens 320 | lut_ll 4096 | lut_d 2048 | sorted_ll 576 | sorted_d 64 | meta_ll 96 | meta_d 96 | ring 512
+#define B2_OFF_LUTLL 320
+#define B2_OFF_LUTD (B2_OFF_LUTLL + (4 << B2_TB_LL))
+#define B2_OFF_SORTLL (B2_OFF_LUTD + (4 << B2_TB_D))
+#define B2_OFF_SORTD (B2_OFF_SORTLL + 576)
+#define B2_OFF_METALL (B2_OFF_SORTD + 64)
+#define B2_OFF_METAD (B2_OFF_METALL + 96)
+#define B2_OFF_WIN (B2_OFF_METAD + 96)
+#define B2_LDS (B2_OFF_WIN + 512)
+// LUT entry: bits 0-3 code length, 4-7 number of extra bits, 8-23 base value (literal byte / base length / base distance /
+// raw symbol), 28-31 kind: 0 literal (or plain symbol), 1 length, 2 end of block; 0xffffffff = longer code or unused.
+#define B2_ESC 0xffffffffu
+#define B2_KIND_LEN (1u << 28)
+#define B2_KIND_EOB (2u << 28)
+enum { B2_MODE_RAW = 0, B2_MODE_LL = 1, B2_MODE_DIST = 2 };
+enum { B2_OK = 0, B2_E_BTYPE = 1, B2_E_STORED = 2, B2_E_TABLE = 3, B2_E_SYMBOL = 4, B2_E_DIST = 5, B2_E_OVERRUN = 6, B2_E_INPUT = 7, B2_E_SIZE = 8 };
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned b2_rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned b2_rl(unsigned v, unsigned lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)lane); }
+
+__constant__ unsigned char b2_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ unsigned b2_entry(int mode, unsigned sym, unsigned l) {
+    if (mode == B2_MODE_RAW) return (sym << 8) | l;
+    if (mode == B2_MODE_LL) {
+        if (sym < 256) return (sym << 8) | l;
+        if (sym == 256) return B2_KIND_EOB | l;
+        const unsigned lc = sym - 257;
+        if (lc > 28) return B2_ESC;
+        unsigned eb = 0, base = 3 + lc;
+        if (lc == 28) base = 258;
+        else if (lc >= 8) {
+            eb = (lc - 4) >> 2;
+            base = 3 + ((4 + (lc & 3)) << eb);
+        }
+        return B2_KIND_LEN | (base << 8) | (eb << 4) | l;
+    }
+    if (sym > 29) return B2_ESC;
+    unsigned eb = 0, base = 1 + sym;
+    if (sym >= 4) {
+        eb = (sym >> 1) - 1;
+        base = 1 + ((2 + (sym & 1)) << eb);
+    }
+    return (base << 8) | (eb << 4) | l;
+}
+
+// Canonical Huffman tables from `n` code lengths in LDS (lane k carries the state of code length k).
+__device__ __forceinline__ bool b2_build(const unsigned char *lens, int n, int tb, int mode, unsigned *lut, unsigned short *sorted,
+                                         unsigned short *meta, int lane) {
+    for (int i = lane; i < (1 << tb); i += 64) lut[i] = B2_ESC;
+    unsigned cntv = 0;
+#pragma nounroll
+    for (int c = 0; c < n; c += 64) {
+        const int s = c + lane;
+        const unsigned l = s < n ? lens[s] : 0;
+#pragma nounroll
+        for (int k = 1; k < 16; k++) {
+            const unsigned m = (unsigned)__popcll(__ballot(l == (unsigned)k));
+            cntv += lane == k ? m : 0;
+        }
+    }
+    int left = 1;
+    bool over = false;
+    unsigned code = 0, o = 0, prev = 0, firstv = 0, offv = 0;
+#pragma nounroll
+    for (int k = 1; k < 16; k++) {
+        const unsigned ck = b2_rl(cntv, k);
+        left = (left << 1) - (int)ck;
+        over = over || left < 0;
+        code = (code + prev) << 1;
+        firstv = lane == k ? code : firstv;
+        offv = lane == k ? o : offv;
+        o += ck;
+        prev = ck;
+    }
+    if (over) return false;
+    if (lane < 16) {
+        meta[lane] = (unsigned short)firstv;
+        meta[16 + lane] = (unsigned short)cntv;
+        meta[32 + lane] = (unsigned short)offv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    unsigned runv = offv;
+    const u64 below = (1ull << lane) - 1ull;
+#pragma nounroll
+    for (int c = 0; c < n; c += 64) {
+        const int s = c + lane;
+        const unsigned l = s < n ? lens[s] : 0;
+        unsigned rank = 0;
+#pragma nounroll
+        for (int k = 1; k < 16; k++) {
+            const u64 m = __ballot(l == (unsigned)k);
+            const unsigned rk = b2_rl(runv, k);
+            rank = l == (unsigned)k ? rk + (unsigned)__popcll(m & below) : rank;
+            runv += lane == k ? (unsigned)__popcll(m) : 0;
+        }
+        if (l) {
+            sorted[rank] = (unsigned short)s;
+            if ((int)l <= tb) {
+                const unsigned fc = (unsigned)meta[l] + (rank - (unsigned)meta[32 + l]);
+                const unsigned rev = __brev(fc) >> (32 - l);
+                const unsigned e = b2_entry(mode, (unsigned)s, l);
+                for (unsigned k = rev; k < (1u << tb); k += 1u << l) lut[k] = e;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// code longer than the LUT: canonical walk over lengths tb+1..15 (uniform).  -> LUT entry, B2_ESC if no code matches
+__device__ __noinline__ unsigned b2_long_code(unsigned bits, int tb, int mode, const unsigned short *sorted, const unsigned short *meta) {
+#pragma nounroll
+    for (int l = tb + 1; l <= 15; l++) {
+        const unsigned code = __brev(bits & ((1u << l) - 1u)) >> (32 - l);
+        const unsigned f = b2_rfl(meta[l]), c = b2_rfl(meta[16 + l]);
+        if (code - f < c) {
+            const unsigned sym = b2_rfl(sorted[b2_rfl(meta[32 + l]) + code - f]);
+            return b2_entry(mode, sym, (unsigned)l);
+        }
+    }
+    return B2_ESC;
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: Hillis-Steele inside each row of 16, then the two row broadcasts)
+__device__ __forceinline__ unsigned b2_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// 64 stream bits starting `q` bits into the stream, gathered from the LDS ring (any lane, any q inside the staged windows)
+__device__ __forceinline__ u64 b2_bits_at(const unsigned *win, unsigned q) {
+    const unsigned d = q >> 5, s = q & 31;
+    const unsigned a = win[d & 127], b = win[(d + 1) & 127], c = win[(d + 2) & 127];
+    const unsigned lo = __builtin_amdgcn_alignbit(b, a, s), hi = __builtin_amdgcn_alignbit(c, b, s);
+    return ((u64)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(64 * B2_WAVES) void bgzf_inflate_lanes(const unsigned char *__restrict__ comp, const BzDesc *__restrict__ blocks,
+                                                                    int nblocks, unsigned char *__restrict__ out,
+                                                                    unsigned *__restrict__ status) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[B2_WAVES][B2_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wv = (int)b2_rfl(threadIdx.x >> 6);
+    const int b = blockIdx.x * B2_WAVES + wv;
+    if (b >= nblocks) return;
+    unsigned char *lds = lds_all[wv];
+    unsigned char *lens = lds;
+    unsigned *lut_ll = (unsigned *)(lds + B2_OFF_LUTLL), *lut_d = (unsigned *)(lds + B2_OFF_LUTD);
+    unsigned short *sorted_ll = (unsigned short *)(lds + B2_OFF_SORTLL), *sorted_d = (unsigned short *)(lds + B2_OFF_SORTD);
+    unsigned short *meta_ll = (unsigned short *)(lds + B2_OFF_METALL), *meta_d = (unsigned short *)(lds + B2_OFF_METAD);
+    unsigned *win = (unsigned *)(lds + B2_OFF_WIN);
+
+    const BzDesc D = blocks[b];
+    const unsigned isize = D.isize, in_len = D.in_len;
+    unsigned char *const dst = out + D.out_off;
+    const unsigned *const base = (const unsigned *)(comp + (D.in_off & ~3ull));
+    const unsigned lead = (unsigned)(D.in_off & 3ull);
+    const unsigned end_bit = (lead + in_len) * 8;               // first bit past the payload
+    unsigned bp = lead * 8;                                     // stream position in bits from `base`
+    unsigned cw = 0;                                            // windows cw and cw+1 are staged (window w in ring half w & 1)
+    unsigned err = B2_OK;
+    unsigned op = 0;
+
+    win[lane] = base[lane];
+    win[64 + lane] = base[64 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+// keep the windows that hold bp .. bp + 160 bits staged; a position beyond the payload ends the decode (sticky error)
+#define B2_ENSURE()                                                                       \
+    do {                                                                                  \
+        const unsigned w_ = bp >> 11;                                                     \
+        if (w_ != cw) {                                                                   \
+            if (bp > end_bit + 64) err = B2_E_INPUT;                                      \
+            else {                                                                        \
+                __builtin_amdgcn_wave_barrier();                                          \
+                if (w_ != cw + 1) win[(w_ & 1) * 64 + lane] = base[(size_t)w_ * 64 + lane]; \
+                win[((w_ + 1) & 1) * 64 + lane] = base[(size_t)(w_ + 1) * 64 + lane];     \
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                    \
+                __builtin_amdgcn_wave_barrier();                                          \
+            }                                                                             \
+            cw = w_;                                                                      \
+        }                                                                                 \
+    } while (0)
+
+    bool last = false;
+    while (!last && err == B2_OK) {
+        u64 hb;
+        {
+            const unsigned d = bp >> 5, s = bp & 31;
+            hb = (((u64)b2_rfl(win[(d + 1) & 127]) << 32) | b2_rfl(win[d & 127])) >> s;
+        }
+        last = hb & 1;
+        const unsigned btype = (unsigned)(hb >> 1) & 3;
+        bp += 3;
+        if (btype == 0) {  // stored: byte-align, LEN, NLEN, raw bytes straight from the compressed buffer
+            bp = (bp + 7) & ~7u;
+            B2_ENSURE();
+            const unsigned d = bp >> 5, s = bp & 31;
+            const u64 v = (((u64)b2_rfl(win[(d + 1) & 127]) << 32) | b2_rfl(win[d & 127])) >> s;
+            const unsigned len = (unsigned)v & 0xffff, nlen = (unsigned)(v >> 16) & 0xffff;
+            bp += 32;
+            if ((len ^ nlen) != 0xffff) {
+                err = B2_E_STORED;
+                break;
+            }
+            if (op + len > isize || bp / 8 + len > lead + in_len) {
+                err = B2_E_OVERRUN;
+                break;
+            }
+            const unsigned char *src = (const unsigned char *)base + bp / 8;
+            for (unsigned i = lane; i < len; i += 64) dst[op + i] = src[i];
+            op += len;
+            bp += len * 8;
+            B2_ENSURE();
+            continue;
+        }
+        if (btype == 3) {
+            err = B2_E_BTYPE;
+            break;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (btype == 1) {  // fixed code: lengths per RFC 1951 3.2.6
+            for (int s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 32) lens[288 + lane] = lane < 30 ? 5 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {  // dynamic code: HLIT, HDIST, HCLEN, the code-length code, then the run-length coded lengths
+            B2_ENSURE();
+            unsigned hlit, hdist, hclen;
+            {
+                const unsigned d = bp >> 5, s = bp & 31;
+                const u64 v = (((u64)b2_rfl(win[(d + 1) & 127]) << 32) | b2_rfl(win[d & 127])) >> s;
+                hlit = ((unsigned)v & 31) + 257;
+                hdist = ((unsigned)(v >> 5) & 31) + 1;
+                hclen = ((unsigned)(v >> 10) & 15) + 4;
+                bp += 14;
+            }
+            if (hlit > 286 || hdist > 30) {
+                err = B2_E_TABLE;
+                break;
+            }
+            {   // 3 bits per code-length-code length: lane i reads its own field
+                const unsigned q = bp + 3 * (unsigned)lane;
+                const unsigned v = (unsigned)b2_bits_at(win, (unsigned)lane < hclen ? q : bp) & 7;
+                if (lane < 19) lens[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                if ((unsigned)lane < hclen) lens[b2_clorder[lane]] = (unsigned char)v;
+                bp += 3 * hclen;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            B2_ENSURE();
+            if (!b2_build(lens, 19, 7, B2_MODE_RAW, lut_d, sorted_d, meta_d, lane)) {
+                err = B2_E_TABLE;
+                break;
+            }
+            unsigned n = 0, prev = 0;
+            const unsigned total = hlit + hdist;
+            unsigned char *tmp = (unsigned char *)lut_ll;         // lens[0..19) is still in use: decode here, move afterwards
+            while (n < total && err == B2_OK) {
+                const unsigned d = bp >> 5, s = bp & 31;
+                const u64 v = (((u64)b2_rfl(win[(d + 1) & 127]) << 32) | b2_rfl(win[d & 127])) >> s;   // >= 33 bits: two symbols at most 14 each
+                const unsigned e = b2_rfl(lut_d[(unsigned)v & 127]);
+                if (e == B2_ESC) {
+                    err = B2_E_TABLE;
+                    break;
+                }
+                const unsigned l = e & 15, sym = e >> 8;
+                unsigned rep = 1, val = sym, used = l;
+                if (sym == 16) {
+                    if (n == 0) {
+                        err = B2_E_TABLE;
+                        break;
+                    }
+                    val = prev;
+                    rep = 3 + ((unsigned)(v >> l) & 3);
+                    used += 2;
+                } else if (sym == 17) {
+                    val = 0;
+                    rep = 3 + ((unsigned)(v >> l) & 7);
+                    used += 3;
+                } else if (sym == 18) {
+                    val = 0;
+                    rep = 11 + ((unsigned)(v >> l) & 127);
+                    used += 7;
+                }
+                if (n + rep > total) {
+                    err = B2_E_TABLE;
+                    break;
+                }
+                for (unsigned i = lane; i < rep; i += 64) tmp[n + i] = (unsigned char)val;
+                n += rep;
+                prev = val;
+                bp += used;
+                B2_ENSURE();
+            }
+            if (err != B2_OK) break;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                unsigned char v[5], dv = 0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const unsigned s = (unsigned)(k * 64 + lane);
+                    v[k] = s < hlit ? tmp[s] : 0;
+                }
+                if (lane < 32) dv = (unsigned)lane < hdist ? tmp[hlit + lane] : 0;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const unsigned s = (unsigned)(k * 64 + lane);
+                    if (s < 288) lens[s] = v[k];
+                }
+                if (lane < 32) lens[288 + lane] = dv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (b2_rfl(lens[256]) == 0) {
+                err = B2_E_TABLE;
+                break;
+            }
+        }
+        if (!b2_build(lens, 288, B2_TB_LL, B2_MODE_LL, lut_ll, sorted_ll, meta_ll, lane) ||
+            !b2_build(lens + 288, 32, B2_TB_D, B2_MODE_DIST, lut_d, sorted_d, meta_d, lane)) {
+            err = B2_E_TABLE;
+            break;
+        }
+        // ---- the symbols of this block, a window of 64 bit offsets at a time
+        for (;;) {
+            // every lane: the symbol that would start at bit bp + lane
+            const u64 bits = b2_bits_at(win, bp + (unsigned)lane);
+            const unsigned e1 = lut_ll[(unsigned)bits & ((1u << B2_TB_LL) - 1)];
+            const unsigned l1 = e1 & 15, eb1 = (e1 >> 4) & 15, base1 = (e1 >> 8) & 0xffff, kind = e1 >> 28;
+            const bool is_len = kind == 1, is_lit = kind == 0;
+            const unsigned c1 = l1 + eb1;
+            const unsigned mlen = base1 + ((unsigned)(bits >> l1) & ((1u << eb1) - 1));
+            const u64 bits2 = bits >> c1;
+            const unsigned e2 = lut_d[(unsigned)bits2 & ((1u << B2_TB_D) - 1)];
+            const unsigned l2 = e2 & 15, eb2 = (e2 >> 4) & 15, base2 = (e2 >> 8) & 0xffff;
+            const unsigned dist = base2 + ((unsigned)(bits2 >> l2) & ((1u << eb2) - 1));
+            // next[i], with the two ways a chain ends folded in so the walk needs no second lookup:
+            // 128 + i = the code at bit i is longer than the LUT, 192 + (bit after it) = end of block
+            const bool slow = e1 == B2_ESC || (is_len && e2 == B2_ESC);
+            unsigned nxt = (unsigned)lane + (is_len ? c1 + l2 + eb2 : l1);
+            nxt = kind == 2 ? 192u + nxt : nxt;
+            nxt = slow ? 128u + (unsigned)lane : nxt;
+            // the true chain of symbol starts (scalar: one readlane per symbol)
+            unsigned cur = 0;
+            u64 chain = 0;
+            while (cur < 64) {
+                chain |= 1ull << cur;
+                cur = b2_rl(nxt, cur);
+            }
+            unsigned stop = 0;                                      // 1 = a long code sits at bit cur, 2 = end of block
+            if (cur >= 192) {
+                stop = 2;
+                cur -= 192;
+            } else if (cur >= 128) {
+                stop = 1;
+                cur -= 128;
+                chain &= ~(1ull << cur);
+            }
+            const bool on = (chain >> lane) & 1;
+            const unsigned ol = on ? (is_lit ? 1u : is_len ? mlen : 0u) : 0u;
+            const unsigned incl = b2_scan(ol);
+            const unsigned tot = b2_rl(incl, 63);
+            const unsigned pos = op + incl - ol;
+            const bool copy = on && is_len;
+            if (op + tot > isize || __ballot(copy && dist > pos)) {
+                err = op + tot > isize ? B2_E_OVERRUN : B2_E_DIST;
+                break;
+            }
+            if (on && is_lit) dst[pos] = (unsigned char)base1;
+            const unsigned srco = pos - dist;                       // first source byte of this lane's match
+            // Matches whose source lies wholly before this window's output cannot depend on anything decoded in it: each of
+            // those is copied by its own lane, all at once (3 bytes unconditionally — the minimum match — then the rest).
+            const bool par = copy && srco + mlen <= op && mlen <= 16;
+            if (par) {
+                const unsigned char b0 = dst[srco], b1 = dst[srco + 1], b2 = dst[srco + 2];
+                dst[pos] = b0;
+                dst[pos + 1] = b1;
+                dst[pos + 2] = b2;
+            }
+            for (unsigned k = 3; __ballot(par && k < mlen); k++)
+                if (par && k < mlen) dst[pos + k] = dst[srco + k];
+            u64 mm = __ballot(copy && !par);
+            while (mm) {                                            // the others in stream order (they may read each other's output)
+                const unsigned l = (unsigned)__builtin_ctzll(mm);
+                mm &= ~(1ull << l);
+                const unsigned len = b2_rl(mlen, l), dd = b2_rl(dist, l), p = b2_rl(pos, l), so = b2_rl(srco, l);
+                unsigned i = (unsigned)lane;
+                do {
+                    const unsigned j = dd >= len ? i : i % dd;      // a distance shorter than the match repeats its source
+                    if (i < len) dst[p + i] = dst[so + j];
+                    i += 64;
+                } while (i - (unsigned)lane < len);
+            }
+            if (err != B2_OK) break;
+            op += tot;
+            bp += cur;
+            if (bp > end_bit) {                                     // a valid block ends (EOB included) inside the payload
+                err = B2_E_INPUT;
+                break;
+            }
+            B2_ENSURE();
+            if (err != B2_OK || stop == 2) break;
+            if (stop == 1) {  // one symbol whose code is longer than the LUT: scalar canonical walk
+                const unsigned d = bp >> 5, s = bp & 31;
+                const unsigned w0 = b2_rfl(win[d & 127]), w1 = b2_rfl(win[(d + 1) & 127]), w2 = b2_rfl(win[(d + 2) & 127]);
+                u64 v = ((u64)__builtin_amdgcn_alignbit(w2, w1, s) << 32) | __builtin_amdgcn_alignbit(w1, w0, s);
+                unsigned e = b2_rfl(lut_ll[(unsigned)v & ((1u << B2_TB_LL) - 1)]);
+                if (e == B2_ESC) e = b2_long_code((unsigned)v, B2_TB_LL, B2_MODE_LL, sorted_ll, meta_ll);
+                if (e == B2_ESC) {
+                    err = B2_E_SYMBOL;
+                    break;
+                }
+                unsigned used = e & 15;
+                v >>= used;
+                if (e < B2_KIND_LEN) {
+                    if (op >= isize) {
+                        err = B2_E_OVERRUN;
+                        break;
+                    }
+                    dst[op] = (unsigned char)(e >> 8);
+                    op++;
+                } else if (e >= B2_KIND_EOB) {
+                    bp += used;
+                    B2_ENSURE();
+                    break;
+                } else {
+                    unsigned eb = (e >> 4) & 15;
+                    const unsigned len = ((e >> 8) & 0xffff) + ((unsigned)v & ((1u << eb) - 1));
+                    v >>= eb;
+                    used += eb;
+                    unsigned ed = b2_rfl(lut_d[(unsigned)v & ((1u << B2_TB_D) - 1)]);
+                    if (ed == B2_ESC) ed = b2_long_code((unsigned)v, B2_TB_D, B2_MODE_DIST, sorted_d, meta_d);
+                    if (ed == B2_ESC) {
+                        err = B2_E_DIST;
+                        break;
+                    }
+                    v >>= ed & 15;
+                    eb = (ed >> 4) & 15;
+                    const unsigned dd = ((ed >> 8) & 0xffff) + ((unsigned)v & ((1u << eb) - 1));
+                    used += (ed & 15) + eb;
+                    if (dd > op || op + len > isize) {
+                        err = dd > op ? B2_E_DIST : B2_E_OVERRUN;
+                        break;
+                    }
+                    const unsigned char *src = dst + op - dd;
+                    for (unsigned i = lane; i < len; i += 64) dst[op + i] = src[dd >= len ? i : i % dd];
+                    op += len;
+                }
+                bp += used;
+                B2_ENSURE();
+                if (err != B2_OK) break;
+            }
+        }
+    }
+    if (err == B2_OK && op != isize) err = B2_E_SIZE;
+    if (err == B2_OK && bp > end_bit + 7) err = B2_E_INPUT;
+    if (lane == 0) status[b] = err;
+#undef B2_ENSURE
+}
+
+void tdt_bz_launch_lanes(hipStream_t st, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,
+                         unsigned *d_status) {
+    const unsigned grid = (unsigned)((nblocks + B2_WAVES - 1) / B2_WAVES);
+    hipLaunchKernelGGL(bgzf_inflate_lanes, dim3(grid), dim3(64 * B2_WAVES), 0, st, d_comp, d_blocks, (int)nblocks, d_out, d_status);
+}
