@@ -50,9 +50,13 @@ def _cases():
     }
 
 
+@pytest.mark.parametrize("kernel", ["lanes", "sequential"])
 @pytest.mark.parametrize("name", list(_cases()))
-def test_device_inflate_matches_zlib(ctx, name):
-    """stored / fixed / dynamic DEFLATE blocks, long codes, overlapping matches, 0..64 KiB blocks; CRC32 checked on the device"""
+def test_device_inflate_matches_zlib(ctx, name, kernel, monkeypatch):
+    """stored / fixed / dynamic DEFLATE blocks, long codes, overlapping matches, 0..64 KiB blocks; CRC32 checked on the device.
+    Both kernels: the lane-parallel default (tdt_inflate2.hip) and the one-symbol-at-a-time one (TIDDIT_INFLATE_SEQ=1)."""
+    if kernel == "sequential":
+        monkeypatch.setenv("TIDDIT_INFLATE_SEQ", "1")
     data = _cases()[name]
     for level in (0, 1, 6, 9):
         assert _inflate_hbm(ctx, _bgzf(data, level), len(data)) == data, (name, level)

@@ -552,7 +552,7 @@ int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blo
     TDT_HIP(hipMemsetAsync(d_summary, 0xff, 4, st));
     TDT_HIP(hipMemsetAsync(d_summary + 1, 0, 4, st));
     const unsigned grid = (unsigned)((nblocks + BZ_WAVES - 1) / BZ_WAVES);
-    static const bool sequential = getenv("TIDDIT_INFLATE_SEQ") != nullptr;   // the one-symbol-at-a-time kernel of this file
+    const bool sequential = getenv("TIDDIT_INFLATE_SEQ") != nullptr;   // the one-symbol-at-a-time kernel of this file
     if (sequential) hipLaunchKernelGGL(bgzf_inflate, dim3(grid), dim3(64 * BZ_WAVES), 0, st, d_comp, d_blocks, (int)nblocks, d_out, d_status);
     else tdt_bz_launch_lanes(st, d_comp, d_blocks, nblocks, d_out, d_status);
     TDT_CHECK_LAUNCH();

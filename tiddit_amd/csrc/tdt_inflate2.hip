@@ -11,15 +11,24 @@
 //   * input: the compressed stream is staged through a 512-byte LDS ring (two 256-byte windows, one coalesced load each);
 //     lanes gather their three dwords from it;
 //   * tables: canonical Huffman LUTs in LDS, 32-bit entries with RFC 1951's base value / extra-bit count folded in
-//     (10 bits literal/length, 9 bits distance); a symbol whose code is longer than the LUT stops the chain and is decoded
+//     (9 bits literal/length, 8 bits distance); a symbol whose code is longer than the LUT stops the chain and is decoded
 //     by the scalar canonical walk;
 //   * every loop is bounded by ISIZE / the compressed length; damage sets the block's status.
 #include "tdt_common.h"
 
-#define B2_TB_LL 10
-#define B2_TB_D 9
+// LUT widths and the occupancy target: 9/8 bits keep a wave's LDS at 4.7 KB and, with registers held to 64, eight waves per
+// SIMD — measured 40 ms per 1.94 GB against 51 ms for 10/9 bits at five waves (latency hiding beats the rarer long-code path)
+#ifndef B2_TB_LL
+#define B2_TB_LL 9
+#endif
+#ifndef B2_TB_D
+#define B2_TB_D 8
+#endif
+#ifndef B2_OCC
+#define B2_OCC 8
+#endif
 #define B2_WAVES 4
-// LDS bytes per wave: lens 320 | lut_ll 4096 | lut_d 2048 | sorted_ll 576 | sorted_d 64 | meta_ll 96 | meta_d 96 | ring 512
+// LDS bytes per wave: lens 320 | lut_ll 4 << TB_LL | lut_d 4 << TB_D | sorted_ll 576 | sorted_d 64 | meta_ll 96 | meta_d 96 | ring 512
 #define B2_OFF_LUTLL 320
 #define B2_OFF_LUTD (B2_OFF_LUTLL + (4 << B2_TB_LL))
 #define B2_OFF_SORTLL (B2_OFF_LUTD + (4 << B2_TB_D))
@@ -166,7 +175,7 @@ __device__ __forceinline__ u64 b2_bits_at(const unsigned *win, unsigned q) {
     return ((u64)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(64 * B2_WAVES) void bgzf_inflate_lanes(const unsigned char *__restrict__ comp, const BzDesc *__restrict__ blocks,
+__global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B2_OCC, 8))) void bgzf_inflate_lanes(const unsigned char *__restrict__ comp, const BzDesc *__restrict__ blocks,
                                                                     int nblocks, unsigned char *__restrict__ out,
                                                                     unsigned *__restrict__ status) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[B2_WAVES][B2_LDS];
