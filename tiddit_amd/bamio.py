@@ -461,7 +461,7 @@ class DeviceBamReader:
             import os
             from concurrent.futures import ThreadPoolExecutor
             fd, fsize, fo = self._f.fileno(), x_hi, b_lo           # this reader's byte range of the file
-            pool = ThreadPoolExecutor(4)
+            pool = ThreadPoolExecutor(int(os.environ.get("TIDDIT_READ_THREADS", "8")))
             try:
                 k, carry = 0, np.zeros(0, dtype=np.uint8)
                 eof = False

@@ -80,32 +80,45 @@ __global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__re
     else if (s0 > lo) p = s0;
     const bool forced = s0 >= lo && s0 < hi;                    // the first record's offset is known, not guessed
     const long long stop = hi < limit ? hi : limit;
-    for (; p < stop; p++) {
-        unsigned bs;
-        int rc = rec_check<true>(buf, p, T, n_ref, &bs);
-        if (rc == 2 && !forced) continue;
-        long long q = p;
-        unsigned n = 0;
-        while (rc == 0 && q < stop) {
-            q += 4 + (long long)bs;
-            n++;
-            if (q >= T) break;                                  // the batch ends exactly on a record boundary
-            if (q < stop) rc = rec_check<false>(buf, q, T, n_ref, &bs);
-            else rc = rec_check<true>(buf, q, T, n_ref, &bs);   // where the chain LANDS beyond the segment: must look like a record
-        }
-        if (rc != 2 || forced) {                                // chain ran to the segment end (or into the batch tail)
-            if (n == 0 && !forced) {                            // nothing complete: remember the first such offset, keep looking
-                if (!weak) {
-                    weak = true;
-                    f = e = (unsigned)p;
-                }
-                continue;
+    // Two phases per round so that the lanes of a wave stay in step: (A) every lane scans to its next candidate, (B) every
+    // lane follows its candidate's chain.  (One fused loop made each lane's chain run while the other 63 waited.)
+    bool done = p >= stop;
+    while (__any(!done)) {
+        unsigned bs = 0;
+        int rc = 2;
+        if (!done) {                                            // (A) next offset that passes the deep check (or the forced one)
+            for (; p < stop; p++) {
+                rc = rec_check<true>(buf, p, T, n_ref, &bs);
+                if (rc != 2 || forced) break;
             }
-            f = (unsigned)p;
-            e = (unsigned)q;
-            c = n;
-            if (forced && rc == 2) f = ING_NONE - 1;            // corrupt record on the true chain: never matches the walk
-            break;
+            if (p >= stop) done = true;
+        }
+        if (!done) {                                            // (B) its chain to the end of the segment
+            long long q = p;
+            unsigned n = 0;
+            while (rc == 0 && q < stop) {
+                q += 4 + (long long)bs;
+                n++;
+                if (q >= T) break;                              // the batch ends exactly on a record boundary
+                if (q < stop) rc = rec_check<false>(buf, q, T, n_ref, &bs);
+                else rc = rec_check<true>(buf, q, T, n_ref, &bs);   // where the chain LANDS beyond the segment: must look like a record
+            }
+            if (rc != 2 || forced) {                            // chain ran to the segment end (or into the batch tail)
+                if (n == 0 && !forced) {                        // nothing complete: remember the first such offset, keep looking
+                    if (!weak) {
+                        weak = true;
+                        f = e = (unsigned)p;
+                    }
+                    p++;
+                } else {
+                    f = (unsigned)p;
+                    e = (unsigned)q;
+                    c = n;
+                    if (forced && rc == 2) f = ING_NONE - 1;    // corrupt record on the true chain: never matches the walk
+                    done = true;
+                }
+            } else p++;
+            if (p >= stop) done = true;
         }
     }
     first[g] = f;
