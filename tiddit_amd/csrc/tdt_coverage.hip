@@ -215,7 +215,7 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
 
     auto contribute = [&](int bin, unsigned long long v) {
         const unsigned off = (unsigned)(bin - base);
-#ifdef COV_EXP_NOATOMIC
+#ifdef COV_EXP_NOATOMIC  // measurement variant (tools/build_variant.sh): everything but the LDS atomics — DESIGN.md §3.1 ceilings
         if (v == 0x1234567ull) win[0] = v;
 #else
         if (off < COV_WIN) atomicAdd(&win[off], v);  // ds_add_u64 (bins past the contig end only ever see +x and -x)
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         const int K = cov_div(sv[0] < 0 ? 0 : sv[0], P.magic, P.shift);
         const unsigned Kz = (unsigned)K * z;
         unsigned long long a0 = 0, a1 = 0, a2 = 0;
-#ifdef COV_EXP_LOADONLY
+#ifdef COV_EXP_LOADONLY  // measurement variant: the loads alone (the 0.79 "load-only" ceiling quoted in DESIGN.md §3.1)
         for (int j = 0; j < COV_RPL; j++) a0 += (unsigned)(sv[j] + ev[j]) + mq[j] + fl[j];
         if (a0 == 0x1234567ull) contribute(K, a0);
         cur = nxt;
