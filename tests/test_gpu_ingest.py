@@ -301,3 +301,40 @@ def test_cli_cov_unsorted_bam_device_equals_host(tmp_path, monkeypatch):
         cli.run_cov(cli._cov_parser().parse_args(["--cov", "--bam", path, "-o", o, "-z", "1000", "-q", "10"]))
         outs[mode] = open(o + ".bed").read()
     assert outs["0"] == outs["1"] and len(outs["0"]) > 1000
+
+
+@pytest.mark.parametrize("kernel", ["lanes", "sequential"])
+def test_device_inflate_damage_fuzz(ctx, kernel, monkeypatch):
+    """random bit flips, smashed bytes, zeroed tails and 0xff runs inside BGZF payloads: every damaged stream is rejected
+    (decode error or CRC32), nothing hangs, and the context still works afterwards (tools/fuzz_inflate_gpu.py runs more)"""
+    if kernel == "sequential":
+        monkeypatch.setenv("TIDDIT_INFLATE_SEQ", "1")
+    rng = np.random.default_rng(99)
+    cases = _cases()
+    srcs = [cases["skew"], cases["text"], cases["dna"]]
+    rejected = 0
+    for it in range(60):
+        data = srcs[it % 3]
+        comp = bytearray(_bgzf(data, (1, 6, 9)[it % 3]))
+        spans, o = [], 0
+        while o < len(comp) - 28:
+            bs = struct.unpack_from("<H", comp, o + 16)[0] + 1
+            spans.append((o + 18, bs - 26))
+            o += bs
+        for _ in range(1 + it % 4):
+            so, n = spans[int(rng.integers(0, len(spans)))]
+            p = so + int(rng.integers(0, n))
+            if it % 4 == 0:
+                comp[p] ^= 1 << int(rng.integers(0, 8))
+            elif it % 4 == 1:
+                comp[p:p + 8] = bytes(rng.integers(0, 256, len(comp[p:p + 8]), dtype=np.uint8))
+            elif it % 4 == 2:
+                comp[p:so + n] = bytes(so + n - p)
+            else:
+                comp[p:min(p + 64, so + n)] = b"\xff" * (min(p + 64, so + n) - p)
+        try:
+            assert _inflate_hbm(ctx, bytes(comp), len(data)) == data      # a harmless flip must still give the right bytes
+        except _native.TdtError:
+            rejected += 1
+    assert rejected >= 55
+    assert _inflate_hbm(ctx, _bgzf(srcs[1], 6), len(srcs[1])) == srcs[1]
