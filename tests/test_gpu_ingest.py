@@ -338,3 +338,39 @@ def test_device_inflate_damage_fuzz(ctx, kernel, monkeypatch):
             rejected += 1
     assert rejected >= 55
     assert _inflate_hbm(ctx, _bgzf(srcs[1], 6), len(srcs[1])) == srcs[1]
+
+
+def test_device_ingest_rejects_damaged_records(ctx, tmp_path):
+    """valid BGZF around a damaged BAM record: the device reader fails like the host decoder does (no crash, no garbage)"""
+    path = str(tmp_path / "ok.bam")
+    synth_bam.write_synthetic_bam(path, [("chr1", 120000), ("chr2", 50000)], depth=6, seed=8)
+    raw = b"".join(bamio.bgzf_blocks(open(path, "rb")))
+    hdr = bamio.BamReader(path)
+    skip = hdr.header_bytes
+    hdr.close()
+    offs, o = [], skip
+    while o + 4 <= len(raw):
+        offs.append(o)
+        o += 4 + struct.unpack_from("<I", raw, o)[0]
+    for what in ("block_size", "l_seq", "n_cigar"):
+        dmg = bytearray(raw)
+        r = offs[len(offs) // 2]
+        if what == "block_size":
+            struct.pack_into("<I", dmg, r, 7)
+        elif what == "l_seq":
+            struct.pack_into("<i", dmg, r + 4 + 16, -5)
+        else:
+            struct.pack_into("<H", dmg, r + 4 + 12, 60000)
+        bad = str(tmp_path / (what + ".bam"))
+        with open(bad, "wb") as f:
+            for k in range(0, len(dmg), 0xff00):
+                f.write(bamio._bgzf_block(bytes(dmg[k:k + 0xff00]), 1))
+            f.write(bamio._BGZF_EOF)
+        for make in (lambda: bamio.BamReader(bad), lambda: bamio.DeviceBamReader(bad, ctx=ctx), lambda: bamio.DeviceBamReader(bad, ctx=ctx, chunk=100_000)):
+            with pytest.raises((_native.TdtError, ValueError)):
+                rd = make()
+                for _ in rd.batches():
+                    pass
+    rd = bamio.DeviceBamReader(path, ctx=ctx)                         # the context is still healthy
+    assert sum(len(b) for b in rd.batches()) == len(offs)
+    rd.close()

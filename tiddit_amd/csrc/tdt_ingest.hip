@@ -434,6 +434,18 @@ extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_
                 return TDT_E_ARG;
             }
             if (cur + 4 + (size_t)bs > T) break;
+            {   // the same consistency test as tdt_bam_decode: the field kernel walks CIGAR / aux inside [record, record + bs)
+                const unsigned char *r = raw.data() + cur + 4;
+                int32_t lseq;
+                uint16_t ncig;
+                memcpy(&lseq, r + 16, 4);
+                memcpy(&ncig, r + 12, 2);
+                const size_t var = 32 + (size_t)r[8] + 4 * (size_t)ncig + ((size_t)(lseq < 0 ? 0 : lseq) + 1) / 2 + (size_t)(lseq < 0 ? 0 : lseq);
+                if (lseq < 0 || var > bs) {
+                    tdt_set_error("tdt_ingest_push: record %zu is inconsistent (fixed + variable fields exceed block_size %u)", n, bs);
+                    return TDT_E_ARG;
+                }
+            }
             const int s = (int)(cur / ING_SEG);
             if (h_first[s] == ING_NONE) {
                 h_first[s] = (unsigned)cur;
