@@ -196,6 +196,9 @@ int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
  * the header (exact), so agreement at every seam makes the whole decode exact.  A bounded push ends the stream. */
 int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records,
                             size_t *first_off, size_t *next_off);
+/* Optional overlap: start the host-to-device copy of the NEXT span (pinned memory) on the copy stream; the next push of
+ * exactly this (pointer, len) finds it there, so the transfer hides behind the kernels of the push issued in between. */
+int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t len);
 int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len);
 int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n);
 int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);

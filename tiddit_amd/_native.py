@@ -68,6 +68,7 @@ SYMBOLS = {
     "tdt_ingest_destroy": (_i, [_P]),
     "tdt_ingest_push": (_i, [_P, _P, _sz, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_push_bounded": (_i, [_P, _P, _sz, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "tdt_ingest_prefetch": (_i, [_P, _P, _sz]),
     "tdt_ingest_arrays": (_i, [_P, _PP, ctypes.POINTER(_sz)]),
     "tdt_ingest_edges": (_i, [_P, _P, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),

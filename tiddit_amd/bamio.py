@@ -444,7 +444,7 @@ class DeviceBamReader:
         chunk = self.chunk
         b_lo, x_hi = self._b_lo, self._x_hi
         chunk = max(1 << 16, min(chunk, x_hi - b_lo))
-        bufs = [torch.empty(chunk + (2 << 20), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(3)]
+        bufs = [torch.empty(chunk + (2 << 20), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(4)]   # in use, prefetched, queued, being read
         q = queue.Queue(maxsize=1)
         stop = self._stop
 
@@ -466,7 +466,7 @@ class DeviceBamReader:
                 k, carry = 0, np.zeros(0, dtype=np.uint8)
                 eof = False
                 while True:
-                    buf = bufs[k % 3]
+                    buf = bufs[k % 4]
                     have = len(carry)
                     buf[:have] = carry
                     if not eof:                                  # parallel positional reads into the pinned buffer
@@ -504,17 +504,39 @@ class DeviceBamReader:
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        try:
-            while True:
-                item = q.get()
+
+        class Spans:
+            """blocking ``next()`` and non-blocking ``poll()`` over the reader thread's queue; None = end of range"""
+            done = False
+
+            def _take(self, item):
                 if item is None:
-                    break
+                    self.done = True
+                    stop.set()
+                    th.join()
+                    return None
                 if isinstance(item, BaseException):
+                    self.done = True
+                    stop.set()
                     raise item
-                yield item
-        finally:
-            stop.set()                                           # a consumer that stops early releases the reader thread
-            th.join()
+                return item
+
+            def next(self):
+                return None if self.done else self._take(q.get())
+
+            def poll(self):
+                if self.done:
+                    return None
+                try:
+                    return self._take(q.get_nowait())
+                except queue.Empty:
+                    return False                                  # nothing read yet
+
+            def close(self):
+                stop.set()                                        # a consumer that stops early releases the reader thread
+                th.join()
+
+        return Spans()
 
     def batches(self):
         lib, ctx = self.ctx.lib, self.ctx
@@ -523,7 +545,23 @@ class DeviceBamReader:
         nothing = ctypes.c_size_t(-1).value
         if self.shard is not None and self._b_lo >= self._b_hi:      # an empty shard: the seam passes straight through
             return
-        for buf, consumed, abs0 in self._spans():
+        spans = self._spans()
+        pending = False                                             # False: nothing looked at yet; None: end of the range
+        try:
+            yield from self._batches(spans, lib, ctx, nothing)
+        finally:
+            spans.close()
+
+    def _batches(self, spans, lib, ctx, nothing):
+        prev, first, pending = None, True, False
+        while True:
+            cur = spans.next() if pending is False else pending
+            if cur is None:
+                break
+            buf, consumed, abs0 = cur
+            pending = spans.poll()                                  # span k+1 already read?  start its PCIe copy now: it overlaps
+            if pending:                                             # the kernels of span k (never waits for the disk)
+                _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(pending[0]), pending[1]))
             if prev is not None:
                 prev._live = False
             n = ctypes.c_size_t(0)

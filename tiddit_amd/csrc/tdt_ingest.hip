@@ -220,6 +220,10 @@ struct tdt_ingest {
     tdt_ctx *ctx = nullptr;
     int n_ref = 0;
     tdt_buf comp, table, out, seg, soa;            // device buffers (grow only)
+    tdt_buf comp2;                                 // compressed blocks of the NEXT batch, filled by tdt_ingest_prefetch
+    const uint8_t *pf_host = nullptr;              // what comp2 holds: host pointer / length of the prefetched span
+    size_t pf_len = 0;
+    hipEvent_t pf_done = nullptr;
     tdt_buf pin;                                   // pinned staging for the segment table / edges
     size_t carry = 0, tail_off = 0;                // bytes of the partial record at out[tail_off..), moved to the front by the next push
     size_t out_len = 0;                            // carry + inflated bytes of the current batch
@@ -267,10 +271,33 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
     if (!g) return TDT_OK;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    for (tdt_buf *b : {&g->comp, &g->table, &g->out, &g->seg, &g->soa})
+    if (g->pf_done) (void)hipEventDestroy(g->pf_done);
+    (void)hipStreamSynchronize(g->ctx->copy_stream);
+    for (tdt_buf *b : {&g->comp, &g->comp2, &g->table, &g->out, &g->seg, &g->soa})
         if (b->p) (void)hipFree(b->p);
     if (g->pin.p) (void)hipHostFree(g->pin.p);
     delete g;
+    return TDT_OK;
+}
+
+// Start copying the NEXT span of blocks to the device on the context's copy stream; a following push of exactly this
+// (pointer, length) uses it instead of copying, so the transfer overlaps the kernels of the push in between.
+extern "C" int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t len) {
+    if (!g || !comp || !len) {
+        tdt_set_error("tdt_ingest_prefetch: bad argument");
+        return TDT_E_ARG;
+    }
+    tdt_ctx *ctx = g->ctx;
+    TDT_HIP(hipSetDevice(ctx->device));
+    const size_t comp_pad = (len + 4096 + 255) & ~(size_t)255;
+    int rc = ing_grow(g, g->comp2, comp_pad);
+    if (rc) return rc;
+    if (!g->pf_done) TDT_HIP(hipEventCreateWithFlags(&g->pf_done, hipEventDisableTiming));
+    TDT_HIP(hipMemcpyAsync(g->comp2.p, comp, len, hipMemcpyHostToDevice, ctx->copy_stream));
+    TDT_HIP(hipMemsetAsync((char *)g->comp2.p + len, 0, comp_pad - len, ctx->copy_stream));
+    TDT_HIP(hipEventRecord(g->pf_done, ctx->copy_stream));
+    g->pf_host = comp;
+    g->pf_len = len;
     return TDT_OK;
 }
 
@@ -319,11 +346,17 @@ extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_
         const size_t tab = (nb * sizeof(BzDesc) + 255) & ~(size_t)255, stb = (nb * 4 + 255) & ~(size_t)255;
         rc = ing_grow(g, g->table, tab + stb + 256);
         if (rc) return rc;
-        unsigned char *d_comp = (unsigned char *)g->comp.p;
         BzDesc *d_blocks = (BzDesc *)g->table.p;
         unsigned *d_status = (unsigned *)((char *)g->table.p + tab), *d_summary = (unsigned *)((char *)d_status + stb);
-        TDT_HIP(hipMemcpyAsync(d_comp, comp, len, hipMemcpyHostToDevice, st));
-        TDT_HIP(hipMemsetAsync(d_comp + len, 0, comp_pad - len, st));
+        if (g->pf_host == comp && g->pf_len == len && g->comp2.cap >= comp_pad) {
+            std::swap(g->comp, g->comp2);                         // the span is already on the device (copy stream)
+            TDT_HIP(hipStreamWaitEvent(st, g->pf_done, 0));
+        } else {
+            TDT_HIP(hipMemcpyAsync(g->comp.p, comp, len, hipMemcpyHostToDevice, st));
+            TDT_HIP(hipMemsetAsync((char *)g->comp.p + len, 0, comp_pad - len, st));
+        }
+        g->pf_host = nullptr;
+        unsigned char *d_comp = (unsigned char *)g->comp.p;
         TDT_HIP(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
         rc = tdt_bz_launch(ctx, d_comp, d_blocks, nb, d_out, true, d_status, d_summary);
         if (rc) return rc;

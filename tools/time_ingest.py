@@ -12,8 +12,12 @@ for rep in range(2):
     r = bamio.DeviceBamReader(path)
     t1 = time.perf_counter()
     n = 0
-    for buf, consumed, _abs in r._spans():
-        n += consumed
+    sp = r._spans()
+    while True:
+        item = sp.next()
+        if item is None:
+            break
+        n += item[1]
     t2 = time.perf_counter()
     r.close()
     print("open %.3f s; read spans only %.3f s (%.0f MB)" % (t1 - t0, t2 - t1, n / 1e6))
@@ -21,7 +25,12 @@ for rep in range(2):
     r = bamio.DeviceBamReader(path)
     tp = 0.0; k = 0; first = True
     t0 = time.perf_counter()
-    for buf, consumed, _abs in r._spans():
+    sp = r._spans()
+    while True:
+        item = sp.next()
+        if item is None:
+            break
+        buf, consumed, _abs = item
         ta = time.perf_counter()
         nn = ctypes.c_size_t(0)
         _native.check(lib.tdt_ingest_push(r._h, _native.ptr(buf), consumed, r._skip if first else 0, ctypes.byref(nn)))
