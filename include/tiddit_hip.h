@@ -154,6 +154,14 @@ int tdt_region_counts_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t
                              size_t n, int tid, int max_span, int64_t contig_length, const int32_t *d_q_start, const int32_t *d_q_end,
                              const int32_t *d_q_bp, size_t nq, int min_q, int64_t max_ins, int64_t *d_out);
 
+/* ---- coverage table text (host, threaded) ----------------------------------------------------------- *
+ * The row loop of print_coverage (tiddit_coverage.pyx:30-44) for one contig: kind 0 = bed rows
+ * `name \t 1+i*bin \t (i+1)*bin+1 \t value \n` (last row ends at contig_len), kind 1 = wig values, one per line.
+ * Values are written exactly like Python's `"{}".format(numpy.float64)`.  Two-call protocol: out == NULL returns the
+ * size in *out_len; then call again with a buffer of at least that many bytes. */
+int tdt_format_coverage(const double *values, size_t n, const char *name, int64_t bin_size, int64_t contig_len, int kind, char *out,
+                        size_t out_cap, size_t *out_len);
+
 /* ---- BGZF inflate (host, threaded) ---------------------------------------------------------------- *
  * Replaces pysam/htslib's block reader (`pysam.AlignmentFile(bam, "r", threads=n)`, tiddit_signal.pyx:159,
  * __main__.py:224).  tdt_bgzf_scan hops the block headers of `comp[0..len)`: it reports how many WHOLE blocks are

@@ -1,0 +1,54 @@
+"""The native coverage table writer (tdt_format_coverage, host code) against the reference's Python formatting
+(`"{}".format(numpy.float64)` rows of print_coverage, tiddit_coverage.pyx:30-44) — CPU only."""
+import ctypes
+
+import numpy as np
+
+from tiddit_amd import _native, build, tiddit_coverage
+
+
+def _native_rows(values, name, bin_size, ln, kind):
+    lib = _native.load()
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    size = ctypes.c_size_t(0)
+    _native.check(lib.tdt_format_coverage(_native.ptr(values), len(values), name.encode(), bin_size, ln, kind, None, 0, ctypes.byref(size)))
+    buf = np.empty(size.value + 1, dtype=np.uint8)
+    _native.check(lib.tdt_format_coverage(_native.ptr(values), len(values), name.encode(), bin_size, ln, kind, _native.ptr(buf), len(buf), ctypes.byref(size)))
+    return bytes(buf[:size.value]).decode()
+
+
+def test_repr_layout_matches_python_on_hard_values():
+    build.build()
+    rng = np.random.default_rng(3)
+    specials = [0.0, 1.0, 2.0, 10.0, 100.0, 0.5, 0.1, 0.30000001192092896, 0.0020000000949949026, 0.7226277589797974, 1e-4, 9.999e-5, 1e-5,
+                5e-324, 2.2250738585072014e-308, 1e15, 1e16, 9999999999999998.0, 1.2345678901234567e16, 123456789012345680.0, 1e21, 1e22, 1e100,
+                1.7976931348623157e308, 0.1 + 0.2, 1 / 3, 2 / 3, 1e-7, 123456.789, 4.35, 0.000123456, 1234567.0, 1e-310, float(2 ** 53),
+                float(2 ** 53 + 2), 33.333333333333336, 149.99999999999997, -0.0, -1.5, -2e-7, float("inf"), float("-inf"), float("nan")]
+    q32 = (rng.integers(0, 3000, 20000).astype(np.float32) / np.float32(500)).astype(np.float64)            # the quotients bins are made of
+    sums = np.cumsum(q32)                                                                                     # ... and sums of them
+    wide = np.exp(rng.uniform(-40, 40, 20000)) * rng.choice([1.0, 1.0, 1.0], 20000)
+    ints = rng.integers(0, 10 ** 17, 2000).astype(np.float64)
+    vals = np.concatenate([np.array(specials), q32, sums, wide, ints])
+    got = _native_rows(vals, "x", 7, 10, 1).split("\n")[:-1]
+    want = ["{}".format(v) for v in vals]
+    bad = [(w, g) for w, g in zip(want, got) if w != g]
+    assert not bad, bad[:5]
+    assert len(got) == len(vals)
+
+
+def test_bed_and_wig_rows_match_the_python_loop(tmp_path):
+    build.build()
+    rng = np.random.default_rng(4)
+    header = {"SQ": [{"SN": "chr1", "LN": 1_000_137}, {"SN": "HLA-A*01:01:01:01", "LN": 3503}, {"SN": "tiny", "LN": 20}]}
+    for z in (500, 50, 1, 977):
+        cov = {c["SN"]: np.cumsum(rng.integers(0, 400, -(-c["LN"] // z)).astype(np.float32) / np.float32(z)).astype(np.float64) % 97
+               for c in header["SQ"]}
+        for kind in ("bed", "wig"):
+            out = str(tmp_path / ("o.%s" % kind))
+            tiddit_coverage.print_coverage(cov, header, z, kind, out)
+            want = "#chromosome\tstart\tend\tcoverage\n" if kind == "bed" else "track type=wiggle_0 name=\"Coverage\" description=\"Per bin average coverage\"\n"
+            for c in header["SQ"]:
+                if kind == "wig":
+                    want += "fixedStep chrom={} start=1 step={}\n".format(c["SN"], z)
+                want += tiddit_coverage._rows_python(cov[c["SN"]], c["SN"], c["LN"], z, kind)
+            assert open(out).read() == want, (z, kind)

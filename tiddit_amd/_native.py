@@ -60,6 +60,7 @@ SYMBOLS = {
     "tdt_masked_medians": (_i, [_P, _P, _P, _P, _i, _P, _P, _P]),
     "tdt_region_counts": (_i, [_P] * 9 + [_sz, _i, _i64, _P, _P, _P, _sz, _i, _i64, _P]),
     "tdt_region_counts_device": (_i, [_P] * 9 + [_sz, _i, _i, _i64, _P, _P, _P, _sz, _i, _i64, _P]),
+    "tdt_format_coverage": (_i, [_P, _sz, ctypes.c_char_p, _i64, _i64, _i, _P, _sz, ctypes.POINTER(_sz)]),
     "tdt_host_threads": (_i, [_i]),
     "tdt_bgzf_scan": (_i, [_P, _sz, _sz, _P, _P, _P]),
     "tdt_bgzf_inflate": (_i, [_P, _sz, _P, _sz, _i]),

@@ -1,0 +1,152 @@
+// Host-side text writer for the coverage tables (no device code): the rows of print_coverage (tiddit_coverage.pyx:22-45).
+// The reference formats every bin with `"{}".format(numpy.float64)` in a Python loop — 6 M rows for a human genome at
+// 500-bp bins.  Here the rows are produced by the host thread pool: shortest round-trip digits from std::to_chars, laid out
+// by Python's repr rules (fixed notation for 1e-4 <= |x| < 1e16 with a trailing ".0" on integers, otherwise d.ddde[+-]XX
+// with at least two exponent digits), so the file is byte-identical to the reference's.
+#include "tdt_common.h"
+
+#include <charconv>
+#include <string>
+#include <thread>
+
+// repr(float) of a finite or special double into p; returns the number of bytes written (<= 32)
+static size_t fmt_repr(double v, char *p) {
+    char *const p0 = p;
+    if (v != v) {
+        memcpy(p, "nan", 3);
+        return 3;
+    }
+    if (v < 0 || (v == 0 && 1.0 / v < 0)) {
+        *p++ = '-';
+        v = -v;
+    }
+    if (v > 1.7976931348623157e308) {
+        memcpy(p, "inf", 3);
+        return (size_t)(p + 3 - p0);
+    }
+    if (v == 0) {
+        memcpy(p, "0.0", 3);
+        return (size_t)(p + 3 - p0);
+    }
+    char s[40];
+    const auto r = std::to_chars(s, s + sizeof s, v, std::chars_format::scientific);   // d[.ddd]e[+-]XX, shortest digits
+    char digits[24];
+    int nd = 0;
+    const char *q = s;
+    for (; q < r.ptr && *q != 'e'; q++)
+        if (*q != '.') digits[nd++] = *q;
+    int ex = 0;
+    {
+        const char *e = q + 1;
+        const bool neg = *e == '-';
+        e++;
+        for (; e < r.ptr; e++) ex = ex * 10 + (*e - '0');
+        if (neg) ex = -ex;
+    }
+    const int decpt = ex + 1;                                   // value = 0.d1d2... * 10^decpt
+    if (decpt <= -4 || decpt > 16) {                            // exponent notation
+        *p++ = digits[0];
+        if (nd > 1) {
+            *p++ = '.';
+            memcpy(p, digits + 1, (size_t)nd - 1);
+            p += nd - 1;
+        }
+        *p++ = 'e';
+        int x = decpt - 1;
+        *p++ = x < 0 ? '-' : '+';
+        if (x < 0) x = -x;
+        if (x >= 100) *p++ = (char)('0' + x / 100);
+        *p++ = (char)('0' + (x / 10) % 10);
+        *p++ = (char)('0' + x % 10);
+    } else if (decpt <= 0) {
+        *p++ = '0';
+        *p++ = '.';
+        for (int i = 0; i < -decpt; i++) *p++ = '0';
+        memcpy(p, digits, (size_t)nd);
+        p += nd;
+    } else if (decpt >= nd) {
+        memcpy(p, digits, (size_t)nd);
+        p += nd;
+        for (int i = nd; i < decpt; i++) *p++ = '0';
+        *p++ = '.';
+        *p++ = '0';
+    } else {
+        memcpy(p, digits, (size_t)decpt);
+        p += decpt;
+        *p++ = '.';
+        memcpy(p, digits + decpt, (size_t)(nd - decpt));
+        p += nd - decpt;
+    }
+    return (size_t)(p - p0);
+}
+
+static inline size_t fmt_u64(unsigned long long v, char *p) {
+    char t[24];
+    int n = 0;
+    do {
+        t[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    for (int i = 0; i < n; i++) p[i] = t[n - 1 - i];
+    return (size_t)n;
+}
+
+// One contig's rows.  kind 0 = bed (`name \t 1+i*bin \t (i+1)*bin+1 \t value`, the last row ends at contig_len,
+// tiddit_coverage.pyx:34-41), kind 1 = wig (one value per line, :42-44).  Appends to `out`.
+static void fmt_rows(const double *v, size_t lo, size_t hi, size_t n, const char *name, size_t name_len, long long bin, long long contig_len,
+                     int kind, std::string &out) {
+    out.reserve(out.size() + (hi - lo) * (kind ? 22 : 48 + name_len));
+    char row[160];
+    for (size_t i = lo; i < hi; i++) {
+        char *p = row;
+        if (kind == 0) {
+            memcpy(p, name, name_len);
+            p += name_len;
+            *p++ = '\t';
+            p += fmt_u64((unsigned long long)(1 + (long long)i * bin), p);
+            *p++ = '\t';
+            const long long end = i == n - 1 ? contig_len : ((long long)i + 1) * bin + 1;
+            if (end < 0) {
+                *p++ = '-';
+                p += fmt_u64((unsigned long long)(-end), p);
+            } else p += fmt_u64((unsigned long long)end, p);
+            *p++ = '\t';
+        }
+        p += fmt_repr(v[i], p);
+        *p++ = '\n';
+        out.append(row, (size_t)(p - row));
+    }
+}
+
+extern "C" int tdt_format_coverage(const double *values, size_t n, const char *name, int64_t bin_size, int64_t contig_len, int kind,
+                                   char *out, size_t out_cap, size_t *out_len) {
+    if ((!values && n) || !name || !out_len || (kind != 0 && kind != 1) || strlen(name) > 100) {
+        tdt_set_error("tdt_format_coverage: bad argument");
+        return TDT_E_ARG;
+    }
+    const size_t name_len = strlen(name);
+    int threads = tdt_host_thread_count();
+    if (n < 65536) threads = 1;
+    std::vector<std::string> parts((size_t)threads);
+    const size_t per = (n + threads - 1) / threads;
+    auto work = [&](int t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+        if (lo < hi) fmt_rows(values, lo, hi, n, name, name_len, bin_size, contig_len, kind, parts[(size_t)t]);
+    };
+    if (threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(work, t);
+        for (auto &t : pool) t.join();
+    }
+    size_t total = 0;
+    for (auto &s : parts) total += s.size();
+    *out_len = total;
+    if (!out || total > out_cap) return out ? TDT_E_RANGE : TDT_OK;   // out == NULL: size query
+    size_t o = 0;
+    for (auto &s : parts) {
+        memcpy(out + o, s.data(), s.size());
+        o += s.size();
+    }
+    return TDT_OK;
+}

@@ -30,27 +30,44 @@ def create_coverage(bam_header, bin_size, c="all"):
 def print_coverage(coverage_data, bam_header, bin_size, file_type, outfile):
     """tiddit_coverage.pyx:22-45 — bed (note the reference's `+1` bin end and LN on the last row)
     or fixedStep wig; values are formatted exactly like ``"{}".format(numpy.float64)``."""
-    f = open(outfile, "w", buffering=819200)
+    lib = _native.load()
+    f = open(outfile, "wb", buffering=0)
     if file_type == "bed":
-        f.write("#chromosome\tstart\tend\tcoverage\n")
+        f.write(b"#chromosome\tstart\tend\tcoverage\n")
     elif file_type == "wig":
-        f.write("track type=wiggle_0 name=\"Coverage\" description=\"Per bin average coverage\"\n")
+        f.write(b"track type=wiggle_0 name=\"Coverage\" description=\"Per bin average coverage\"\n")
     for contig in bam_header["SQ"]:
         name = contig["SN"]
-        values = coverage_data[name]
-        n = len(values)
+        values = numpy.ascontiguousarray(coverage_data[name], dtype=numpy.float64)
         if file_type == "wig":
-            f.write("fixedStep chrom={} start=1 step={}\n".format(name, bin_size))
-            f.write("".join("{}\n".format(v) for v in values))
-        elif file_type == "bed":
-            rows = []
-            for i in range(0, n):
-                bin_end = (i + 1) * bin_size + 1
-                if i == n - 1:
-                    bin_end = contig["LN"]
-                rows.append("{}\t{}\t{}\t{}\n".format(name, 1 + i * bin_size, bin_end, values[i]))
-            f.write("".join(rows))
+            f.write("fixedStep chrom={} start=1 step={}\n".format(name, bin_size).encode())
+        elif file_type != "bed":
+            continue
+        if len(name.encode()) > 100 or not len(values):                 # odd names: the literal loop of the reference
+            f.write(_rows_python(values, name, contig["LN"], bin_size, file_type).encode())
+            continue
+        # the row loop (:34-44) on the host thread pool, byte-identical to "{}".format(numpy.float64)
+        kind = 0 if file_type == "bed" else 1
+        size = ctypes.c_size_t(0)
+        cap = len(values) * (26 if kind else 50 + len(name.encode())) + 64
+        buf = numpy.empty(cap, dtype=numpy.uint8)
+        _native.check(lib.tdt_format_coverage(_native.ptr(values), len(values), name.encode(), int(bin_size), int(contig["LN"]), kind,
+                                              _native.ptr(buf), cap, ctypes.byref(size)))
+        f.write(memoryview(buf)[:size.value])
     f.close()
+
+
+def _rows_python(values, name, contig_len, bin_size, file_type):
+    n = len(values)
+    if file_type == "wig":
+        return "".join("{}\n".format(v) for v in values)
+    rows = []
+    for i in range(0, n):
+        bin_end = (i + 1) * bin_size + 1
+        if i == n - 1:
+            bin_end = contig_len
+        rows.append("{}\t{}\t{}\t{}\n".format(name, 1 + i * bin_size, bin_end, values[i]))
+    return "".join(rows)
 
 
 class CoverageHistogram:
