@@ -334,10 +334,12 @@ def main():
     # ---- BAM ingest: BGZF inflate + record decode on the device, from a file to the packed arrays (next-row path, §8(f)2)
     if not args.no_ingest:
         from tiddit_amd import bamio, synth_bam
-        path = "/tmp/tiddit_bench_%d_r%d.bam" % (args.ingest_mb, rank)
-        if not os.path.exists(path):
-            synth_bam.write_bulk_bam(path, [("chr1", args.ingest_mb * 1_000_000), ("chr2", args.ingest_mb * 1_000_000)], depth=30,
+        path = "/tmp/tiddit_bench_%d.bam" % args.ingest_mb          # one file per node, written by local rank 0, read by every rank
+        if local_rank == 0 and not os.path.exists(path):
+            synth_bam.write_bulk_bam(path + ".tmp", [("chr1", args.ingest_mb * 1_000_000), ("chr2", args.ingest_mb * 1_000_000)], depth=30,
                                      threads=min(16, os.cpu_count() or 1))
+            os.replace(path + ".tmp", path)
+        barrier()
         fsize = os.path.getsize(path)
 
         def ingest_pass():
