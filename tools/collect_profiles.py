@@ -11,7 +11,7 @@ tag = sys.argv[1]
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
-ours = ("cov_", "gc_", "db", "scan_", "sd_", "segmented", "radix")
+ours = ("cov_", "gc_", "db", "scan_", "sd_", "segmented", "radix", "rs_", "bgzf_", "bam_", "sig_", "med_", "region_")
 rows = list(csv.reader(open(os.path.join(src, "trace", "t_kernel_stats.csv"))))
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
