@@ -374,3 +374,50 @@ def test_device_ingest_rejects_damaged_records(ctx, tmp_path):
     rd = bamio.DeviceBamReader(path, ctx=ctx)                         # the context is still healthy
     assert sum(len(b) for b in rd.batches()) == len(offs)
     rd.close()
+
+
+def _sharded_worker(rank, world, port, q, bam, out_prefix):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), TIDDIT_HIP_DEVICE="0")
+    import torch.distributed as dist
+    from tiddit_amd import dist as tdist
+    from tiddit_amd import tiddit_coverage
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the box's one GPU; the exchange runs over gloo
+    try:
+        header, cov, n = tdist.coverage_sharded(bam, 200, 10, chunk=1_500_000)
+        if rank == 0:
+            tiddit_coverage.print_coverage(cov, header, 200, "bed", out_prefix + ".bed")
+        q.put((rank, n))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_coverage_sharded_multi_process(bams, tmp_path, world):
+    """real ranks: every process ingests its byte range of ONE BAM on the device, the seams are checked with an all-gather and
+    the bins meet in an all-reduce; rank 0's .bed equals the single-process CLI output and the record counts add up"""
+    import socket
+    import torch.multiprocessing as mp
+    from tiddit_amd import __main__ as cli
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_sharded_worker, args=(r, world, port, q, bams[1], str(tmp_path / "sh"))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(isinstance(v, int) for v in res.values()), res
+    cli.run_cov(cli._cov_parser().parse_args(["--cov", "--bam", bams[1], "-o", str(tmp_path / "one"), "-z", "200", "-q", "10"]))
+    assert open(str(tmp_path / "sh.bed")).read() == open(str(tmp_path / "one.bed")).read()
+    want, _, _ = _host_records(bams[1])
+    assert sum(res.values()) == len(want["tid"])
