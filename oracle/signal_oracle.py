@@ -11,7 +11,6 @@ import itertools
 import struct
 import zlib
 
-import numpy as np
 
 import oracle
 

@@ -1,7 +1,6 @@
 """GPU parity of the device ingest: BGZF inflate (one wavefront per block) against zlib, record finding + field decode
 against the host decoder (tdt_bam_decode, itself checked against the independent parser in test_bamio_cpu.py), and the
 pipeline (tiddit --cov / signal scan) with device ingest against the host-thread ingest."""
-import ctypes
 import os
 import struct
 import zlib

@@ -2,7 +2,6 @@
 (restated here in numpy) equals the literal state machine, and the C BAM decoder
 agrees with the independent pure-Python parser on random records."""
 import numpy as np
-import pytest
 from hypothesis import given, settings, strategies as st
 
 import oracle

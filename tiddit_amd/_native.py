@@ -5,7 +5,6 @@ import os
 import sys
 import threading
 
-import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("TIDDIT_HIP_LIB") or os.path.join(_HERE, "libtiddit_hip.so")

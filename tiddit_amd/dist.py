@@ -6,7 +6,6 @@ collective; ONE exchange step — a variable-count all-gather of the label array
 assembles the final cluster set on every rank.  The coverage / GC histograms shard by contig and
 need no exchange (each rank returns its contigs' bins to the host caller).
 """
-import numpy as np
 
 
 def shard_buckets(sizes, world_size):

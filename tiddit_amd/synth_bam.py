@@ -135,7 +135,6 @@ def write_bulk_bam(path, contigs, depth=30, read_len=100, insert=350, seed=1, le
     """Large plain paired-end BAM written with numpy (fixed-size records: 12-byte name, one M cigar op, no aux), for
     end-to-end timing of the BGZF/BAM ingest.  ~10 M records/min.  -> number of records."""
     import struct
-    import zlib
     from concurrent.futures import ThreadPoolExecutor
     from .bamio import _BGZF_EOF, _bgzf_block
     rng = np.random.default_rng(seed)
