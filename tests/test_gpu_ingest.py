@@ -420,3 +420,211 @@ def test_coverage_sharded_multi_process(bams, tmp_path, world):
     assert open(str(tmp_path / "sh.bed")).read() == open(str(tmp_path / "one.bed")).read()
     want, _, _ = _host_records(bams[1])
     assert sum(res.values()) == len(want["tid"])
+
+
+class _BitWriter:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def bits(self, v, n):                 # LSB first (header fields, extra bits)
+        self.acc |= (v & ((1 << n) - 1)) << self.n
+        self.n += n
+        while self.n >= 8:
+            self.out.append(self.acc & 0xff)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, c, n):                 # Huffman codes are packed MSB first
+        for i in range(n - 1, -1, -1):
+            self.bits((c >> i) & 1, 1)
+
+    def done(self):
+        if self.n:
+            self.out.append(self.acc & 0xff)
+        return bytes(self.out)
+
+
+def _canon(lengths):
+    """canonical code of every symbol from its length (RFC 1951 3.2.2)"""
+    bl = [0] * 16
+    for l in lengths:
+        bl[l] += 1
+    bl[0] = 0
+    code, nxt = 0, [0] * 16
+    for b in range(1, 16):
+        code = (code + bl[b - 1]) << 1
+        nxt[b] = code
+    out = []
+    for l in lengths:
+        out.append(nxt[l] if l else 0)
+        if l:
+            nxt[l] += 1
+    return out
+
+
+def _huff_lengths(weights):
+    """code lengths of a Huffman code (complete prefix code) for {symbol: weight}, at least two symbols"""
+    import heapq
+    heap = [(w, i, (s,)) for i, (s, w) in enumerate(sorted(weights.items()))]
+    heapq.heapify(heap)
+    depth = {s: 0 for s in weights}
+    tick = len(heap)
+    while len(heap) > 1:
+        w1, _, a = heapq.heappop(heap)
+        w2, _, b = heapq.heappop(heap)
+        for s in a + b:
+            depth[s] += 1
+        heapq.heappush(heap, (w1 + w2, tick, a + b))
+        tick += 1
+    return depth
+
+
+_LBASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+_LEXT = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+_DBASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+_DEXT = [0, 0, 0, 0] + [i // 2 for i in range(2, 28)]
+
+
+def _dynamic_block(w, syms, ll_len, d_len, final):
+    """one dynamic-Huffman DEFLATE block from (literal | (length, distance)) symbols with the GIVEN code lengths;
+    the code-length sequence uses the 16/17/18 run codes (runs may cross from the literal/length into the distance lengths)"""
+    hlit = max(257, max(i for i, l in enumerate(ll_len) if l) + 1)
+    hdist = max(1, max([i for i, l in enumerate(d_len) if l] + [0]) + 1)
+    seq = list(ll_len[:hlit]) + list(d_len[:hdist])
+    rl, i = [], 0                                         # run-length code the sequence
+    while i < len(seq):
+        v, j = seq[i], i
+        while j < len(seq) and seq[j] == v:
+            j += 1
+        run = j - i
+        if v == 0 and run >= 3:
+            r = min(run, 138)
+            rl.append((18, r - 11, 7) if r >= 11 else (17, r - 3, 3))
+            i += r
+        elif v and run >= 4:
+            rl.append((v, 0, 0))
+            r = min(run - 1, 6)
+            rl.append((16, r - 3, 2))
+            i += 1 + r
+        else:
+            rl.append((v, 0, 0))
+            i += 1
+    freq = {}
+    for s, _, _ in rl:
+        freq[s] = freq.get(s, 0) + 1
+    assert len(freq) >= 2
+    cl = _huff_lengths(freq)
+    if max(cl.values()) > 7:
+        cl = _huff_lengths({k: 1 for k in freq})
+    cl_len = [cl.get(s, 0) for s in range(19)]
+    order19 = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    hclen = max(4, max(i for i, s in enumerate(order19) if cl_len[s]) + 1)
+    w.bits(1 if final else 0, 1)
+    w.bits(2, 2)
+    w.bits(hlit - 257, 5)
+    w.bits(hdist - 1, 5)
+    w.bits(hclen - 4, 4)
+    for s in order19[:hclen]:
+        w.bits(cl_len[s], 3)
+    cl_code = _canon(cl_len)
+    for s, x, nb in rl:
+        w.code(cl_code[s], cl_len[s])
+        if nb:
+            w.bits(x, nb)
+    ll_code, d_code = _canon(ll_len), _canon(d_len)
+    for s in syms + [256]:
+        if isinstance(s, tuple):
+            ln, dist = s
+            lc = max(i for i in range(29) if _LBASE[i] <= ln)
+            if lc == 28 and ln != 258:
+                lc = 27
+            w.code(ll_code[257 + lc], ll_len[257 + lc])
+            w.bits(ln - _LBASE[lc], _LEXT[lc])
+            dc = max(i for i in range(30) if _DBASE[i] <= dist)
+            w.code(d_code[dc], d_len[dc])
+            w.bits(dist - _DBASE[dc], _DEXT[dc])
+        else:
+            w.code(ll_code[s], ll_len[s])
+
+
+def _skewed_lengths(symbols, n, maxlen=15):
+    """a complete prefix code over `symbols` whose lengths run 1,2,3,...,maxlen,maxlen (then padded at maxlen)"""
+    lens = [0] * n
+    symbols = list(symbols)
+    k = min(len(symbols), maxlen + 1)
+    chain = list(range(1, k)) + [k - 1]
+    for s, l in zip(symbols[:k], chain):
+        lens[s] = l
+    return lens
+
+
+@pytest.mark.parametrize("kernel", ["lanes", "sequential"])
+def test_device_inflate_hand_built_streams(ctx, kernel, monkeypatch):
+    """DEFLATE streams zlib's encoder would never emit: 15-bit literal/length AND distance codes (canonical walk beyond the
+    LUT on both tables), length 258 / distance 32768 and distance 1, a single distance code, code-length runs that cross from
+    the literal/length into the distance lengths, empty stored blocks between Huffman blocks.  Validity is zlib's verdict."""
+    if kernel == "sequential":
+        monkeypatch.setenv("TIDDIT_INFLATE_SEQ", "1")
+    rng = np.random.default_rng(21)
+    streams = []
+    # (1) sixteen literal/length symbols and sixteen distance symbols with weights 1,1,2,4,...: Huffman depths 15,15,14,...,1
+    lits = [65 + i for i in range(13)]
+    ll_syms = [256, 285, 257] + lits                         # EOB and the two length codes get the DEEPEST codes
+    wts = [1, 1] + [2 ** i for i in range(1, 15)]
+    lld = _huff_lengths(dict(zip(ll_syms, wts)))
+    ll = [lld.get(s, 0) for s in range(286)]
+    assert max(ll) == 15 and sorted(ll)[-2] == 15
+    d_syms = [0, 29, 28, 26, 22, 18, 14, 10, 6, 1, 2, 3, 4, 24, 12, 16]
+    dld = _huff_lengths(dict(zip(d_syms, wts)))
+    dl = [dld.get(s, 0) for s in range(30)]
+    assert max(dl) == 15
+    data_syms = []
+    out = bytearray()
+    def emit(sym):
+        data_syms.append(sym)
+        if isinstance(sym, tuple):
+            ln, dist = sym
+            for _ in range(ln):
+                out.append(out[-dist])
+        else:
+            out.append(sym)
+    for _ in range(40000):
+        emit(int(rng.choice(lits)))
+    emit((258, 1))
+    emit((3, 1))
+    emit((258, 32768))
+    emit((3, 24577))
+    for dist in sorted(set([_DBASE[c] for c in d_syms] + [_DBASE[c] + (1 << _DEXT[c]) - 1 for c in d_syms])):   # both ends of every used code
+        emit((3, dist))
+        emit(lits[0])
+    w = _BitWriter()
+    _dynamic_block(w, data_syms, ll, dl, final=False)
+    w.bits(0, 1); w.bits(0, 2)                               # an EMPTY stored block
+    while w.n:
+        w.bits(0, 1)
+    w.bits(0, 16); w.bits(0xffff, 16)
+    # (2) a block with ONE distance code (incomplete code) and literal lengths that end in a long zero run crossing into HDIST
+    ll2 = [0] * 286
+    for s in range(32, 64):
+        ll2[s] = 6                                           # 32 symbols at depth 6 = half of the code space
+    ll2[256] = 2
+    ll2[257] = 2                                             # length 3; nothing above 257 -> zeros run on into the distance lengths
+    dl2 = [0] * 30
+    dl2[0] = 1
+    syms2 = []
+    base_len = len(out)
+    for _ in range(5000):
+        s = int(rng.integers(32, 64))
+        syms2.append(s)
+        out.append(s)
+        if rng.random() < 0.2:
+            syms2.append((3, 1))
+            out.extend(out[-1:] * 3)
+    _dynamic_block(w, syms2, ll2, dl2, final=True)
+    raw = w.done()
+    assert zlib.decompress(raw, -15) == bytes(out)           # the stream is valid DEFLATE and means what we think
+    data = bytes(out)
+    assert len(data) < 65536
+    comp = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
+            struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))) + bamio._BGZF_EOF
+    assert _inflate_hbm(ctx, comp, len(data)) == data
