@@ -156,14 +156,17 @@ __device__ __noinline__ unsigned b2_long_code(unsigned bits, int tb, int mode, c
     return B2_ESC;
 }
 
-// inclusive prefix sum over the 64 lanes (DPP: Hillis-Steele inside each row of 16, then the two row broadcasts)
+// inclusive prefix sum over the 64 lanes: six fused DPP adds (Hillis-Steele inside each row of 16, then the two row
+// broadcasts); the s_nop pairs cover the VALU-write -> DPP-read hazard the assembler does not see inside inline asm
 __device__ __forceinline__ unsigned b2_scan(unsigned v) {
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1, 3
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2, 3
+    asm volatile("s_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
     return v;
 }
 
@@ -369,16 +372,20 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
         // ---- the symbols of this block, a window of 64 bit offsets at a time
         for (;;) {
             // every lane: the symbol that would start at bit bp + lane
-            const u64 bits = b2_bits_at(win, bp + (unsigned)lane);
-            const unsigned e1 = lut_ll[(unsigned)bits & ((1u << B2_TB_LL) - 1)];
+            // (three dwords from the ring; every field but the distance's extra bits lies in the first 32 stream bits:
+            //  9-bit code + 5 extra + 8-bit code = 22, so 64-bit shifts are not needed)
+            const unsigned q = bp + (unsigned)lane, qd = q >> 5, qs = q & 31;
+            const unsigned wa = win[qd & 127], wb = win[(qd + 1) & 127], wc = win[(qd + 2) & 127];
+            const unsigned lo = __builtin_amdgcn_alignbit(wb, wa, qs), hi = __builtin_amdgcn_alignbit(wc, wb, qs);
+            const unsigned e1 = lut_ll[lo & ((1u << B2_TB_LL) - 1)];
             const unsigned l1 = e1 & 15, eb1 = (e1 >> 4) & 15, base1 = (e1 >> 8) & 0xffff, kind = e1 >> 28;
             const bool is_len = kind == 1, is_lit = kind == 0;
-            const unsigned c1 = l1 + eb1;
-            const unsigned mlen = base1 + ((unsigned)(bits >> l1) & ((1u << eb1) - 1));
-            const u64 bits2 = bits >> c1;
-            const unsigned e2 = lut_d[(unsigned)bits2 & ((1u << B2_TB_D) - 1)];
+            const unsigned c1 = l1 + eb1;                           // <= 9 + 5 on the LUT path (an escape entry is never used)
+            const unsigned mlen = base1 + ((lo >> l1) & ((1u << eb1) - 1));
+            const unsigned e2 = lut_d[(lo >> (c1 & 31)) & ((1u << B2_TB_D) - 1)];
             const unsigned l2 = e2 & 15, eb2 = (e2 >> 4) & 15, base2 = (e2 >> 8) & 0xffff;
-            const unsigned dist = base2 + ((unsigned)(bits2 >> l2) & ((1u << eb2) - 1));
+            const unsigned c2 = (c1 + l2) & 31;                     // <= 22: the extra bits start here and may reach into `hi`
+            const unsigned dist = base2 + (__builtin_amdgcn_alignbit(hi, lo, c2) & ((1u << eb2) - 1));
             // next[i], with the two ways a chain ends folded in so the walk needs no second lookup:
             // 128 + i = the code at bit i is longer than the LUT, 192 + (bit after it) = end of block
             const bool slow = e1 == B2_ESC || (is_len && e2 == B2_ESC);
