@@ -67,6 +67,17 @@ __device__ __forceinline__ signed char gc_result(unsigned long long gc, unsigned
     return (signed char)q;
 }
 
+// the same in 32 bits for the small-bin kernel (gc, n, chars <= 2048): a 64-bit division is ~150 VALU instructions in
+// software, and with five bins per lane it was half of that kernel's vector work
+__device__ __forceinline__ signed char gc_result32(unsigned gc, unsigned n, unsigned chars, unsigned n_min) {
+    if (n >= n_min) return -1;
+    const unsigned a = 100u * gc;
+    unsigned q = a / chars;
+    const unsigned r2 = 2u * (a - q * chars);
+    if (r2 > chars || (r2 == chars && (q & 1u))) q++;
+    return (signed char)q;
+}
+
 __global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__restrict__ seq, long long len, int bin_size,
                                                             int tile_bins, long long nbins, unsigned long long n_min,
                                                             signed char *__restrict__ out) {
@@ -80,8 +91,13 @@ __global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__res
     unsigned short *n16 = reinterpret_cast<unsigned short *>(nbits);
     const int tid = threadIdx.x;
 
+    const unsigned nmin32 = n_min > 0xffffffffull ? 0xffffffffu : (unsigned)n_min;
     for (long long tile = blockIdx.x; tile * tile_bins < nbins; tile += gridDim.x) {
         const long long T0 = tile * (long long)tile_bytes;
+        // A tile that lies wholly inside the sequence (all but the last) is addressed as uniform base + 32-bit lane
+        // offset and has only full bins; the 64-bit bounds arithmetic is left to the one tile at the end.
+        const bool whole = T0 + tile_bytes <= len && (tile + 1) * tile_bins <= nbins;
+        const uint8_t *const tp = seq + T0;
         // phase 1, four chunks per lane per trip: the four 16-byte loads are issued back to back
         // (prefetching the next trip across the popcount phase was measured slower: 0.63 vs 0.57 ms per 3 Gb)
         for (int c0 = 0; c0 < chunks; c0 += 4 * GC_THREADS) {
@@ -89,7 +105,7 @@ __global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__res
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int c = c0 + k * GC_THREADS + tid;
-                if (c < chunks) v[k] = gc_load16(seq, T0 + 16ll * c, len);
+                if (c < chunks) v[k] = whole ? *reinterpret_cast<const uint4 *>(tp + 16u * (unsigned)c) : gc_load16(seq, T0 + 16ll * c, len);
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -107,12 +123,15 @@ __global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__res
             n16[chunks] = 0;
         }
         __syncthreads();
+        signed char *const to = out + tile * tile_bins;
         for (int j = tid; j < tile_bins; j += GC_THREADS) {
-            const long long bin = tile * tile_bins + j;
-            if (bin >= nbins) break;
+            if (!whole && tile * tile_bins + j >= nbins) break;
             const int lo = j * bin_size;
-            long long rem = len - (T0 + lo);
-            const int chars = rem < bin_size ? (int)rem : bin_size;
+            int chars = bin_size;
+            if (!whole) {
+                const long long rem = len - (T0 + lo);
+                chars = rem < bin_size ? (int)rem : bin_size;
+            }
             const int hi = lo + chars - 1;  // inclusive last bit
             const int w0 = lo >> 5, w1 = hi >> 5;
             unsigned gcnt = 0, ncnt = 0;
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__res
                 gcnt += __popc(gbits[w] & m);
                 ncnt += __popc(nbits[w] & m);
             }
-            out[bin] = gc_result(gcnt, ncnt, (unsigned long long)chars, n_min);
+            to[j] = gc_result32(gcnt, ncnt, (unsigned)chars, nmin32);
         }
         __syncthreads();
     }
