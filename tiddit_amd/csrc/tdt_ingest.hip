@@ -220,10 +220,14 @@ struct tdt_ingest {
     tdt_ctx *ctx = nullptr;
     int n_ref = 0;
     tdt_buf comp, table, out, seg, soa;            // device buffers (grow only)
-    tdt_buf comp2;                                 // compressed blocks of the NEXT batch, filled by tdt_ingest_prefetch
-    const uint8_t *pf_host = nullptr;              // what comp2 holds: host pointer / length of the prefetched span
-    size_t pf_len = 0;
-    hipEvent_t pf_done = nullptr;
+    // compressed blocks of spans copied ahead by tdt_ingest_prefetch: two slots, so that the copy of span k+1 can be issued
+    // while span k (prefetched earlier) has not been pushed yet
+    struct Prefetch {
+        tdt_buf buf;
+        const uint8_t *host = nullptr;             // what the slot holds: host pointer / length of the span (null = free)
+        size_t len = 0;
+        hipEvent_t done = nullptr;
+    } pf[2];
     tdt_buf pin;                                   // pinned staging for the segment table / edges
     size_t carry = 0, tail_off = 0;                // bytes of the partial record at out[tail_off..), moved to the front by the next push
     size_t out_len = 0;                            // carry + inflated bytes of the current batch
@@ -271,9 +275,10 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
     if (!g) return TDT_OK;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    if (g->pf_done) (void)hipEventDestroy(g->pf_done);
     (void)hipStreamSynchronize(g->ctx->copy_stream);
-    for (tdt_buf *b : {&g->comp, &g->comp2, &g->table, &g->out, &g->seg, &g->soa})
+    for (auto &p : g->pf)
+        if (p.done) (void)hipEventDestroy(p.done);
+    for (tdt_buf *b : {&g->comp, &g->pf[0].buf, &g->pf[1].buf, &g->table, &g->out, &g->seg, &g->soa})
         if (b->p) (void)hipFree(b->p);
     if (g->pin.p) (void)hipHostFree(g->pin.p);
     delete g;
@@ -290,14 +295,16 @@ extern "C" int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t le
     tdt_ctx *ctx = g->ctx;
     TDT_HIP(hipSetDevice(ctx->device));
     const size_t comp_pad = (len + 4096 + 255) & ~(size_t)255;
-    int rc = ing_grow(g, g->comp2, comp_pad);
+    tdt_ingest::Prefetch *slot = g->pf[0].host ? &g->pf[1] : &g->pf[0];   // a free slot (a second pending one is overwritten)
+    // (a buffer swapped into a slot by an earlier push is free: that push waited for its inflate kernel before returning)
+    int rc = ing_grow(g, slot->buf, comp_pad);
     if (rc) return rc;
-    if (!g->pf_done) TDT_HIP(hipEventCreateWithFlags(&g->pf_done, hipEventDisableTiming));
-    TDT_HIP(hipMemcpyAsync(g->comp2.p, comp, len, hipMemcpyHostToDevice, ctx->copy_stream));
-    TDT_HIP(hipMemsetAsync((char *)g->comp2.p + len, 0, comp_pad - len, ctx->copy_stream));
-    TDT_HIP(hipEventRecord(g->pf_done, ctx->copy_stream));
-    g->pf_host = comp;
-    g->pf_len = len;
+    if (!slot->done) TDT_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+    TDT_HIP(hipMemcpyAsync(slot->buf.p, comp, len, hipMemcpyHostToDevice, ctx->copy_stream));
+    TDT_HIP(hipMemsetAsync((char *)slot->buf.p + len, 0, comp_pad - len, ctx->copy_stream));
+    TDT_HIP(hipEventRecord(slot->done, ctx->copy_stream));
+    slot->host = comp;
+    slot->len = len;
     return TDT_OK;
 }
 
@@ -348,14 +355,17 @@ extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_
         if (rc) return rc;
         BzDesc *d_blocks = (BzDesc *)g->table.p;
         unsigned *d_status = (unsigned *)((char *)g->table.p + tab), *d_summary = (unsigned *)((char *)d_status + stb);
-        if (g->pf_host == comp && g->pf_len == len && g->comp2.cap >= comp_pad) {
-            std::swap(g->comp, g->comp2);                         // the span is already on the device (copy stream)
-            TDT_HIP(hipStreamWaitEvent(st, g->pf_done, 0));
+        tdt_ingest::Prefetch *hit = nullptr;
+        for (auto &p : g->pf)
+            if (p.host == comp && p.len == len && p.buf.cap >= comp_pad) hit = &p;
+        if (hit) {
+            std::swap(g->comp, hit->buf);                         // the span is already on the device (copy stream)
+            TDT_HIP(hipStreamWaitEvent(st, hit->done, 0));
+            hit->host = nullptr;
         } else {
             TDT_HIP(hipMemcpyAsync(g->comp.p, comp, len, hipMemcpyHostToDevice, st));
             TDT_HIP(hipMemsetAsync((char *)g->comp.p + len, 0, comp_pad - len, st));
         }
-        g->pf_host = nullptr;
         unsigned char *d_comp = (unsigned char *)g->comp.p;
         TDT_HIP(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
         rc = tdt_bz_launch(ctx, d_comp, d_blocks, nb, d_out, true, d_status, d_summary);

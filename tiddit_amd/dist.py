@@ -135,7 +135,8 @@ def coverage_sharded(bam_file_name, bin_size, min_q, group=None, ctx=None, chunk
     reader.close()
     check_seams(first_off, next_off, empty, group)
     dev = torch.device("cuda", ctx.device)
-    bins = torch.zeros(hist.total_bins(), dtype=torch.float64, device=dev)
+    bins = torch.empty(hist.total_bins(), dtype=torch.float64, device=dev)   # every bin is written by the finalize kernel
+    torch.cuda.synchronize(dev)          # torch's allocator/fill work runs on torch's stream, the library on its own: order them
     hist.finish_all_device(bins.data_ptr())
     ctx.sync()
     if dist.get_backend(group) != "nccl":

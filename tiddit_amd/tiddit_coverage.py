@@ -31,7 +31,7 @@ def print_coverage(coverage_data, bam_header, bin_size, file_type, outfile):
     """tiddit_coverage.pyx:22-45 — bed (note the reference's `+1` bin end and LN on the last row)
     or fixedStep wig; values are formatted exactly like ``"{}".format(numpy.float64)``."""
     lib = _native.load()
-    f = open(outfile, "wb", buffering=0)
+    f = open(outfile, "wb")                     # buffered: a raw FileIO.write may write short and does not retry
     if file_type == "bed":
         f.write(b"#chromosome\tstart\tend\tcoverage\n")
     elif file_type == "wig":
