@@ -468,14 +468,11 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         ull *EM = (ull *)q; q += mask_bytes;
         ull *S1M = (ull *)q; q += mask_bytes;
         ull *FM = (ull *)q; q += mask_bytes;
-        TDT_HIP(hipMemsetAsync(ctl, 0, sizeof(DbfCtl), st));
-        TDT_HIP(hipMemsetAsync(PM, 0, 8, st));   // the word before the array
-        TDT_HIP(hipMemsetAsync(PM + (size_t)ntf * DBF_WORDS + 1, 0, 8, st));   // ... and the one after the last tile
-        TDT_HIP(hipMemsetAsync(PY, 0, 8, st));
+        // (the control word and the three guard words of the mask arrays are zeroed by tile 0 of dbm_x_masks)
         if (nb == 1 && m <= 4)
-            hipLaunchKernelGGL(dbm_x_masks<true>, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x);
+            hipLaunchKernelGGL(dbm_x_masks<true>, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x, PY, ctl);
         else
-            hipLaunchKernelGGL(dbm_x_masks<false>, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x);
+            hipLaunchKernelGGL(dbm_x_masks<false>, dim3(ntf), dim3(DBF_THREADS), 0, st, d_x, n, (const int *)d_boff, nb, (ull)eps, m, PM, agg_x, PY, ctl);
         if (ntf > DBM_INLINE_PREFIX_MAX) hipLaunchKernelGGL(tile_scan, dim3(1), dim3(1024), 0, st, agg_x, ntf);
         hipLaunchKernelGGL(dbm_x_labels, dim3(ntf), dim3(DBF_THREADS), 0, st, (const ull *)PM, (const ull *)agg_x, n, (const int *)d_boff, nb,
                            m, d_xlab, d_runbase, d_seg0, d_seg1);

@@ -229,11 +229,18 @@ __device__ __forceinline__ ull dbf_px_word_fast(const unsigned *xsh, int sh0, in
 // p masks of one tile (+ the count of run starts)  — x staged with 16-byte loads
 template <bool FAST>
 __global__ __launch_bounds__(DBF_THREADS) void dbm_x_masks(const unsigned *__restrict__ x, int n, const int *__restrict__ boff, int nb,
-                                                           ull eps, int m, ull *__restrict__ PM, ull *__restrict__ agg) {
+                                                           ull eps, int m, ull *__restrict__ PM, ull *__restrict__ agg,
+                                                           ull *__restrict__ PY, DbfCtl *__restrict__ ctl) {
     __shared__ __attribute__((aligned(16))) unsigned xsh[DBM_XSH4 * 4];
     __shared__ ull pm[DBF_WORDS + 1];   // [0] = last word of the previous tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
+    if (tile == 0 && tid < 4) {   // the pass's few words of zero state (four memset launches otherwise): nothing reads them before
+        if (tid == 0) PM[0] = 0;                                        // the word before the mask array ...
+        if (tid == 1) PM[(size_t)gridDim.x * DBF_WORDS + 1] = 0;        // ... and the one after the last tile
+        if (tid == 2) PY[0] = 0;
+        if (tid == 3) *ctl = DbfCtl{};
+    }
     const int t0 = tile * DBF_TILE;
     const int sh0 = t0 - 64;
     {   // all loads first (independent, one round trip), then the LDS stores
