@@ -628,3 +628,36 @@ def test_device_inflate_hand_built_streams(ctx, kernel, monkeypatch):
     comp = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
             struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))) + bamio._BGZF_EOF
     assert _inflate_hbm(ctx, comp, len(data)) == data
+
+
+def test_device_ingest_degenerate_files(ctx, tmp_path):
+    """header-only BAM, a single record, only unplaced reads: the device reader and the CLI behave like the host reader"""
+    from tiddit_amd import __main__ as cli
+    refs = [("c1", 5000), ("c2", 3000)]
+    paths = {}
+    for kind in ("empty", "one", "unplaced"):
+        p = str(tmp_path / (kind + ".bam"))
+        w = bamio.BamWriter(p, refs)
+        if kind == "one":
+            w.write("r1", 99, 0, 100, 60, "50M", 0, 300, 250, "A" * 50)
+        if kind == "unplaced":
+            for i in range(500):
+                w.write("u%d" % i, 77, -1, -1, 0, "", -1, -1, 0, "ACGT" * 10)
+        w.close()
+        paths[kind] = p
+    for kind, p in paths.items():
+        want, _, _ = (_host_records(p) if kind != "empty" else ({k: np.zeros(0) for k in FIELDS}, [], []))
+        rd = bamio.DeviceBamReader(p, ctx=ctx)
+        got = [b for b in rd.batches()]
+        n = sum(len(b) for b in got)
+        assert n == len(want["tid"]), kind
+        if n:
+            assert np.array_equal(np.concatenate([b.pos for b in got]), want["pos"]) and np.array_equal(np.concatenate([b.tid for b in got]), want["tid"])
+        rd.close()
+        cli.run_cov(cli._cov_parser().parse_args(["--cov", "--bam", p, "-o", str(tmp_path / ("o_" + kind)), "-z", "500"]))
+        bed = open(str(tmp_path / ("o_" + kind)) + ".bed").read().splitlines()
+        assert len(bed) == 1 + 10 + 6                                   # header + ceil(5000/500) + ceil(3000/500) rows
+        if kind != "one":
+            assert all(l.endswith("\t0.0") for l in bed[1:])
+        else:
+            assert bed[1].endswith("\t0.10000000149011612")               # 50 bases / 500 as float32
