@@ -12,7 +12,6 @@ usage: python tests/golden/make_golden.py [--slow]     (--slow adds the 1M-point
 """
 import hashlib
 import importlib
-import io
 import json
 import os
 import subprocess

@@ -539,21 +539,18 @@ class DeviceBamReader:
         return Spans()
 
     def batches(self):
-        lib, ctx = self.ctx.lib, self.ctx
-        prev = None
-        first = True
-        nothing = ctypes.c_size_t(-1).value
+        """yield :class:`DeviceBatch` objects, one per span of BGZF blocks pushed through the device ingest"""
         if self.shard is not None and self._b_lo >= self._b_hi:      # an empty shard: the seam passes straight through
             return
         spans = self._spans()
-        pending = False                                             # False: nothing looked at yet; None: end of the range
         try:
-            yield from self._batches(spans, lib, ctx, nothing)
+            yield from self._batches(spans, self.ctx.lib, self.ctx, ctypes.c_size_t(-1).value)
         finally:
             spans.close()
 
     def _batches(self, spans, lib, ctx, nothing):
-        prev, first, pending = None, True, False
+        prev, first = None, True
+        pending = False                                             # False: span k+1 not looked at yet; None: end of the range
         while True:
             cur = spans.next() if pending is False else pending
             if cur is None:
