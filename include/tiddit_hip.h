@@ -187,7 +187,8 @@ int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t len, uint8_t 
  * in front of the first record (the BAM header; first call only).  The incomplete record at the end of the batch is
  * kept and prepended to the next call.  Records are located by parallel per-segment guesses that the host confirms
  * against the block_size chain; a batch that cannot be confirmed is chased serially on the host instead (counted in
- * tdt_ingest_carry's host_chases) — the result is the sequential decode either way.  tdt_ingest_arrays: device pointers, valid until the next push, in tdt_bam_decode's
+ * tdt_ingest_carry's host_chases) — the result is the sequential decode either way.  After a push has returned an error
+ * the stream position is undefined: further pushes on that object are refused.  tdt_ingest_arrays: device pointers, valid until the next push, in tdt_bam_decode's
  * output order (tid, pos, end, mapq, flag, mate_tid, mate_pos, tlen, l_seq, cigar_first, cigar_last, rec_off, sa_off)
  * followed by the batch's raw record bytes (rec_off / sa_off index into them).  tdt_ingest_edges: record indices
  * where the contig id changes (*n = (size_t)-1 when there are more than 1023, i.e. the input is not coordinate

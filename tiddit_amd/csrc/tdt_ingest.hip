@@ -235,6 +235,7 @@ struct tdt_ingest {
     IngestOut O{};
     std::vector<unsigned> edges;
     bool edges_overflow = false;
+    bool failed = false;                           // a push returned an error: the stream position is undefined from then on
     size_t host_chases = 0;                        // batches whose record chain had to be chased on the host
 };
 
@@ -312,12 +313,26 @@ extern "C" int tdt_ingest_push(tdt_ingest *g, const uint8_t *comp, size_t len, s
     return tdt_ingest_push_bounded(g, comp, len, skip, (size_t)-1, n_records, nullptr, nullptr);
 }
 
+static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records, size_t *first_off,
+                    size_t *next_off);
+
 extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records,
                                        size_t *first_off, size_t *next_off) {
     if (!g || (!comp && len) || !n_records) {
         tdt_set_error("tdt_ingest_push: bad argument");
         return TDT_E_ARG;
     }
+    if (g->failed) {
+        tdt_set_error("tdt_ingest_push: an earlier push on this stream failed; create a new tdt_ingest");
+        return TDT_E_ARG;
+    }
+    const int rc = ing_push(g, comp, len, skip, own_bytes, n_records, first_off, next_off);
+    if (rc != TDT_OK) g->failed = true;
+    return rc;
+}
+
+static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records, size_t *first_off,
+                    size_t *next_off) {
     const bool unknown_start = skip == (size_t)-1;
     if (unknown_start && g->carry) {
         tdt_set_error("tdt_ingest_push_bounded: an unknown start is only possible on a fresh stream");
