@@ -13,6 +13,8 @@
 // Several independent (chrA,chrB) buckets are processed by the same launches (ids restart per bucket).
 #include "tdt_common.h"
 
+#include <atomic>
+
 #include <algorithm>
 #include <cmath>
 
@@ -185,6 +187,14 @@ __global__ __launch_bounds__(DB_THREADS) void dbx_final(const int *__restrict__ 
     if (k >= n) return;
     const int l = xlab[k];
     labels[k] = l < 0 ? -1.0 : (double)(l - (int)runbase[db_bucket(boff, nb, k)]);
+}
+
+// One word back to the host without a stream synchronisation: the value goes to pinned host memory, then a sequence number;
+// the host spins on the sequence number (a hipStreamSynchronize wake-up costs ~40 us, a third of a 5 M-point pass).
+__global__ void db_signal_host(const unsigned *__restrict__ word, volatile unsigned *host, unsigned seq) {
+    host[0] = *word;
+    __threadfence_system();
+    host[1] = seq;
 }
 
 // -------------------------------------------------------------------------------------- y pass
@@ -502,8 +512,28 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
             TDT_CHECK_LAUNCH();
             if (attempt == 1) break;
             unsigned nlarge = 0;
-            TDT_HIP(hipMemcpyAsync(&nlarge, &ctl->nlarge, 4, hipMemcpyDeviceToHost, st));
-            TDT_HIP(hipStreamSynchronize(st));
+            {
+                void *hp = nullptr;
+                rc = tdt_pinned(ctx, 2, 64, &hp);
+                if (rc) return rc;
+                volatile unsigned *hw = (volatile unsigned *)hp;
+                static std::atomic<unsigned> seq_counter{0};
+                unsigned seq = ++seq_counter;
+                if (seq == 0) seq = ++seq_counter;                                    // never 0
+                hw[1] = 0;
+                hipLaunchKernelGGL(db_signal_host, dim3(1), dim3(1), 0, st, (const unsigned *)&ctl->nlarge, hw, seq);
+                TDT_CHECK_LAUNCH();
+                bool seen = false;
+                for (long spin = 0; spin < 4000000; spin++) {     // a few milliseconds at most, then the ordinary wait
+                    if (hw[1] == seq) {
+                        seen = true;
+                        break;
+                    }
+                    __builtin_ia32_pause();
+                }
+                if (!seen) TDT_HIP(hipStreamSynchronize(st));
+                nlarge = hw[0];
+            }
             if (!nlarge) break;
             rc = db_sort_large(ctx, d_xlab, d_y, n, d_lflag, d_tsum, d_key, d_ksorted, d_v0, d_v1, d_cpos, d_ys, d_ord);
             if (rc) return rc;
