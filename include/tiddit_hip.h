@@ -95,6 +95,14 @@ int tdt_cov_kept(tdt_cov *cov, int64_t *kept);
 int tdt_gc_bins(tdt_ctx *ctx, const uint8_t *seq, int64_t len, int bin_size, double n_cutoff, int8_t *out);
 /* d_seq must be 16-byte aligned; asynchronous. */
 int tdt_gc_bins_device(tdt_ctx *ctx, const uint8_t *d_seq, int64_t len, int bin_size, double n_cutoff, int8_t *d_out);
+/* The same bins straight from the FASTA bytes of a contig, line ends still in place (what pysam.FastaFile.fetch hides,
+ * tiddit_gc.pyx:14-19): raw = the nbytes the contig occupies in the file, len bases, linebases / linewidth as in the
+ * .fai index.  TDT_E_UNSUPPORTED for layouts the kernel does not take (bins > 2048, contigs >= 2^31 bases, line ends
+ * longer than two bytes): strip the line ends on the host and call tdt_gc_bins then. */
+int tdt_gc_bins_fasta(tdt_ctx *ctx, const uint8_t *raw, int64_t nbytes, int64_t len, int linebases, int linewidth, int bin_size,
+                      double n_cutoff, int8_t *out);
+int tdt_gc_bins_fasta_device(tdt_ctx *ctx, const uint8_t *d_raw, int64_t nbytes, int64_t len, int linebases, int linewidth, int bin_size,
+                             double n_cutoff, int8_t *d_out);
 
 /* ---- signal clustering ("DBSCAN") ----------------------------------------------------------- *
  * Replaces DBSCAN.x_coordinate_clustering (DBSCAN.py:33-64), y_coordinate_clustering (:66-123) and
@@ -161,6 +169,10 @@ int tdt_region_counts_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t
  * size in *out_len; then call again with a buffer of at least that many bytes. */
 int tdt_format_coverage(const double *values, size_t n, const char *name, int64_t bin_size, int64_t contig_len, int kind, char *out,
                         size_t out_cap, size_t *out_len);
+
+/* FASTA index: writes `fai_path` in samtools faidx format (name, bases, offset of the first base, bases per line, bytes per
+ * line) — what the reference obtains from pysam.faidx when the .fai is missing (__main__.py:95-97). */
+int tdt_fasta_write_fai(const char *fasta_path, const char *fai_path);
 
 /* ---- BGZF inflate (host, threaded) ---------------------------------------------------------------- *
  * Replaces pysam/htslib's block reader (`pysam.AlignmentFile(bam, "r", threads=n)`, tiddit_signal.pyx:159,

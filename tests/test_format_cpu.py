@@ -52,3 +52,27 @@ def test_bed_and_wig_rows_match_the_python_loop(tmp_path):
                     want += "fixedStep chrom={} start=1 step={}\n".format(c["SN"], z)
                 want += tiddit_coverage._rows_python(cov[c["SN"]], c["SN"], c["LN"], z, kind)
             assert open(out).read() == want, (z, kind)
+
+
+def test_native_fai_matches_python_index(tmp_path):
+    """tdt_fasta_write_fai (one memchr pass) writes the same .fai as the line-by-line Python indexer: LF and CRLF files, a last
+    line without a line end, empty sequences, descriptions after the name, lines longer than the read buffer"""
+    build.build()
+    from tiddit_amd import fasta
+    rng = np.random.default_rng(6)
+    for eol, last_eol in ((b"\n", True), (b"\r\n", True), (b"\n", False)):
+        p = str(tmp_path / ("x%d%d.fa" % (len(eol), last_eol)))
+        with open(p, "wb") as f:
+            for name, ln, width in (("chr1 first contig", 12345, 60), ("c2\tdesc", 61, 61), ("empty", 0, 60), ("long", 20_000_000, 20_000_000),
+                                    ("last", 777, 70)):
+                f.write(b">" + name.encode() + eol)
+                s = np.array(list(b"ACGTN"), np.uint8)[rng.integers(0, 5, ln)].tobytes()
+                for o in range(0, ln, width):
+                    f.write(s[o:o + width] + eol)
+            if not last_eol:
+                f.seek(-len(eol), 2)
+                f.truncate()
+        want = fasta.build_fai(p)
+        py = open(p + ".fai").read()
+        _native.check(_native.load().tdt_fasta_write_fai(p.encode(), (p + ".fai2").encode()))
+        assert open(p + ".fai2").read() == py and len(want) == 5

@@ -571,3 +571,32 @@ def test_determine_ploidy_table(ctx, tmp_path):
     rows = open(str(tmp_path / "p.ploidies.tab")).read().splitlines()
     assert rows[0] == "Chromosome\tPloidy\tPloidy_rounded\tMean_coverage" and len(rows) == 4
     assert rows[1] == "chr1\t{}\t{}\t{}".format(want["chr1"] / lib["avg_coverage"] * 2, lib["contig_ploidy_chr1"], want["chr1"])
+
+
+@pytest.mark.parametrize("width,eol", [(60, "\n"), (61, "\n"), (70, "\r\n"), (1, "\n"), (7, "\n"), (100000, "\n"), (50, "\n"), (64, "\n")])
+def test_gc_from_fasta_layout_equals_stripped(tmp_path, width, eol):
+    """binned_gc straight from the file bytes (line ends in place) == the oracle on the stripped sequence, for line widths that
+    do and do not divide the bin, CRLF files, one-base lines, a single-line contig and contigs ending on / off a line end"""
+    from tiddit_amd import tiddit_gc
+    from tiddit_amd.fasta import FastaFile
+    rng = np.random.default_rng(width)
+    path = str(tmp_path / "r.fa")
+    seqs = {}
+    with open(path, "wb") as f:
+        for name, ln in (("a", 100_003), ("b", 60 * 70), ("c", 49), ("d", 250_000), ("e", 1)):
+            s = synth.gen_sequence(ln, seed=int(rng.integers(1, 1 << 30)))
+            s[rng.integers(0, ln, max(1, ln // 50))] = ord("N")
+            if ln > 5000:
+                s[1000:1000 + 2600] = ord("n")
+            seqs[name] = s
+            f.write((">%s some description%s" % (name, eol)).encode())
+            b = s.tobytes()
+            for o in range(0, ln, width):
+                f.write(b[o:o + width] + eol.encode())
+    fa = FastaFile(path)
+    for name, s in seqs.items():
+        for z in (50, 500, 7, 2048, 3000):
+            got = tiddit_gc.binned_gc(fa, name, z, 0.5)[1]
+            assert np.array_equal(got, oracle.binned_gc(s, z, 0.5)), (name, z)
+    g = tiddit_gc.main(path, ["a", "d"], 1, 50, 0.5)
+    assert np.array_equal(g["a"], oracle.binned_gc(seqs["a"], 50, 0.5)) and np.array_equal(g["d"], oracle.binned_gc(seqs["d"], 50, 0.5))

@@ -50,6 +50,8 @@ SYMBOLS = {
     "tdt_cov_finish_device": (_i, [_P, _i, _P]),
     "tdt_cov_kept": (_i, [_P, ctypes.POINTER(_i64)]),
     "tdt_gc_bins": (_i, [_P, _P, _i64, _i, _dbl, _P]),
+    "tdt_gc_bins_fasta": (_i, [_P, _P, _i64, _i64, _i, _i, _i, _dbl, _P]),
+    "tdt_gc_bins_fasta_device": (_i, [_P, _P, _i64, _i64, _i, _i, _i, _dbl, _P]),
     "tdt_gc_bins_device": (_i, [_P, _P, _i64, _i, _dbl, _P]),
     "tdt_dbscan": (_i, [_P, _P, _sz, _sz, _dbl, _i, _i, _P, ctypes.POINTER(_i64)]),
     "tdt_dbscan_device": (_i, [_P, _P, _P, _sz, _P, _i, ctypes.c_uint64, _i, _i, _P, _P]),
@@ -60,6 +62,7 @@ SYMBOLS = {
     "tdt_region_counts": (_i, [_P] * 9 + [_sz, _i, _i64, _P, _P, _P, _sz, _i, _i64, _P]),
     "tdt_region_counts_device": (_i, [_P] * 9 + [_sz, _i, _i, _i64, _P, _P, _P, _sz, _i, _i64, _P]),
     "tdt_format_coverage": (_i, [_P, _sz, ctypes.c_char_p, _i64, _i64, _i, _P, _sz, ctypes.POINTER(_sz)]),
+    "tdt_fasta_write_fai": (_i, [ctypes.c_char_p, ctypes.c_char_p]),
     "tdt_host_threads": (_i, [_i]),
     "tdt_bgzf_scan": (_i, [_P, _sz, _sz, _P, _P, _P]),
     "tdt_bgzf_inflate": (_i, [_P, _sz, _P, _sz, _i]),

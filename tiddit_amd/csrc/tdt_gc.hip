@@ -148,6 +148,76 @@ __global__ __launch_bounds__(GC_THREADS) void gc_small_bins(const uint8_t *__res
     }
 }
 
+// The same histogram straight from the FASTA bytes of a contig (line feeds still in place): base b sits at byte
+// fb(b) = (b / linebases) * linewidth + b % linebases of the contig's byte range.  Line-end bytes classify as neither GC nor
+// N, so phase 1 is unchanged; phase 2 gives bin j the bit range [fb(j*bin), fb(end-1)] and its true base count.  The
+// reference reads the file through pysam.FastaFile one 50-bp slice at a time (tiddit_gc.pyx:14-19); this removes the
+// host-side newline stripping (two full copies of a 3 GB genome) from the path.
+__global__ __launch_bounds__(GC_THREADS) void gc_fasta_bins(const uint8_t *__restrict__ raw, long long nbytes, long long len, int bin_size,
+                                                            unsigned linebases, unsigned linewidth, unsigned magic, int shift, int tile_bins,
+                                                            int max_chunks, long long nbins, unsigned n_min, signed char *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned gc_smem[];
+    const int words = (max_chunks + 1) >> 1;
+    unsigned *gbits = gc_smem;
+    unsigned *nbits = gc_smem + words;
+    unsigned short *g16 = reinterpret_cast<unsigned short *>(gbits);
+    unsigned short *n16 = reinterpret_cast<unsigned short *>(nbits);
+    const int tid = threadIdx.x;
+    auto fb = [&](unsigned b) -> long long {          // byte offset of base b (b < 2^31)
+        const unsigned line = shift < 0 ? b : (unsigned)(__umulhi(b, magic) >> shift);
+        return (long long)line * linewidth + (b - line * linebases);
+    };
+    for (long long tile = blockIdx.x; tile * tile_bins < nbins; tile += gridDim.x) {
+        const long long B0 = tile * (long long)tile_bins * bin_size;
+        long long B1 = B0 + (long long)tile_bins * bin_size;
+        if (B1 > len) B1 = len;
+        const long long f0 = fb((unsigned)B0) & ~15ll;                 // 16-byte aligned start of the tile's bytes
+        const long long f1 = fb((unsigned)(B1 - 1)) + 1;               // one past its last base
+        const int chunks = (int)((f1 - f0 + 15) >> 4);                 // <= max_chunks by construction
+        for (int c0 = 0; c0 < chunks; c0 += 4 * GC_THREADS) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = c0 + k * GC_THREADS + tid;
+                if (c < chunks) v[k] = gc_load16(raw, f0 + 16ll * c, nbytes);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = c0 + k * GC_THREADS + tid;
+                if (c < chunks) {
+                    unsigned gm, nm;
+                    gc_classify16(v[k], gm, nm);
+                    g16[c] = (unsigned short)gm;
+                    n16[c] = (unsigned short)nm;
+                }
+            }
+        }
+        if (tid == 0 && (chunks & 1)) {
+            g16[chunks] = 0;
+            n16[chunks] = 0;
+        }
+        __syncthreads();
+        for (int j = tid; j < tile_bins; j += GC_THREADS) {
+            const long long bin = tile * tile_bins + j;
+            if (bin >= nbins) break;
+            const long long b0 = bin * bin_size;
+            const long long b1 = b0 + bin_size < len ? b0 + bin_size : len;
+            const int lo = (int)(fb((unsigned)b0) - f0), hi = (int)(fb((unsigned)(b1 - 1)) - f0);   // inclusive bit range
+            const int w0 = lo >> 5, w1 = hi >> 5;
+            unsigned gcnt = 0, ncnt = 0;
+            for (int w = w0; w <= w1; w++) {
+                unsigned m = 0xffffffffu;
+                if (w == w0) m &= 0xffffffffu << (lo & 31);
+                if (w == w1) m &= 0xffffffffu >> (31 - (hi & 31));
+                gcnt += __popc(gbits[w] & m);
+                ncnt += __popc(nbits[w] & m);
+            }
+            out[bin] = gc_result32(gcnt, ncnt, (unsigned)(b1 - b0), n_min);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(GC_THREADS) void gc_large_bins(const uint8_t *__restrict__ seq, long long len,
                                                             long long bin_size, long long nbins, unsigned long long n_min,
                                                             signed char *__restrict__ out) {
@@ -253,6 +323,84 @@ extern "C" int tdt_gc_bins(tdt_ctx *ctx, const uint8_t *seq, int64_t len, int bi
     if (rc) return rc;
     TDT_HIP(hipMemcpyAsync(d_seq, seq, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
     rc = tdt_gc_bins_device(ctx, (const uint8_t *)d_seq, len, bin_size, n_cutoff, (int8_t *)d_out);
+    if (rc) return rc;
+    TDT_HIP(hipMemcpyAsync(out, d_out, nbins, hipMemcpyDeviceToHost, ctx->stream));
+    TDT_HIP(hipStreamSynchronize(ctx->stream));
+    return TDT_OK;
+}
+
+// FASTA-layout variants: `raw` = the contig's bytes exactly as in the file (nbytes of them, line ends included), `len` bases,
+// `linebases` bases per full line, `linewidth` bytes per full line (the .fai columns).
+extern "C" int tdt_gc_bins_fasta_device(tdt_ctx *ctx, const uint8_t *d_raw, int64_t nbytes, int64_t len, int linebases, int linewidth,
+                                        int bin_size, double n_cutoff, int8_t *d_out) {
+    if (!ctx || len < 0 || nbytes < 0 || bin_size <= 0 || (len > 0 && (!d_raw || !d_out))) {
+        tdt_set_error("tdt_gc_bins_fasta_device: bad argument");
+        return TDT_E_ARG;
+    }
+    if (len == 0) return TDT_OK;
+    if (linebases <= 0 || linewidth < linebases || linewidth > linebases + 2 || bin_size > GC_SMALL_MAX || len >= (1ll << 31) ||
+        ((uintptr_t)d_raw & 15) != 0) {
+        tdt_set_error("tdt_gc_bins_fasta_device: unsupported layout (linebases %d, linewidth %d, bin %d, len %lld): strip the line ends "
+                      "on the host and use tdt_gc_bins", linebases, linewidth, bin_size, (long long)len);
+        return TDT_E_UNSUPPORTED;
+    }
+    const long long nfull = len / linebases, tail = len - nfull * linebases;
+    const long long need = nfull * linewidth + tail - (tail == 0 ? (linewidth - linebases) : 0);
+    if (nbytes < need) {
+        tdt_set_error("tdt_gc_bins_fasta_device: %lld bytes cannot hold %lld bases at %d/%d per line", (long long)nbytes, (long long)len,
+                      linebases, linewidth);
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(ctx->device));
+    // floor(b / linebases) = mulhi(b, magic) >> shift for 0 <= b < 2^31 (round-up method, as for the coverage bins)
+    unsigned magic = 0;
+    int shift = -1;
+    if (linebases > 1) {
+        int l = 0;
+        while ((1ll << l) < linebases) l++;
+        const unsigned long long m = ((1ull << (31 + l)) + (unsigned long long)linebases - 1) / (unsigned long long)linebases;
+        if (m > 0xffffffffull) {
+            tdt_set_error("tdt_gc_bins_fasta_device: line length %d has no 32-bit reciprocal", linebases);
+            return TDT_E_UNSUPPORTED;
+        }
+        magic = (unsigned)m;
+        shift = l - 1;   // mulhi already drops 32 bits: (b * m) >> (31 + l) == mulhi(b, m) >> (l - 1)
+    }
+    const long long nbins = (len + bin_size - 1) / bin_size;
+    const unsigned long long n_min = gc_n_min(bin_size, n_cutoff);
+    int tile_bins = 65536 / bin_size;
+    tile_bins = tile_bins >= GC_THREADS ? tile_bins / GC_THREADS * GC_THREADS : (tile_bins & ~15);
+    if (tile_bins < 16) tile_bins = 16;
+    const long long tile_bases = (long long)tile_bins * bin_size;
+    const long long tile_span = (tile_bases / linebases + 2) * linewidth + 32;        // bytes a tile can cover, generously
+    const int max_chunks = (int)((tile_span + 15) >> 4);
+    const size_t lds = (size_t)((max_chunks + 1) / 2) * 2 * sizeof(unsigned);
+    long long grid = (nbins + tile_bins - 1) / tile_bins;
+    const long long cap = (long long)ctx->num_cu * 256;
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(gc_fasta_bins, dim3((unsigned)grid), dim3(GC_THREADS), lds, ctx->stream, d_raw, (long long)nbytes, (long long)len, bin_size,
+                       (unsigned)linebases, (unsigned)linewidth, magic, shift, tile_bins, max_chunks, nbins,
+                       n_min > 0xffffffffull ? 0xffffffffu : (unsigned)n_min, (signed char *)d_out);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
+extern "C" int tdt_gc_bins_fasta(tdt_ctx *ctx, const uint8_t *raw, int64_t nbytes, int64_t len, int linebases, int linewidth, int bin_size,
+                                 double n_cutoff, int8_t *out) {
+    if (!ctx || len < 0 || nbytes < 0 || bin_size <= 0 || (len > 0 && (!raw || !out))) {
+        tdt_set_error("tdt_gc_bins_fasta: bad argument");
+        return TDT_E_ARG;
+    }
+    if (len == 0) return TDT_OK;
+    TDT_HIP(hipSetDevice(ctx->device));
+    const size_t nbins = (size_t)((len + bin_size - 1) / bin_size);
+    void *d_raw = nullptr, *d_out = nullptr;
+    int rc = tdt_scratch(ctx, 1, (size_t)nbytes + 16, &d_raw);
+    if (rc) return rc;
+    rc = tdt_scratch(ctx, 2, nbins, &d_out);
+    if (rc) return rc;
+    TDT_HIP(hipMemcpyAsync(d_raw, raw, (size_t)nbytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = tdt_gc_bins_fasta_device(ctx, (const uint8_t *)d_raw, nbytes, len, linebases, linewidth, bin_size, n_cutoff, (int8_t *)d_out);
     if (rc) return rc;
     TDT_HIP(hipMemcpyAsync(out, d_out, nbins, hipMemcpyDeviceToHost, ctx->stream));
     TDT_HIP(hipStreamSynchronize(ctx->stream));

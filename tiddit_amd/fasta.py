@@ -8,6 +8,7 @@ import numpy as np
 
 
 def build_fai(path):
+    """Python reference of tdt_fasta_write_fai (csrc/tdt_format.hip), kept for the CPU tests"""
     entries = []
     with open(path, "rb") as f:
         name = None
@@ -40,7 +41,8 @@ class FastaFile:
     def __init__(self, path):
         self.path = path
         if not os.path.isfile(path + ".fai"):
-            build_fai(path)
+            from . import _native
+            _native.check(_native.load().tdt_fasta_write_fai(path.encode(), (path + ".fai").encode()))   # build_fai() in C
         self.index = {}
         self.references = []
         for line in open(path + ".fai"):
@@ -66,6 +68,19 @@ class FastaFile:
             return raw[:length].copy()
         body = raw[:nfull * linewidth].reshape(nfull, linewidth)[:, :linebases].reshape(-1)
         return np.concatenate([body, raw[nfull * linewidth:nfull * linewidth + tail]])
+
+    def fetch_raw(self, contig):
+        """the contig's bytes exactly as they are in the file (line ends included) -> (uint8[nbytes], length, linebases, linewidth);
+        the GC kernel reads this layout directly (csrc/tdt_gc.hip: gc_fasta_bins), so nothing is stripped or copied on the host"""
+        length, offset, linebases, linewidth = self.index[contig]
+        if length == 0:
+            return np.zeros(0, dtype=np.uint8), 0, linebases, linewidth
+        nfull = length // linebases if linebases else 0
+        tail = length - nfull * linebases
+        nbytes = nfull * linewidth + tail
+        if tail == 0:
+            nbytes -= linewidth - linebases
+        return np.fromfile(self.path, dtype=np.uint8, count=nbytes, offset=offset), length, linebases, linewidth
 
     def fetch(self, contig, start=0, end=None):
         a = self.fetch_array(contig)

@@ -28,9 +28,21 @@ def binned_gc_array(seq, bin_size, n_cutoff, ctx=None):
     return out
 
 
-def binned_gc(fasta_path, contig, bin_size, n_cutoff):
+def binned_gc(fasta_path, contig, bin_size, n_cutoff, ctx=None):
+    """tiddit_gc.pyx:6-33.  The contig's bytes go to the device as they are in the file; the kernel steps over the line ends."""
     fasta = fasta_path if isinstance(fasta_path, FastaFile) else FastaFile(fasta_path)
-    return [contig, binned_gc_array(fasta.fetch_array(contig), bin_size, n_cutoff)]
+    bin_size = int(bin_size)
+    if bin_size <= 0:
+        raise ZeroDivisionError("bin_size must be positive")
+    length, _, linebases, linewidth = fasta.index[contig]
+    if 0 < bin_size <= 2048 and 0 < length < (1 << 31) and 0 < linebases <= linewidth <= linebases + 2:
+        ctx = ctx or _native.default_context()
+        raw, length, linebases, linewidth = fasta.fetch_raw(contig)
+        out = numpy.zeros(-(-length // bin_size), dtype=numpy.int8)
+        _native.check(ctx.lib.tdt_gc_bins_fasta(ctx.handle, _native.ptr(raw), len(raw), length, linebases, linewidth, bin_size,
+                                                float(n_cutoff), _native.ptr(out)))
+        return [contig, out]
+    return [contig, binned_gc_array(fasta.fetch_array(contig), bin_size, n_cutoff, ctx)]
 
 
 def main(reference, contigs, threads, bin_size, n_cutoff):
