@@ -165,3 +165,15 @@ def test_region_counts_vs_literal_loop(sv_bam):
     cov, flq, nd, ns, cf, cr = tiddit_region.get_region(table, "chr1", 1000, 1500, 1200, 5, 600)
     w = oracle.get_region_counts(table.contigs[0], 0, CONTIGS[0][1], 1000, 1500, 1200, 5, 600)
     assert cov == w[0] / 501 and nd == w[3] and ns == w[4] and cf == w[5] and cr == w[6]
+
+
+def test_signal_worker_has_the_reference_shape(sv_bam, tmp_path):
+    """tiddit_signal.worker (per-contig entry point of the reference, tiddit_signal.pyx:147-228): same rows as the whole-file scan"""
+    from tiddit_amd import tiddit_signal
+    bam, fa, info, d = sv_bam
+    header, chroms, cov, data, splits, clips = tiddit_signal.scan_signals(bam, 5, 600, 0, 30, 20, 50)
+    prefix = str(tmp_path / "w")
+    for chrom in chroms[:3]:
+        name, rows, srows, bins, path = tiddit_signal.worker(chrom, bam, fa, prefix, 5, 600, "SYN", 50, True, 30, 20)
+        assert name == chrom and rows == data[chrom] and srows == splits[chrom] and np.array_equal(bins, cov[chrom])
+        assert open(path).read() == "".join("".join(c) for c in clips[chrom])

@@ -204,6 +204,28 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     return header, chromosomes, coverage, data, splits, clips
 
 
+_SCAN_CACHE = {}
+
+
+def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bin_size, skip_index, min_anchor_len, min_clip_len):
+    """One contig's share of the scan with the reference's signature and return value (tiddit_signal.pyx:147-228):
+    ``(chromosome, discordant rows, split rows, float64 coverage bins, path of the clipped-read FASTA)``.  The reference runs
+    one indexed pysam pass per contig in a joblib worker; here ONE device pass over the file serves every contig (cached per
+    file and parameter set), so calling ``worker`` contig by contig costs one scan in total."""
+    key = (os.path.abspath(bam_file_name), os.path.getmtime(bam_file_name), min_q, max_ins, bin_size, min_anchor_len, min_clip_len)
+    if key not in _SCAN_CACHE:
+        _SCAN_CACHE.clear()
+        _SCAN_CACHE[key] = scan_signals(bam_file_name, min_q, max_ins, 0, min_anchor_len, min_clip_len, bin_size)
+    header, chromosomes, coverage, data, splits, clips = _SCAN_CACHE[key]
+    print("Collecting signals on contig: {}".format(chromosome))
+    os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
+    path = "{}_tiddit/clips/{}.fa".format(prefix, chromosome)
+    with open(path, "w") as f:
+        for clip in clips[chromosome]:
+            f.write("".join(clip))
+    return (chromosome, data[chromosome], splits[chromosome], coverage[chromosome], path)
+
+
 def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
     t = time.time()
     header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
