@@ -661,3 +661,47 @@ def test_device_ingest_degenerate_files(ctx, tmp_path):
             assert all(l.endswith("\t0.0") for l in bed[1:])
         else:
             assert bed[1].endswith("\t0.10000000149011612")               # 50 bases / 500 as float32
+
+
+def _libdeflate():
+    import ctypes
+    try:
+        L = ctypes.CDLL("libdeflate.so.0")
+    except OSError:
+        return None
+    L.libdeflate_alloc_compressor.restype = ctypes.c_void_p
+    L.libdeflate_alloc_compressor.argtypes = [ctypes.c_int]
+    L.libdeflate_deflate_compress.restype = ctypes.c_size_t
+    L.libdeflate_deflate_compress.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    L.libdeflate_deflate_compress_bound.restype = ctypes.c_size_t
+    L.libdeflate_deflate_compress_bound.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.libdeflate_free_compressor.argtypes = [ctypes.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("kernel", ["lanes", "sequential"])
+def test_device_inflate_libdeflate_streams(ctx, kernel, monkeypatch):
+    """htslib >= 1.10 writes BAM through libdeflate, whose DEFLATE streams are shaped differently from zlib's (block splitting,
+    code-length choices, fixed blocks for short data): every level's output inflates to the same bytes on the device"""
+    import ctypes
+    L = _libdeflate()
+    if L is None:
+        pytest.skip("libdeflate.so.0 not present")
+    if kernel == "sequential":
+        monkeypatch.setenv("TIDDIT_INFLATE_SEQ", "1")
+    cases = _cases()
+    for level in (1, 3, 6, 9, 12):
+        comp = L.libdeflate_alloc_compressor(level)
+        for name, data in cases.items():
+            out = b""
+            for o in range(0, max(1, len(data)), 0xff00):
+                d = data[o:o + 0xff00]
+                cap = L.libdeflate_deflate_compress_bound(comp, len(d))
+                buf = ctypes.create_string_buffer(cap)
+                n = L.libdeflate_deflate_compress(comp, d, len(d), buf, cap)
+                assert n > 0
+                raw = buf.raw[:n]
+                out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
+                        struct.pack("<II", zlib.crc32(d) & 0xffffffff, len(d)))
+            assert _inflate_hbm(ctx, out + bamio._BGZF_EOF, len(data)) == data, (name, level)
+        L.libdeflate_free_compressor(comp)
