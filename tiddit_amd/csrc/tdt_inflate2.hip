@@ -418,11 +418,14 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 err = op + tot > isize ? B2_E_OVERRUN : B2_E_DIST;
                 break;
             }
+#ifndef B2_EXP_NOLIT   // B2_EXP_*: ablation switches (tools/build_variant.sh) behind the stage costs quoted in DESIGN.md 3.6
             if (on && is_lit) dst[pos] = (unsigned char)base1;
+#endif
             const unsigned srco = pos - dist;                       // first source byte of this lane's match
             // Matches whose source lies wholly before this window's output cannot depend on anything decoded in it: each of
             // those is copied by its own lane, all at once (3 bytes unconditionally — the minimum match — then the rest).
             const bool par = copy && srco + mlen <= op && mlen <= 16;
+#ifndef B2_EXP_NOPAR
             if (par) {
                 const unsigned char b0 = dst[srco], b1 = dst[srco + 1], b2 = dst[srco + 2];
                 dst[pos] = b0;
@@ -431,7 +434,12 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             }
             for (unsigned k = 3; __ballot(par && k < mlen); k++)
                 if (par && k < mlen) dst[pos + k] = dst[srco + k];
+#endif
+#ifdef B2_EXP_NOSEQ
+            u64 mm = 0;
+#else
             u64 mm = __ballot(copy && !par);
+#endif
             while (mm) {                                            // the others in stream order (they may read each other's output)
                 const unsigned l = (unsigned)__builtin_ctzll(mm);
                 mm &= ~(1ull << l);
