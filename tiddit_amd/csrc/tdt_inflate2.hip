@@ -46,6 +46,9 @@ enum { B2_MODE_RAW = 0, B2_MODE_LL = 1, B2_MODE_DIST = 2 };
 enum { B2_OK = 0, B2_E_BTYPE = 1, B2_E_STORED = 2, B2_E_TABLE = 3, B2_E_SYMBOL = 4, B2_E_DIST = 5, B2_E_OVERRUN = 6, B2_E_INPUT = 7, B2_E_SIZE = 8 };
 
 typedef unsigned long long u64;
+struct __attribute__((packed, aligned(1))) B2U32 {
+    unsigned v;
+};
 
 __device__ __forceinline__ unsigned b2_rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned b2_rl(unsigned v, unsigned lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)lane); }
@@ -427,10 +430,10 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             const bool par = copy && srco + mlen <= op && mlen <= 16;
 #ifndef B2_EXP_NOPAR
             if (par) {
-                const unsigned char b0 = dst[srco], b1 = dst[srco + 1], b2 = dst[srco + 2];
-                dst[pos] = b0;
-                dst[pos + 1] = b1;
-                dst[pos + 2] = b2;
+                const unsigned w4 = reinterpret_cast<const B2U32 *>(dst + srco)->v;   // one unaligned load (the 4th byte is unused)
+                dst[pos] = (unsigned char)w4;
+                dst[pos + 1] = (unsigned char)(w4 >> 8);
+                dst[pos + 2] = (unsigned char)(w4 >> 16);
             }
             for (unsigned k = 3; __ballot(par && k < mlen); k++)
                 if (par && k < mlen) dst[pos + k] = dst[srco + k];
