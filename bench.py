@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-gc", action="store_true")
     ap.add_argument("--gc-len", type=int, default=3_000_000_000, help="reference bases for the GC histogram pass")
     ap.add_argument("--no-ingest", action="store_true")
+    ap.add_argument("--no-next", action="store_true", help="skip the small next-row kernels (masked medians, regional evidence counts)")
     ap.add_argument("--ingest-mb", type=int, default=8, help="Mb per contig (2 contigs, 30x, 100-bp reads) of the BAM the ingest pass reads")
     return ap.parse_args()
 
@@ -383,6 +384,80 @@ def main():
             ires["cpu_baseline"] = {"value": hk / t_host, "unit": "records/s", "cores": threads, "kind": "port",
                                     "sample": "same file, zlib inflate + C record decode on %d host threads (this library's host path)" % threads}
         result["ingest"] = ires
+
+    # ---- the other next-row kernels: masked coverage medians, regional evidence counts — rank 0, small
+    if not args.no_next and rank == 0:
+        from tiddit_amd import tiddit_coverage_analysis as tca
+        rng = np.random.default_rng(11)
+        pairs = [(rng.gamma(30, 1.0, 250_000), np.where(rng.random(250_000) < 0.03, -1, 41).astype(np.int8)) for _ in range(24)]
+        tca.masked_medians(pairs[:2])
+        t0 = time.perf_counter()
+        med, allm = tca.masked_medians(pairs)
+        t_dev = time.perf_counter() - t0
+        nres = {"median": {"metric": "masked medians of 24 x 250000 coverage bins + the genome-wide one (determine_ploidy), host arrays in",
+                           "ms": 1e3 * t_dev, "bins_per_sec": 6_000_000 / t_dev}}
+        if not args.no_cpu_baseline:
+            t0 = time.perf_counter()
+            ref = [float(np.median(c[(c > 0) & (g != -1)])) for c, g in pairs]
+            refall = float(np.median(np.concatenate([c[(c > 0) & (g != -1)] for c, g in pairs])))
+            t_np = time.perf_counter() - t0
+            if med != ref or allm != refall:
+                raise SystemExit("PARITY FAILURE: device medians differ from numpy.median")
+            nres["median"]["cpu_baseline"] = {"value": 6_000_000 / t_np, "unit": "bins/s", "cores": 1, "kind": "port",
+                                              "sample": "numpy boolean mask + numpy.median, the reference's own method"}
+            nres["median"]["parity_checked"] = True
+        # regional evidence counts: one contig of the coverage stream as the read table, 100k candidate regions
+        L1 = args.contig_len
+        r_start, r_end, r_mapq, r_flag = synth.gen_reads_device(L1, args.depth, dev, seed=synth.SEED + 77)
+        n1 = int(r_start.numel())
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(5)
+        ins = (torch.randn(n1, generator=g2, device=dev) * 50 + 350).to(torch.int32)
+        mate_pos = torch.clamp(r_start + ins, 0, L1 - 1)
+        tlen = (mate_pos - r_start + 150).to(torch.int32)
+        mate_tid = torch.where(torch.rand(n1, generator=g2, device=dev) < 0.01, 3, 0).to(torch.int32)
+        has_sa = (torch.rand(n1, generator=g2, device=dev) < 0.01).to(torch.uint8)
+        NQ = 100_000
+        qs = torch.randint(0, L1 - 5000, (NQ,), generator=g2, device=dev, dtype=torch.int32)
+        qe = qs + torch.randint(0, 2000, (NQ,), generator=g2, device=dev, dtype=torch.int32)
+        qb = torch.where(torch.rand(NQ, generator=g2, device=dev) < 0.5, qs, qe)
+        rout = torch.zeros(NQ, 7, dtype=torch.int64, device=dev)
+        max_span = int((r_end - r_start).max().item())
+        torch.cuda.synchronize()
+
+        def region_call():
+            _native.check(ctx.lib.tdt_region_counts_device(ctx.handle, r_start.data_ptr(), r_end.data_ptr(), r_mapq.data_ptr(), r_flag.data_ptr(),
+                                                           mate_tid.data_ptr(), mate_pos.data_ptr(), tlen.data_ptr(), has_sa.data_ptr(), n1, 0,
+                                                           max_span, L1, qs.data_ptr(), qe.data_ptr(), qb.data_ptr(), NQ, 5, 600, rout.data_ptr()))
+
+        with torch.cuda.stream(stream):
+            region_call()
+            stream.synchronize()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(stream)
+            for _ in range(10):
+                region_call()
+            eb.record(stream)
+            stream.synchronize()
+        r_ms = ea.elapsed_time(eb) / 10
+        nres["region"] = {"metric": "get_region evidence counts, candidates/sec (one 30x contig of %d reads resident, %d candidate regions)" % (n1, NQ),
+                          "value": NQ / (r_ms * 1e-3), "unit": "candidates/s", "ms": r_ms}
+        if not args.no_cpu_baseline:
+            import oracle
+            tab = dict(start=r_start.cpu().numpy(), end=r_end.cpu().numpy(), mapq=r_mapq.cpu().numpy(), flag=r_flag.cpu().numpy().view(np.uint16),
+                       mate_tid=mate_tid.cpu().numpy(), mate_pos=mate_pos.cpu().numpy(), tlen=tlen.cpu().numpy(), has_sa=has_sa.cpu().numpy())
+            hq = (qs.cpu().numpy(), qe.cpu().numpy(), qb.cpu().numpy())
+            got = rout.cpu().numpy()
+            t0 = time.perf_counter()
+            for q in range(0, NQ, NQ // 16):
+                want = oracle.get_region_counts(tab, 0, L1, int(hq[0][q]), int(hq[1][q]), int(hq[2][q]), 5, 600)
+                if not np.array_equal(got[q], want):
+                    raise SystemExit("PARITY FAILURE: region counts differ from the literal loop at candidate %d" % q)
+            t_lit = (time.perf_counter() - t0) / 16
+            nres["region"]["cpu_baseline"] = {"value": 1.0 / t_lit, "unit": "candidates/s", "cores": 1, "kind": "port",
+                                              "sample": "16 of the candidates through the literal per-read loop (full scan of the contig's reads per candidate)"}
+            nres["region"]["parity_checked"] = True
+        result["next_rows"] = nres
 
     if rank == 0:
         print(json.dumps(result))
