@@ -42,21 +42,42 @@ class ReadTable:
             self.contigs[t]["has_sa"] = numpy.concatenate(d["has_sa"]) if d["has_sa"] else numpy.zeros(0, dtype=numpy.uint8)
 
 
+def _resident(table, t, ctx):
+    """the contig's arrays in HBM (uploaded on first use, kept for the life of the table) -> (dict of tensors, max read span)"""
+    import torch
+    cache = table.__dict__.setdefault("_device", {})
+    if t not in cache:
+        a = table.contigs[t]
+        dev = torch.device("cuda", ctx.device)
+        ten = {k: torch.from_numpy(v.view(numpy.int16) if v.dtype == numpy.uint16 else v).to(dev) for k, v in a.items()}
+        if len(a["start"]) and numpy.any(numpy.diff(a["start"]) < 0):
+            raise ValueError("tiddit_region: reads of %s are not coordinate sorted" % table.references[t])
+        span = int((a["end"].astype(numpy.int64) - a["start"]).max()) if len(a["start"]) else 1
+        torch.cuda.synchronize(dev)
+        cache[t] = (ten, max(1, span))
+    return cache[t]
+
+
 def region_counts(table, chrom, starts, ends, bps, min_q, max_ins, ctx=None):
-    """-> int64[nq, 7]: bases, n_reads, low_q, n_discs, n_splits, crossing_f, crossing_r for every (start, end, bp)"""
+    """-> int64[nq, 7]: bases, n_reads, low_q, n_discs, n_splits, crossing_f, crossing_r for every (start, end, bp).
+    The contig's reads stay resident on the device between calls; only the candidates travel."""
+    import torch
     ctx = ctx or _native.default_context()
     t = table.tid[chrom]
-    a = table.contigs[t]
-    qs = numpy.ascontiguousarray(starts, dtype=numpy.int32)
-    qe = numpy.ascontiguousarray(ends, dtype=numpy.int32)
-    qb = numpy.ascontiguousarray(bps, dtype=numpy.int32)
-    out = numpy.zeros((len(qs), 7), dtype=numpy.int64)
-    _native.check(ctx.lib.tdt_region_counts(ctx.handle, _native.ptr(a["start"]), _native.ptr(a["end"]), _native.ptr(a["mapq"]),
-                                            _native.ptr(a["flag"]), _native.ptr(a["mate_tid"]), _native.ptr(a["mate_pos"]),
-                                            _native.ptr(a["tlen"]), _native.ptr(a["has_sa"]), len(a["start"]), t, table.lengths[t],
-                                            _native.ptr(qs), _native.ptr(qe), _native.ptr(qb), len(qs), int(min_q), int(max_ins),
-                                            _native.ptr(out)))
-    return out
+    ten, span = _resident(table, t, ctx)
+    dev = ten["start"].device
+    nq = len(starts)
+    q = torch.from_numpy(numpy.ascontiguousarray(numpy.stack([numpy.asarray(starts), numpy.asarray(ends), numpy.asarray(bps)]), dtype=numpy.int32)).to(dev)
+    out = torch.empty((nq, 7), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(dev)                       # torch's copies run on its stream, the library on its own
+    n = int(ten["start"].numel())
+    _native.check(ctx.lib.tdt_region_counts_device(ctx.handle, ten["start"].data_ptr(), ten["end"].data_ptr(), ten["mapq"].data_ptr(),
+                                                   ten["flag"].data_ptr(), ten["mate_tid"].data_ptr(), ten["mate_pos"].data_ptr(),
+                                                   ten["tlen"].data_ptr(), ten["has_sa"].data_ptr(), n, t, span, table.lengths[t],
+                                                   q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), nq, int(min_q), int(max_ins),
+                                                   out.data_ptr()))
+    ctx.sync()
+    return out.cpu().numpy()
 
 
 def get_region(table, chrom, start, end, bp, min_q, max_ins, contig_number=None):
