@@ -131,9 +131,12 @@ def write_synthetic_bam(path, contigs, depth=10, read_len=100, insert=350, inser
     return {"events": events, "n_records": len(recs)}
 
 
-def write_bulk_bam(path, contigs, depth=30, read_len=100, insert=350, seed=1, level=1, threads=8, chunk=1 << 20):
+def write_bulk_bam(path, contigs, depth=30, read_len=100, insert=350, seed=1, level=1, threads=8, chunk=1 << 20, realistic=False):
     """Large plain paired-end BAM written with numpy (fixed-size records: 12-byte name, one M cigar op, no aux), for
-    end-to-end timing of the BGZF/BAM ingest.  ~10 M records/min.  -> number of records."""
+    end-to-end timing of the BGZF/BAM ingest.  ~10 M records/min.  -> number of records.
+    realistic: reads are cut from one random reference per contig (overlapping reads share sequence, as in a real
+    coordinate-sorted BAM, so DEFLATE finds long matches) and base qualities come in runs; the default draws every base and
+    quality independently (hard to compress, short matches)."""
     import struct
     from concurrent.futures import ThreadPoolExecutor
     from .bamio import _BGZF_EOF, _bgzf_block
@@ -160,6 +163,7 @@ def write_bulk_bam(path, contigs, depth=30, read_len=100, insert=350, seed=1, le
             del pend[:nblk * 0xff00]
 
         for tid, (name, L) in enumerate(contigs):
+            ref_nib = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, L + read_len + 2, dtype=np.uint8)] if realistic else None
             n_pairs = int(L * depth / (2 * read_len))
             posA = rng.integers(0, max(1, L - insert - 100), n_pairs).astype(np.int64)
             ins = np.maximum(read_len + 1, rng.normal(insert, 30, n_pairs).astype(np.int64))
@@ -186,9 +190,17 @@ def write_bulk_bam(path, contigs, depth=30, read_len=100, insert=350, seed=1, le
                 digits = (ids[:, None] // (10 ** np.arange(10, -1, -1, dtype=np.int64))[None, :] % 10 + 48).astype(np.uint8)
                 a["name"] = np.concatenate([digits, np.zeros((m, 1), np.uint8)], axis=1).view("S12")[:, 0]
                 a["cigar"] = (read_len << 4) | 0
-                nib = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, (m, read_len + (read_len & 1)), dtype=np.uint8)]
+                if realistic:
+                    idx = pos[lo:hi, None] + np.arange(read_len + (read_len & 1))[None, :]
+                    nib = ref_nib[idx]
+                    mism = rng.random(nib.shape) < 0.003                      # sequencing errors / variants
+                    nib = np.where(mism, np.roll(nib, 1, axis=1), nib)
+                    q = np.repeat(qual_lut[rng.integers(96, 256, (m, (read_len + 9) // 10), dtype=np.uint8)], 10, axis=1)[:, :read_len]
+                    a["qual"] = np.where(rng.random((m, read_len)) < 0.1, qual_lut[rng.integers(0, 256, (m, read_len), dtype=np.uint8)], q)
+                else:
+                    nib = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, (m, read_len + (read_len & 1)), dtype=np.uint8)]
+                    a["qual"] = qual_lut[rng.integers(0, 256, (m, read_len), dtype=np.uint8)]
                 a["seq"] = (nib[:, 0::2] << 4) | nib[:, 1::2]
-                a["qual"] = qual_lut[rng.integers(0, 256, (m, read_len), dtype=np.uint8)]
                 pend += a.tobytes()
                 flush()
             total += len(pos)

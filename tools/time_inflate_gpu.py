@@ -5,9 +5,10 @@ import numpy as np
 from tiddit_amd import _native, synth_bam
 mb = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-path = "/tmp/bulk_inf_%d_%d.bam" % (mb, level)
+realistic = "--realistic" in sys.argv
+path = "/tmp/bulk_inf_%d_%d%s.bam" % (mb, level, "_real" if realistic else "")
 if not os.path.exists(path):
-    synth_bam.write_bulk_bam(path, [("chr1", mb * 1_000_000), ("chr2", mb * 1_000_000)], depth=30, threads=16, level=level)
+    synth_bam.write_bulk_bam(path, [("chr1", mb * 1_000_000), ("chr2", mb * 1_000_000)], depth=30, threads=16, level=level, realistic=realistic)
 ctx = _native.default_context(); lib = ctx.lib
 comp = np.fromfile(path, dtype=np.uint8)
 nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
