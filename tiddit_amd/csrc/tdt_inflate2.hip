@@ -49,6 +49,9 @@ typedef unsigned long long u64;
 struct __attribute__((packed, aligned(1))) B2U32 {
     unsigned v;
 };
+struct __attribute__((packed, aligned(1))) B2U128 {
+    unsigned w[4];
+};
 
 __device__ __forceinline__ unsigned b2_rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned b2_rl(unsigned v, unsigned lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)lane); }
@@ -430,13 +433,20 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             const bool par = copy && srco + mlen <= op && mlen <= 16;
 #ifndef B2_EXP_NOPAR
             if (par) {
-                const unsigned w4 = reinterpret_cast<const B2U32 *>(dst + srco)->v;   // one unaligned load (the 4th byte is unused)
-                dst[pos] = (unsigned char)w4;
-                dst[pos + 1] = (unsigned char)(w4 >> 8);
-                dst[pos + 2] = (unsigned char)(w4 >> 16);
+                // all (<= 16) source bytes in ONE unaligned load, then the stores: a byte-by-byte loop costs one memory round trip
+                // per byte, and on BAM-shaped data the typical match is ~10 bytes long
+                const B2U128 v = *reinterpret_cast<const B2U128 *>(dst + srco);
+                unsigned char *const p_ = dst + pos;
+                if (mlen >= 4) reinterpret_cast<B2U32 *>(p_)->v = v.w[0];
+                if (mlen >= 8) reinterpret_cast<B2U32 *>(p_ + 4)->v = v.w[1];
+                if (mlen >= 12) reinterpret_cast<B2U32 *>(p_ + 8)->v = v.w[2];
+                if (mlen >= 16) reinterpret_cast<B2U32 *>(p_ + 12)->v = v.w[3];
+                const unsigned q4 = mlen >> 2, t = mlen & 3, b4 = mlen & ~3u;
+                const unsigned wt = q4 == 0 ? v.w[0] : q4 == 1 ? v.w[1] : q4 == 2 ? v.w[2] : v.w[3];
+                if (t >= 1) p_[b4] = (unsigned char)wt;
+                if (t >= 2) p_[b4 + 1] = (unsigned char)(wt >> 8);
+                if (t == 3) p_[b4 + 2] = (unsigned char)(wt >> 16);
             }
-            for (unsigned k = 3; __ballot(par && k < mlen); k++)
-                if (par && k < mlen) dst[pos + k] = dst[srco + k];
 #endif
 #ifdef B2_EXP_NOSEQ
             u64 mm = 0;
