@@ -432,7 +432,10 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             // those is copied by its own lane, all at once (3 bytes unconditionally — the minimum match — then the rest).
             const bool par = copy && srco + mlen <= op && mlen <= 16;
 #ifndef B2_EXP_NOPAR
-            if (par) {
+            const bool wide = par && srco + 16 <= isize;            // the 16-byte read stays inside this block's output
+            if (par && !wide)                                       // (a source in the block's last bytes: plain byte copy)
+                for (unsigned k = 0; k < mlen; k++) dst[pos + k] = dst[srco + k];
+            if (wide) {
                 // all (<= 16) source bytes in ONE unaligned load, then the stores: a byte-by-byte loop costs one memory round trip
                 // per byte, and on BAM-shaped data the typical match is ~10 bytes long
                 const B2U128 v = *reinterpret_cast<const B2U128 *>(dst + srco);
