@@ -81,6 +81,19 @@ def parse_bam(path):
             elif typ == "A":
                 r.tags[tag] = chr(raw[p])
                 p += 1
+            elif typ in "cCsSIf":
+                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "I": "I", "f": "f"}[typ]
+                r.tags[tag] = struct.unpack_from("<" + fmt, raw, p)[0]
+                p += struct.calcsize(fmt)
+            elif typ == "H":
+                e = raw.index(b"\x00", p)
+                r.tags[tag] = raw[p:e].decode()
+                p = e + 1
+            elif typ == "B":
+                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[chr(raw[p])]
+                cnt = struct.unpack_from("<I", raw, p + 1)[0]
+                r.tags[tag] = list(struct.unpack_from("<%d%s" % (cnt, fmt), raw, p + 5))
+                p += 5 + cnt * struct.calcsize(fmt)
             else:
                 raise ValueError("tag type " + typ)
         r.flag, r.mapq, r.isize = flag, mapq, tlen

@@ -705,3 +705,18 @@ def test_device_inflate_libdeflate_streams(ctx, kernel, monkeypatch):
                         struct.pack("<II", zlib.crc32(d) & 0xffffffff, len(d)))
             assert _inflate_hbm(ctx, out + bamio._BGZF_EOF, len(data)) == data, (name, level)
         L.libdeflate_free_compressor(comp)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_device_ingest_random_legal_records(ctx, tmp_path, seed):
+    """the record sanity checks behind the parallel record finder must accept every legal record: twelve random files, every field
+    equal to the host decoder's, and not one batch handed to the host chase"""
+    path = str(tmp_path / "rnd.bam")
+    n = synth_bam.write_random_bam(path, 100 + seed)
+    want, sa_w, _ = _host_records(path)
+    got, sa_g, runs_ok, nb, hc = _device_records(path, ctx, int(np.random.default_rng(seed).choice([1 << 28, 70_000, 200_000])))
+    assert len(want["tid"]) == n == len(got["tid"])
+    for k in FIELDS:
+        if k not in ("rec_off", "sa_off"):
+            assert np.array_equal(want[k], got[k]), k
+    assert sa_w == sa_g and runs_ok and hc == 0

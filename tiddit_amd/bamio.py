@@ -690,6 +690,14 @@ class BamWriter:
                 aux += tag.encode() + b"i" + struct.pack("<i", val)
             elif typ == "A":
                 aux += tag.encode() + b"A" + val.encode()
+            elif typ in "cCsSIf":
+                aux += tag.encode() + typ.encode() + struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "I": "I", "f": "f"}[typ], val)
+            elif typ == "H":
+                aux += tag.encode() + b"H" + val.encode() + b"\x00"
+            elif typ.startswith("B"):                                  # ("XB", "BS", [1, 2, 3]): array of subtype S
+                sub = typ[1]
+                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+                aux += tag.encode() + b"B" + sub.encode() + struct.pack("<I", len(val)) + struct.pack("<%d%s" % (len(val), fmt), *val)
             else:
                 raise ValueError("unsupported tag type " + typ)
         body = (struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, _reg2bin(pos, pos + rlen), len(cig), flag, lseq, mate_tid,

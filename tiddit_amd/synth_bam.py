@@ -207,3 +207,43 @@ def write_bulk_bam(path, contigs, depth=30, read_len=100, insert=350, seed=1, le
         flush(final=True)
         f.write(_BGZF_EOF)
     return total
+
+
+def write_random_bam(path, seed):
+    """records of every legal shape: names of 1..250 printable characters, CIGARs with all nine operations, empty sequences,
+    unmapped reads, aux fields of every type (arrays included) around an optional SA:Z"""
+    rng = np.random.default_rng(seed)
+    refs = [("r%d" % i, int(rng.integers(1000, 3_000_000))) for i in range(int(rng.integers(1, 40)))]
+    w = BamWriter(path, refs, level=int(rng.integers(1, 7)), align_records=bool(rng.integers(0, 2)))
+    printable = [chr(c) for c in range(33, 127) if chr(c) != "@"]
+    n = int(rng.integers(200, 3000))
+    pos, tid = 0, 0
+    for i in range(n):
+        if rng.random() < 0.02 and tid + 1 < len(refs):
+            tid, pos = tid + 1, 0
+        pos = min(refs[tid][1] - 1, pos + int(rng.integers(0, 50)))
+        name = "".join(rng.choice(printable, int(rng.choice([1, 2, 5, 20, 40, 100, 250]))))
+        kind = rng.random()
+        if kind < 0.05:                                                 # unmapped, no CIGAR
+            cig, lseq, flag, t, p = [], int(rng.integers(0, 200)), 4 | 1, -1 if rng.random() < 0.5 else tid, -1 if rng.random() < 0.5 else pos
+        else:
+            ops = []
+            for _ in range(int(rng.integers(1, 12))):
+                ops.append((int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8])), int(rng.integers(1, 300))))
+            lseq = sum(l for op, l in ops if op in (0, 1, 4, 7, 8))
+            if rng.random() < 0.05:
+                lseq = 0                                                # secondary alignments may omit the sequence
+            cig, flag, t, p = ops, int(rng.choice([0, 16, 99, 147, 256, 2048 + 16, 1024 + 83])), tid, pos
+        tags = []
+        for _ in range(int(rng.integers(0, 6))):
+            ty = str(rng.choice(["A", "c", "C", "s", "S", "i", "I", "f", "Z", "H", "BC", "Bs", "Bi", "Bf"]))
+            tg = "X" + str(rng.choice(list("ABCDEFGH")))
+            val = {"A": "q", "c": -5, "C": 200, "s": -3000, "S": 60000, "i": -70000, "I": 4000000000, "f": 1.5, "Z": "some text", "H": "1AE301",
+                   "BC": [1, 2, 3], "Bs": [-1, 5], "Bi": list(range(int(rng.integers(0, 40)))), "Bf": [0.5]}[ty]
+            tags.append((tg, ty, val))
+        if rng.random() < 0.1:
+            tags.insert(int(rng.integers(0, len(tags) + 1)), ("SA", "Z", "r0,%d,+,30M70S,%d,1;" % (pos + 5, int(rng.integers(0, 60)))))
+        w.write(name, flag, t, p, int(rng.integers(0, 256)), cig, t if rng.random() < 0.8 else -1, int(rng.integers(-1, 1000)),
+                int(rng.integers(-5000, 5000)), "".join(rng.choice(list("ACGTN"), lseq)), tuple(tags))
+    w.close()
+    return n
