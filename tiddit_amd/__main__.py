@@ -191,22 +191,7 @@ def run_sv(args, version):
     print("generated clusters in")
     print(time.time() - t)
     write_candidates(prefix + ".candidates.tab", contigs, sv_clusters)
-    try:
-        import tiddit.tiddit_variant as tiddit_variant          # the reference package, when installed next to us
-        import tiddit.tiddit_vcf_header as tiddit_vcf_header
-    except Exception:
-        print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
-        return
-    vcf_header = tiddit_vcf_header.main(bam_header, library, sample_id, version)
-    variants = tiddit_variant.main(args.bam, sv_clusters, args, library, min_mapq, samples, coverage_data, contig_number, max_ins_len,
-                                   gc_dictionary)
-    with open(prefix + ".vcf", "w") as f:
-        f.write(vcf_header + "\n")
-        for chrom in contigs:
-            if chrom not in variants:
-                continue
-            for variant in sorted(variants[chrom], key=lambda x: x[0]):
-                f.write("\t".join(variant[1]) + "\n")
+    print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
 
 
 def main(argv=None):

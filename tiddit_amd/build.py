@@ -17,7 +17,7 @@ def _newer(a, b):
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    deps = [os.path.join(CSRC, "tdt_common.h"), os.path.join(os.path.dirname(HERE), "include", "tiddit_hip.h")]
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(os.path.dirname(HERE), "include", "tiddit_hip.h")]
     relink = force
     procs = []
     for src in SOURCES:

@@ -25,11 +25,11 @@
 #ifndef COV_RPL
 #define COV_RPL 8                                  // reads per lane per step (4 or 8)
 #endif
-#define COV_TILE (COV_THREADS * COV_RPL)           // 1024 reads per workgroup step
+#define COV_TILE (COV_THREADS * COV_RPL)           // 2048 reads per workgroup step
 #ifndef COV_STEPS
 #define COV_STEPS 8
 #endif
-#define COV_READS_PER_BLOCK (COV_TILE * COV_STEPS) // 8192
+#define COV_READS_PER_BLOCK (COV_TILE * COV_STEPS) // 16384
 #ifndef COV_WIN
 #define COV_WIN 2048                               // LDS window, int64 bins (16 KiB)
 #endif

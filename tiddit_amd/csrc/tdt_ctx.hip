@@ -127,11 +127,3 @@ int tdt_pinned(tdt_ctx *c, int slot, size_t bytes, void **out) {
     return TDT_OK;
 }
 
-// debugging aid: the 16 words behind the async error word (spin statistics in DBF_DEBUG_SPINS builds)
-extern "C" int tdt_debug_words(tdt_ctx *c, unsigned *out16, int reset) {
-    if (!c || !out16) return TDT_E_ARG;
-    TDT_HIP(hipStreamSynchronize(c->stream));
-    TDT_HIP(hipMemcpy(out16, c->d_async_err, 64, hipMemcpyDeviceToHost));
-    if (reset) TDT_HIP(hipMemset(c->d_async_err, 0, 64));
-    return TDT_OK;
-}

@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned bz_rfl(unsigned v) { return __builtin_amdgcn
 
 #ifdef BZ_STATS
 __device__ unsigned long long bz_stats[64];   // [0] literals [1] matches [2] match bytes [3] deflate blocks, [8+k] matches with dist < 2^k, [32+k] len < 2^k
+// BZ_STATS measurement builds only (tools/inflate_stats.py); not part of the shipped ABI
 extern "C" int tdt_debug_bz_stats(unsigned long long *out, int reset) {
     if (reset) {
         unsigned long long z[64] = {0};

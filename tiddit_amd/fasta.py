@@ -66,6 +66,9 @@ class FastaFile:
             raw = np.frombuffer(f.read(nbytes), dtype=np.uint8)
         if linewidth == linebases:
             return raw[:length].copy()
+        if raw.size < nfull * linewidth:
+            # the last contig may end on a full line without a final line end (tail == 0 at EOF)
+            raw = np.concatenate([raw, np.zeros(nfull * linewidth - raw.size, dtype=np.uint8)])
         body = raw[:nfull * linewidth].reshape(nfull, linewidth)[:, :linebases].reshape(-1)
         return np.concatenate([body, raw[nfull * linewidth:nfull * linewidth + tail]])
 

@@ -146,6 +146,7 @@ def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
 def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50):
     """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
     split rows, clip FASTA entries).  Rows are exactly what ``worker`` returns (:228)."""
+    max_ins = int(max_ins)         # the reference's `int max_ins` argument truncates a float percentile (:147,:230; probed with Cython 3.2)
     reader = open_bam(bam_file_name)
     header = reader.header
     names, lengths = reader.references, reader.lengths
@@ -212,6 +213,7 @@ def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bi
     ``(chromosome, discordant rows, split rows, float64 coverage bins, path of the clipped-read FASTA)``.  The reference runs
     one indexed pysam pass per contig in a joblib worker; here ONE device pass over the file serves every contig (cached per
     file and parameter set), so calling ``worker`` contig by contig costs one scan in total."""
+    max_ins = int(max_ins)
     key = (os.path.abspath(bam_file_name), os.path.getmtime(bam_file_name), min_q, max_ins, bin_size, min_anchor_len, min_clip_len)
     if key not in _SCAN_CACHE:
         _SCAN_CACHE.clear()
