@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dbscan-n", type=int, default=5_000_000)
     ap.add_argument("--cpu-contigs", type=int, default=8, help="contigs of the stream the CPU baseline (oracle) is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cov-sv", action="store_true", help="skip the 50-bp / q>=5 pass over the same stream")
     ap.add_argument("--no-dbscan", action="store_true")
     ap.add_argument("--no-gc", action="store_true")
     ap.add_argument("--gc-len", type=int, default=3_000_000_000, help="reference bases for the GC histogram pass")
@@ -125,7 +126,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_cov = float(tt.item())
     ms_per_step = 1e3 * t_cov / args.steps
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)        # avg cov_accumulate launch (whole genome)
+    kern_all = sorted(a.elapsed_time(b) for a, b in ev_pairs)
+    kern_ms = sum(kern_all) / len(kern_all)                                      # avg cov_accumulate launch (whole genome)
     alg_bytes_launch = 12.0 * total_reads + 8.0 * total_bins                     # 12 B/read + 8 B/bin
     achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
     traffic = None
@@ -151,6 +153,7 @@ def main():
         "reads_per_sec": total_reads * world / (t_cov / args.steps),
         "roofline": {"bound": "hbm", "kernel": "cov_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kern_ms,
+                     "median_launch_ms": kern_all[len(kern_all) // 2], "min_launch_ms": kern_all[0],
                      "algorithmic_bytes_per_launch": alg_bytes_launch},
     }
 
@@ -190,6 +193,71 @@ def main():
         t_host = time.perf_counter() - t1
         result["host_push"] = {"reads_per_sec": len(hs) / t_host, "GB_per_s": 11.0 * len(hs) / t_host / 1e9,
                                "note": "one contig (%d reads) from pageable numpy arrays through the pinned staging ring" % len(hs)}
+    # ---------------------------------------------------------------- coverage, SV flavour: same stream, 50-bp bins, q >= 5
+    # (tiddit_signal.pyx:181-182,235: what `tiddit --sv` accumulates; a 150-bp read covers 3-5 bins)
+    if not args.no_cov_sv:
+        zs, qs_ = 50, 5
+        hist_sv = tiddit_coverage.CoverageHistogram([("s%02d" % (c + 1), L) for c in range(C)], zs, ctx=ctx)
+        nb_sv = [hist_sv.nbins(c)[0] for c in range(C)]
+        out_sv = torch.empty(hist_sv.total_bins(), dtype=torch.float64, device=dev)
+        sv_ev = []
+
+        def sv_step(timed):
+            hist_sv.reset()
+            if timed:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+            hist_sv.push_device_multi(items, qs_)
+            if timed:
+                b.record(stream)
+                sv_ev.append((a, b))
+            hist_sv.finish_all_device(out_sv.data_ptr())
+
+        for _ in range(args.warmup):
+            sv_step(False)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sv_step(True)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t_sv = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([t_sv], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_sv = float(tt.item())
+        sv_all = sorted(a.elapsed_time(b) for a, b in sv_ev)
+        sv_ms = sum(sv_all) / len(sv_all)
+        sv_bytes = 12.0 * total_reads + 8.0 * sum(nb_sv)
+        sv_ach = sv_bytes / (sv_ms * 1e-3) / 1e9
+        svres = {"metric": "cov bins/sec, SV flavour (50-bp bins, q>=5)", "value": sum(nb_sv) * world / (t_sv / args.steps), "unit": "bins/s",
+                 "reads_per_sec": total_reads * world / (t_sv / args.steps), "ms_per_step": 1e3 * t_sv / args.steps,
+                 "config": {"workload": "the same %d-read stream, %d-bp bins (%d bins), q>=%d filter: what `tiddit --sv` accumulates, per GPU"
+                                        % (total_reads, zs, sum(nb_sv), qs_)},
+                 "roofline": {"bound": "hbm", "kernel": "cov_accumulate (small-bin flavour)", "achieved": sv_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": sv_ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sv_ms, "median_launch_ms": sv_all[len(sv_all) // 2],
+                              "min_launch_ms": sv_all[0], "algorithmic_bytes_per_launch": sv_bytes}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            import oracle
+            t_cpu = 0.0
+            for c in range(C):
+                s, e, mq, fl = [t.cpu().numpy() for t in reads[c]]
+                fl = fl.view(np.uint16)
+                t1 = time.perf_counter()
+                want, _ = oracle.coverage_stream(s, e, mq, fl, L, zs, qs_)
+                t_cpu += time.perf_counter() - t1
+                o = hist_sv.offset(c)
+                if not np.array_equal(out_sv[o:o + nb_sv[c]].cpu().numpy(), want):
+                    raise SystemExit("PARITY FAILURE: GPU 50-bp bins of contig %d differ from the CPU oracle" % c)
+            svres["cpu_baseline"] = {"value": sum(nb_sv) / t_cpu, "unit": "bins/s", "cores": 1, "kind": "port", "reads_per_sec": total_reads / t_cpu,
+                                     "sample": "all %d contigs (%d reads), oracle/tiddit_oracle.c; bins verified bit-identical to the GPU's" % (C, total_reads)}
+            svres["parity_checked"] = True
+        result["coverage_sv"] = svres
+        del out_sv
+        hist_sv.close()
     del reads, outs, out_all
     hist.close()
     torch.cuda.empty_cache()

@@ -21,6 +21,75 @@ class Read:
     pass
 
 
+def parse_record(raw, o, sq):
+    """one alignment record at byte offset o of the inflated stream -> (Read, offset of the next record)"""
+    bs = struct.unpack_from("<i", raw, o)[0]
+    tid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", raw, o + 4)
+    p = o + 36
+    r = Read()
+    r.query_name = raw[p:p + l_name - 1].decode()
+    p += l_name
+    r.cigartuples = [(w & 0xf, w >> 4) for w in struct.unpack_from("<%dI" % n_cig, raw, p)]
+    p += 4 * n_cig
+    seq = []
+    for i in range(l_seq):
+        b = raw[p + i // 2]
+        seq.append(_SEQ[(b >> 4) if i % 2 == 0 else (b & 0xf)])
+    r.query_sequence = "".join(seq)
+    p += (l_seq + 1) // 2 + l_seq
+    r.tags = {}
+    end = o + 4 + bs
+    while p < end:
+        tag, typ = raw[p:p + 2].decode(), chr(raw[p + 2])
+        p += 3
+        if typ == "Z":
+            e = raw.index(b"\x00", p)
+            r.tags[tag] = raw[p:e].decode()
+            p = e + 1
+        elif typ == "i":
+            r.tags[tag] = struct.unpack_from("<i", raw, p)[0]
+            p += 4
+        elif typ == "A":
+            r.tags[tag] = chr(raw[p])
+            p += 1
+        elif typ in "cCsSIf":
+            fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "I": "I", "f": "f"}[typ]
+            r.tags[tag] = struct.unpack_from("<" + fmt, raw, p)[0]
+            p += struct.calcsize(fmt)
+        elif typ == "H":
+            e = raw.index(b"\x00", p)
+            r.tags[tag] = raw[p:e].decode()
+            p = e + 1
+        elif typ == "B":
+            fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[chr(raw[p])]
+            cnt = struct.unpack_from("<I", raw, p + 1)[0]
+            r.tags[tag] = list(struct.unpack_from("<%d%s" % (cnt, fmt), raw, p + 5))
+            p += 5 + cnt * struct.calcsize(fmt)
+        else:
+            raise ValueError("tag type " + typ)
+    r.flag, r.mapq, r.isize = flag, mapq, tlen
+    r.is_unmapped, r.is_duplicate = bool(flag & 0x4), bool(flag & 0x400)
+    r.is_supplementary, r.is_secondary = bool(flag & 0x800), bool(flag & 0x100)
+    r.mate_is_unmapped, r.is_paired, r.is_reverse = bool(flag & 0x8), bool(flag & 0x1), bool(flag & 0x10)
+    r.reference_id, r.next_reference_id = tid, mtid
+    r.mate_pos = mpos
+    r.reference_name = sq[tid]["SN"] if tid >= 0 else None
+    r.next_reference_name = sq[mtid]["SN"] if mtid >= 0 else None
+    r.reference_start = pos
+    rlen = sum(l for op, l in r.cigartuples if op in (0, 2, 3, 7, 8))
+    r.reference_end = pos + (rlen if (rlen and not r.is_unmapped) else 1)       # bam_endpos
+    qs = 0
+    for op, l in r.cigartuples:
+        if op == 5:
+            continue
+        if op == 4:
+            qs += l
+        else:
+            break
+    r.query_alignment_start = qs
+    return r, end
+
+
 def parse_bam(path):
     """-> (header dict, list of Read) — independent of tiddit_amd.bamio"""
     raw = bytearray()
@@ -52,72 +121,8 @@ def parse_bam(path):
             header.setdefault("RG", []).append(dict(f.split(":", 1) for f in line.split("\t")[1:] if ":" in f))
     reads = []
     while o < len(raw):
-        bs = struct.unpack_from("<i", raw, o)[0]
-        tid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", raw, o + 4)
-        p = o + 36
-        r = Read()
-        r.query_name = raw[p:p + l_name - 1].decode()
-        p += l_name
-        r.cigartuples = [(w & 0xf, w >> 4) for w in struct.unpack_from("<%dI" % n_cig, raw, p)]
-        p += 4 * n_cig
-        seq = []
-        for i in range(l_seq):
-            b = raw[p + i // 2]
-            seq.append(_SEQ[(b >> 4) if i % 2 == 0 else (b & 0xf)])
-        r.query_sequence = "".join(seq)
-        p += (l_seq + 1) // 2 + l_seq
-        r.tags = {}
-        end = o + 4 + bs
-        while p < end:
-            tag, typ = raw[p:p + 2].decode(), chr(raw[p + 2])
-            p += 3
-            if typ == "Z":
-                e = raw.index(b"\x00", p)
-                r.tags[tag] = raw[p:e].decode()
-                p = e + 1
-            elif typ == "i":
-                r.tags[tag] = struct.unpack_from("<i", raw, p)[0]
-                p += 4
-            elif typ == "A":
-                r.tags[tag] = chr(raw[p])
-                p += 1
-            elif typ in "cCsSIf":
-                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "I": "I", "f": "f"}[typ]
-                r.tags[tag] = struct.unpack_from("<" + fmt, raw, p)[0]
-                p += struct.calcsize(fmt)
-            elif typ == "H":
-                e = raw.index(b"\x00", p)
-                r.tags[tag] = raw[p:e].decode()
-                p = e + 1
-            elif typ == "B":
-                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[chr(raw[p])]
-                cnt = struct.unpack_from("<I", raw, p + 1)[0]
-                r.tags[tag] = list(struct.unpack_from("<%d%s" % (cnt, fmt), raw, p + 5))
-                p += 5 + cnt * struct.calcsize(fmt)
-            else:
-                raise ValueError("tag type " + typ)
-        r.flag, r.mapq, r.isize = flag, mapq, tlen
-        r.is_unmapped, r.is_duplicate = bool(flag & 0x4), bool(flag & 0x400)
-        r.is_supplementary, r.is_secondary = bool(flag & 0x800), bool(flag & 0x100)
-        r.mate_is_unmapped, r.is_paired, r.is_reverse = bool(flag & 0x8), bool(flag & 0x1), bool(flag & 0x10)
-        r.reference_id, r.next_reference_id = tid, mtid
-        r.mate_pos = mpos
-        r.reference_name = sq[tid]["SN"] if tid >= 0 else None
-        r.next_reference_name = sq[mtid]["SN"] if mtid >= 0 else None
-        r.reference_start = pos
-        rlen = sum(l for op, l in r.cigartuples if op in (0, 2, 3, 7, 8))
-        r.reference_end = pos + (rlen if (rlen and not r.is_unmapped) else 1)       # bam_endpos
-        qs = 0
-        for op, l in r.cigartuples:
-            if op == 5:
-                continue
-            if op == 4:
-                qs += l
-            else:
-                break
-        r.query_alignment_start = qs
+        r, o = parse_record(raw, o, sq)
         reads.append(r)
-        o = end
     return header, reads
 
 
@@ -208,6 +213,48 @@ def _SA_analysis(read, min_q, reference_name):      # tiddit_signal.pyx:31-145, 
     return [chrA, chrB, read.query_name, split_pos, read.is_reverse, SA_split_pos, "-" == SA_data[2], startA, endA, startB, endB]
 
 
+def _merge_and_format(header, chromosomes, res):
+    """tiddit_signal.main :262-326 — merge the workers' rows and format discordants.tab / splits.tab"""
+    data = {a: {b["SN"]: {} for b in header["SQ"]} for a in chromosomes}
+    splits = {a: {b["SN"]: {} for b in header["SQ"]} for a in chromosomes}
+    coverage_data = {}
+    for chromosome, d, sp, cov in res:
+        coverage_data[chromosome] = cov
+        for signal in d:
+            if signal[0] not in data:
+                continue
+            data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
+        for signal in sp:
+            if signal[0] not in splits:
+                continue
+            splits[signal[0]][signal[1]].setdefault(signal[2], [])
+            splits[signal[0]][signal[1]][signal[2]] += signal[3:]
+    disc_txt = []
+    for chrA in data:
+        for chrB in data[chrA]:
+            for fragment in data[chrA][chrB]:
+                fr = data[chrA][chrB][fragment]
+                if len(fr) < 2:
+                    continue
+                if chrA == chrB:
+                    if fr[1][-1] < fr[0][-1]:
+                        out = fr[1][0:-1] + fr[0][0:-1]
+                    else:
+                        out = fr[0][0:-1] + fr[1][0:-1]
+                else:
+                    if fr[0][-1] == chrA:
+                        out = fr[0][0:-1] + fr[1][0:-1]
+                    else:
+                        out = fr[1][0:-1] + fr[0][0:-1]
+                disc_txt.append("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, out))))
+    split_txt = []
+    for chrA in splits:
+        for chrB in splits[chrA]:
+            for fragment in splits[chrA][chrB]:
+                split_txt.append("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, splits[chrA][chrB][fragment]))))
+    return coverage_data, "".join(disc_txt), "".join(split_txt)
+
+
 def signal_main(header, reads, min_q, max_ins, sample_id, min_contig, min_anchor_len, min_clip_len):
     """-> (coverage dict, discordants.tab text, splits.tab text, clips.fa text, per-contig clip texts)"""
     bin_size = 50
@@ -254,38 +301,94 @@ def signal_main(header, reads, min_q, max_ins, sample_id, min_contig, min_anchor
                 d.append([chrA, chrB, read.query_name, read.reference_start + 1, read.reference_end + 1, read.is_reverse, read_chromosome])
         clip_texts[chromosome] = "".join("".join(c) for c in clips)
         res.append((chromosome, d, sp, cov))
-    for chromosome, d, sp, cov in res:
-        coverage_data[chromosome] = cov
-        for signal in d:
-            if signal[0] not in data:
-                continue
-            data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
-        for signal in sp:
-            if signal[0] not in splits:
-                continue
-            splits[signal[0]][signal[1]].setdefault(signal[2], [])
-            splits[signal[0]][signal[1]][signal[2]] += signal[3:]
-    disc_txt = []
-    for chrA in data:
-        for chrB in data[chrA]:
-            for fragment in data[chrA][chrB]:
-                fr = data[chrA][chrB][fragment]
-                if len(fr) < 2:
-                    continue
-                if chrA == chrB:
-                    if fr[1][-1] < fr[0][-1]:
-                        out = fr[1][0:-1] + fr[0][0:-1]
-                    else:
-                        out = fr[0][0:-1] + fr[1][0:-1]
+    coverage_data, disc, split = _merge_and_format(header, chromosomes, res)
+    return coverage_data, disc, split, "".join(clip_texts[c] for c in chromosomes), clip_texts
+
+
+def inflate_bam(path):
+    """-> (header dict, sq list, uint8 array of the inflated record bytes) — zlib block by block, independent of tiddit_amd.bamio"""
+    import numpy as np
+    parts = []
+    with open(path, "rb") as f:
+        data = f.read()
+    o = 0
+    while o < len(data):
+        xlen = struct.unpack_from("<H", data, o + 10)[0]
+        bsize = struct.unpack_from("<H", data, o + 16)[0]
+        cdata = data[o + 12 + xlen:o + bsize + 1 - 8]
+        if cdata:
+            parts.append(zlib.decompress(cdata, -15))
+        o += bsize + 1
+    del data
+    raw = b"".join(parts)
+    del parts
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text].split(b"\x00")[0].decode()
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    sq = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", raw, o)[0]
+        sq.append({"SN": raw[o + 4:o + 4 + ln - 1].decode(), "LN": struct.unpack_from("<i", raw, o + 4 + ln)[0]})
+        o += 8 + ln
+    header = {"SQ": sq}
+    for line in text.split("\n"):
+        if line.startswith("@RG"):
+            header.setdefault("RG", []).append(dict(f.split(":", 1) for f in line.split("\t")[1:] if ":" in f))
+    return header, sq, np.frombuffer(raw, dtype=np.uint8)[o:]
+
+
+def signal_main_file(path, min_q, max_ins, sample_id, min_contig, min_anchor_len, min_clip_len, want_clips=True):
+    """tiddit_signal.main (:230-334) on a BAM file at scale: the per-read chain of worker (:169-221) runs in C over the decoded
+    fields (oracle.bam_walk + oracle.signal_worker), and only the reads it marks are parsed record by record and pushed through
+    the literal Python of the rest (clip entries, _SA_analysis, discordant rows, the merge and the writers — shared with
+    signal_main).  -> (coverage dict, discordants.tab text, splits.tab text, clips.fa text, per-contig clip texts, n_reads)"""
+    import numpy as np
+    max_ins = int(max_ins)                 # `int max_ins` (:230)
+    header, sq, raw = inflate_bam(path)
+    f = oracle.bam_walk(raw)
+    rawb = raw.tobytes() if len(raw) < (1 << 31) else raw
+    tid = f["tid"]
+    chromosomes = [c["SN"] for c in sq if c["LN"] >= min_contig]
+    names = [c["SN"] for c in sq]
+    res, clip_texts = [], {}
+    # samfile.fetch(chromosome): the contig's records, in file order (a coordinate-sorted file keeps them together; an
+    # unsorted one is gathered by a stable selection)
+    order = np.argsort(tid, kind="stable")
+    bounds = np.searchsorted(tid[order], np.arange(len(sq) + 1))
+    contiguous = bool(np.all(np.diff(tid[tid >= 0]) >= 0)) if len(tid) else True
+    for chromosome in chromosomes:
+        t = names.index(chromosome)
+        lo, hi = int(bounds[t]), int(bounds[t + 1])
+        if contiguous:
+            first = int(order[lo]) if hi > lo else 0
+            g = f
+            sel_lo, sel_hi = first, first + (hi - lo)
+        else:
+            idx = order[lo:hi]
+            g = {k: v[idx] for k, v in f.items()}
+            sel_lo, sel_hi = 0, hi - lo
+        act, cov = oracle.signal_worker(g, sel_lo, sel_hi, sq[t]["LN"], min_q, max_ins, min_anchor_len, min_clip_len, 50)
+        clips, d, sp = [], [], []
+        for k in np.flatnonzero(act & 0xe):
+            a = int(act[k])
+            read, _ = parse_record(rawb, int(g["rec_off"][sel_lo + k]), sq)
+            read_chromosome, mate_chromosome = read.reference_name, read.next_reference_name
+            if a & 2 and want_clips:
+                clips.append([">{}|{}|{}\n".format(read.query_name, read_chromosome, read.reference_start + 1), read.query_sequence + "\n"])
+            if a & 4:
+                split = _SA_analysis(read, min_q, read_chromosome)
+                if split:
+                    sp.append(split)
+            if a & 8:
+                if mate_chromosome < read_chromosome:
+                    chrA, chrB = mate_chromosome, read_chromosome
                 else:
-                    if fr[0][-1] == chrA:
-                        out = fr[0][0:-1] + fr[1][0:-1]
-                    else:
-                        out = fr[1][0:-1] + fr[0][0:-1]
-                disc_txt.append("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, out))))
-    split_txt = []
-    for chrA in splits:
-        for chrB in splits[chrA]:
-            for fragment in splits[chrA][chrB]:
-                split_txt.append("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, splits[chrA][chrB][fragment]))))
-    return coverage_data, "".join(disc_txt), "".join(split_txt), "".join(clip_texts[c] for c in chromosomes), clip_texts
+                    chrA, chrB = read_chromosome, mate_chromosome
+                d.append([chrA, chrB, read.query_name, read.reference_start + 1, read.reference_end + 1, read.is_reverse, read_chromosome])
+        clip_texts[chromosome] = "".join("".join(c) for c in clips)
+        res.append((chromosome, d, sp, cov))
+    cov, disc, split = _merge_and_format(header, chromosomes, res)
+    return cov, disc, split, "".join(clip_texts[c] for c in chromosomes), clip_texts, len(tid)

@@ -294,3 +294,110 @@ void orc_get_region(const int32_t *start, const int32_t *end, const uint8_t *map
     }
     out[0] = bases; out[1] = n_reads; out[2] = low_q; out[3] = n_discs; out[4] = n_splits; out[5] = crossing_f; out[6] = crossing_r;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * BAM record walk (SAM/BAM spec v1 §4.2; what pysam's AlignedSegment attributes expose):
+ *   reference_start = pos, reference_end = htslib bam_endpos (pos + sum of M/D/N/=/X lengths, pos + 1 when that is
+ *   0 or the read is unmapped), mapq, flag, next_reference_id, next_reference_start, isize, l_seq,
+ *   cigartuples[0] / [-1] (raw len<<4|op words, 0xffffffff without CIGAR), has_tag("SA") (aux walk).
+ * PARITY UNPINNED at this boundary (pysam/htslib are not installable here): written from the
+ * specification, independent of the product's decoders (csrc/tdt_bam.hip, csrc/tdt_ingest.hip).
+ * `raw` = inflated BAM bytes from the first record on.  Returns the number of whole records decoded (<= max).
+ * ---------------------------------------------------------------------------------------- */
+static int32_t orc_i32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
+static uint32_t orc_u32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint16_t orc_u16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+int64_t orc_bam_walk(const uint8_t *raw, int64_t len, int64_t max, int32_t *tid, int32_t *pos, int32_t *end, uint8_t *mapq,
+                     uint16_t *flag, int32_t *mate_tid, int32_t *mate_pos, int32_t *tlen, int32_t *l_seq, uint32_t *cig_first,
+                     uint32_t *cig_last, int64_t *rec_off, uint8_t *has_sa) {
+    int64_t o = 0, n = 0;
+    while (o + 4 <= len && n < max) {
+        int64_t bs = orc_i32(raw + o);
+        if (bs < 32 || o + 4 + bs > len) break;
+        const uint8_t *r = raw + o + 4;
+        int l_name = r[8], n_cig = orc_u16(r + 12);
+        int32_t ls = orc_i32(r + 16);
+        tid[n] = orc_i32(r); pos[n] = orc_i32(r + 4); mapq[n] = r[9]; flag[n] = orc_u16(r + 14); l_seq[n] = ls;
+        mate_tid[n] = orc_i32(r + 20); mate_pos[n] = orc_i32(r + 24); tlen[n] = orc_i32(r + 28);
+        const uint8_t *c = r + 32 + l_name;
+        int64_t rlen = 0;
+        for (int k = 0; k < n_cig; k++) {
+            uint32_t w = orc_u32(c + 4 * k);
+            int op = w & 0xf;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += w >> 4;
+        }
+        cig_first[n] = n_cig ? orc_u32(c) : 0xffffffffu;
+        cig_last[n] = n_cig ? orc_u32(c + 4 * (n_cig - 1)) : 0xffffffffu;
+        end[n] = pos[n] + (int32_t)((rlen && !(flag[n] & 0x4)) ? rlen : 1);
+        rec_off[n] = o;
+        /* aux fields: tag[2] type[1] value */
+        const uint8_t *a = c + 4 * (int64_t)n_cig + (ls + 1) / 2 + ls, *stop = r + bs;
+        uint8_t sa = 0;
+        while (a + 3 <= stop) {
+            if (a[0] == 'S' && a[1] == 'A') sa = 1;
+            char t = (char)a[2];
+            a += 3;
+            if (t == 'A' || t == 'c' || t == 'C') a += 1;
+            else if (t == 's' || t == 'S') a += 2;
+            else if (t == 'i' || t == 'I' || t == 'f') a += 4;
+            else if (t == 'Z' || t == 'H') { while (a < stop && *a) a++; a++; }
+            else if (t == 'B') {
+                char st = (char)a[0];
+                int64_t cnt = orc_u32(a + 1);
+                int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                a += 5 + cnt * sz;
+            } else break;
+        }
+        has_sa[n] = sa;
+        o += 4 + bs;
+        n++;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The per-read chain of tiddit_signal.worker — tiddit_signal.pyx:169-221 — for the reads of ONE contig in file order
+ * (`for read in samfile.fetch(chromosome, until_eof=True)`, :169), statement by statement; the string work (names,
+ * sequences, SA_analysis, row building) stays with the caller, which gets one action byte per read:
+ *   bit 0  update_coverage was called (:181-182; done here, on `cov`)     bit 1  clips.append (:190-197)
+ *   bit 2  SA_analysis is called (:199-202)                               bit 3  data.append, a discordant row (:211-221)
+ * mate_tid/tid stand for next_reference_name/reference_name (names are unique per id).  max_ins is the `int max_ins`
+ * argument (:147).  Returns the number of update_coverage calls, or -(i+1) when read i indexes a bin out of range.
+ * ---------------------------------------------------------------------------------------- */
+int64_t orc_signal_worker(int64_t n, const int32_t *tid, const int32_t *pos, const int32_t *end, const uint8_t *mapq,
+                          const uint16_t *flag, const int32_t *mate_tid, const int32_t *tlen, const uint32_t *cig_first,
+                          const uint32_t *cig_last, const uint8_t *has_sa, int min_q, int max_ins, int min_anchor_len,
+                          int min_clip_len, int bin_size, double *cov, int64_t nbins, int end_bin_size, uint8_t *action) {
+    int64_t updates = 0;
+    for (int64_t i = 0; i < n; i++) {
+        uint8_t act = 0;
+        action[i] = 0;
+        if ((flag[i] & 0x4) || (flag[i] & 0x400)) continue;                       /* :171 is_unmapped or is_duplicate */
+        int read_mapq = mapq[i];
+        if (read_mapq >= min_q) {                                                 /* :181-182 */
+            if (orc_update_coverage(pos[i], end[i], bin_size, cov, nbins, end_bin_size)) return -(i + 1);
+            updates++;
+            act |= 1;
+        }
+        action[i] = act;
+        if ((flag[i] & 0x800) || (flag[i] & 0x100)) continue;                     /* :184 supplementary or secondary */
+        if (read_mapq < min_q) continue;                                          /* :188 */
+        int64_t isz = tlen[i] < 0 ? -(int64_t)tlen[i] : (int64_t)tlen[i];
+        int same = mate_tid[i] == tid[i];
+        if (isz < max_ins && same) {                                              /* :191 */
+            uint32_t f = cig_first[i], l = cig_last[i];
+            int f_op = f & 0xf, l_op = l & 0xf;
+            int64_t f_len = f >> 4, l_len = l >> 4;
+            if ((f_op == 4 && f_len > min_clip_len) && (l_op == 0 && l_len > min_anchor_len)) act |= 2;          /* :193 */
+            else if (l_op == 4 && l_len > min_clip_len && (f_op == 0 && f_len > min_anchor_len)) act |= 2;       /* :196 */
+        }
+        if (has_sa[i]) act |= 4;                                                  /* :199 */
+        action[i] = act;
+        if (flag[i] & 0x8) continue;                                              /* :204 mate_is_unmapped */
+        if (!(flag[i] & 0x1)) continue;                                           /* :207 not is_paired */
+        if (isz > max_ins || !same) act |= 8;                                     /* :211 */
+        action[i] = act;
+    }
+    return updates;
+}

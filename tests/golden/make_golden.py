@@ -41,10 +41,15 @@ def build_reference():
             "class FastaFile:\n"
             "    def __init__(self, path): self.path = path\n"
             "    def get_reference_length(self, c): return len(SEQS[c])\n"
-            "    def fetch(self, c, s, e): return SEQS[c][s:e]\n")
+            "    def fetch(self, c, s, e): return SEQS[c][s:e]\n"
+            "READS = lambda: iter(())\n"
+            "class AlignmentFile:\n"
+            "    def __init__(self, *a, **k): pass\n"
+            "    def fetch(self, *a, **k): return READS()\n"
+            "    def close(self): pass\n")
     inc = sysconfig.get_paths()["include"]
     ext = sysconfig.get_config_var("EXT_SUFFIX")
-    for mod in ("tiddit_coverage", "tiddit_gc", "tiddit_cluster"):
+    for mod in ("tiddit_coverage", "tiddit_gc", "tiddit_cluster", "tiddit_coverage_analysis"):
         so = os.path.join(pkg, mod + ext)
         if os.path.exists(so):
             continue
@@ -54,7 +59,7 @@ def build_reference():
                                c, "-o", so])
     sys.path.insert(0, BUILD)
     mods = {m: importlib.import_module("tiddit." + m)
-            for m in ("tiddit_coverage", "tiddit_gc", "tiddit_cluster", "DBSCAN")}
+            for m in ("tiddit_coverage", "tiddit_gc", "tiddit_cluster", "DBSCAN", "tiddit_coverage_analysis", "tiddit_stats")}
     mods["pysam"] = importlib.import_module("pysam")
     return mods
 
@@ -343,6 +348,85 @@ def golden_cluster(M, out):
     json.dump({"find_discordant_pos": fdp, "cases": cases}, open(os.path.join(out, "cluster.json"), "w"))
 
 
+# --------------------------------------------------------------------------------- `tiddit --sv --skip_assembly`, BASELINE configs[3]
+E2E = {"total_mb": 24, "seed": 7, "depth": 30, "read_len": 150, "insert": 400, "insert_sd": 40, "sv_per_mb": 3.0, "fasta_seed": 100,
+       "min_q": 5, "n_reads_stats": 25000000, "min_contig": 10000, "min_anchor_len": 60, "min_clip_len": 25, "m": 3, "min_reads": 3, "ploidy": 2}
+
+
+class _StatRead:
+    __slots__ = ("query_length", "mate_is_unmapped", "is_reverse", "mate_is_reverse", "next_reference_name", "reference_name",
+                 "template_length", "next_reference_start", "reference_start", "is_supplementary", "is_secondary", "is_duplicate", "mapq")
+
+
+def stat_reads(fields, names):
+    """the attributes tiddit_stats.statistics reads (tiddit_stats.py:17-47), record by record, for `samfile.fetch()` —
+    placed records only, in file order"""
+    def gen():
+        r = _StatRead()
+        cols = [fields[k].tolist() for k in ("tid", "pos", "mapq", "flag", "mate_tid", "mate_pos", "tlen", "l_seq")]
+        for tid, pos, mapq, flag, mtid, mpos, tlen, lseq in zip(*cols):
+            if tid < 0:
+                continue
+            r.query_length = lseq
+            r.mate_is_unmapped, r.is_reverse, r.mate_is_reverse = bool(flag & 0x8), bool(flag & 0x10), bool(flag & 0x20)
+            r.reference_name, r.next_reference_name = names[tid], (names[mtid] if mtid >= 0 else None)
+            r.template_length, r.next_reference_start, r.reference_start = tlen, mpos, pos
+            r.is_supplementary, r.is_secondary, r.is_duplicate, r.mapq = bool(flag & 0x800), bool(flag & 0x100), bool(flag & 0x400), mapq
+            yield r
+    return gen
+
+
+def golden_sv_e2e(M, out, params=None, name="sv_e2e.json"):
+    """The whole --sv --skip_assembly path on a WGS-shaped synthetic BAM (tiddit_amd.synth_bam.write_wgs_sv_bam, everything derived
+    from a seed so the GPU box regenerates the identical file): library statistics by the reference's tiddit_stats.py (stub
+    AlignmentFile serving the decoded records), signal extraction by the restatement (oracle/signal_oracle.py — tiddit_signal.pyx
+    cannot be compiled here), GC by the compiled tiddit_gc, ploidies by the compiled tiddit_coverage_analysis, candidates by the
+    compiled tiddit_cluster on the restatement's .tab files."""
+    import oracle
+    from oracle import signal_oracle
+    from tiddit_amd import synth_bam
+    P = dict(E2E)
+    P.update(params or {})
+    contigs = synth_bam.wgs_contigs(P["total_mb"])
+    with tempfile.TemporaryDirectory() as td:
+        fa, bam, prefix = os.path.join(td, "ref.fa"), os.path.join(td, "WGS.bam"), os.path.join(td, "out")
+        seqs = synth_bam.write_fasta(fa, contigs, seed=P["fasta_seed"])
+        info = synth_bam.write_wgs_sv_bam(bam, contigs, depth=P["depth"], read_len=P["read_len"], insert=P["insert"], insert_sd=P["insert_sd"],
+                                          seed=P["seed"], sv_per_mb=P["sv_per_mb"], threads=8, ref_seqs=seqs)
+        header, sq, raw = signal_oracle.inflate_bam(bam)
+        fields = oracle.bam_walk(raw)
+        names = [c["SN"] for c in sq]
+        M["pysam"].READS = stat_reads(fields, names)
+        library = M["tiddit_stats"].statistics(bam, fa, P["min_q"], 100000, P["n_reads_stats"])
+        lib0 = {k: (float(v) if not isinstance(v, bool) else v) for k, v in library.items()}
+        max_ins = library["percentile_insert_size"]
+        cov, disc, split, clips, clip_each, n_rec = signal_oracle.signal_main_file(bam, P["min_q"], max_ins, "WGS", P["min_contig"],
+                                                                                   P["min_anchor_len"], P["min_clip_len"])
+        os.makedirs(prefix + "_tiddit")
+        open(prefix + "_tiddit/discordants_WGS.tab", "w").write(disc)
+        open(prefix + "_tiddit/splits_WGS.tab", "w").write(split)
+        # GC (compiled tiddit_gc.binned_gc through the FastaFile stand-in) and ploidies (compiled determine_ploidy)
+        M["pysam"].SEQS = {n: seqs[n].tobytes().decode() for n, _ in contigs}
+        gc = {n: M["tiddit_gc"].binned_gc(fa, n, 50, 0.5)[1] for n, _ in contigs}
+        lib = M["tiddit_coverage_analysis"].determine_ploidy(cov, names, dict(library), P["ploidy"], prefix, None, fa, 50, header, gc)
+        ploidies = open(prefix + ".ploidies.tab").read()
+        eps = int(library["avg_insert_size"] / 2.0) or 50
+        contig_length = {c["SN"]: c["LN"] for c in sq}
+        cand = M["tiddit_cluster"].main(prefix, names, contig_length, ["WGS"], library["mp"], eps, P["m"], max_ins, P["min_contig"], True, P["min_reads"])
+    from oracle import cluster_oracle
+    h = lambda t: hashlib.sha256(t.encode()).hexdigest()
+    res = {"params": P, "n_records": int(n_rec), "n_events": len(info["events"]), "events": info["events"], "library": lib0,
+           "epsilon": eps,
+           "discordants_sha256": h(disc), "discordants_rows": disc.count("\n"), "splits_sha256": h(split), "splits_rows": split.count("\n"),
+           "clips_sha256": h(clips), "clips_entries": clips.count(">"),
+           "coverage_sha256": {n: sha(cov[n].astype("<f8")) for n in cov}, "gc_sha256": {n: sha(gc[n]) for n in gc},
+           "ploidies_tab": ploidies, "library_after_ploidy": {k: float(v) for k, v in lib.items() if k.startswith(("avg_coverage", "contig_ploidy"))},
+           "candidates_sha256": h(cluster_oracle.canonical(cand)), "candidates": cluster_oracle.summary(cand)}
+    json.dump(res, open(os.path.join(out, name), "w"), indent=0)
+    print("sv_e2e:", n_rec, "records,", res["discordants_rows"], "discordant rows,", res["splits_rows"], "split rows,", len(res["candidates"]), "candidates")
+    return res
+
+
 def main():
     slow = "--slow" in sys.argv
     M = build_reference()
@@ -350,6 +434,8 @@ def main():
     golden_gc(M, HERE)
     golden_dbscan(M, HERE, slow)
     golden_cluster(M, HERE)
+    golden_sv_e2e(M, HERE)
+    golden_sv_e2e(M, HERE, params={"total_mb": 3, "seed": 11, "sv_per_mb": 8.0, "n_reads_stats": 300000}, name="sv_e2e_small.json")
 
 
 if __name__ == "__main__":

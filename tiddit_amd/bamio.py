@@ -653,6 +653,41 @@ def parse_cigar(cigar):
     return out
 
 
+def encode_record(qname, flag, tid, pos, mapq, cigar, mate_tid, mate_pos, tlen, seq="", tags=(), qual=None):
+    """One BAM alignment record (block_size included) as bytes.  pos 0-based; cigar = string or list of (op, len);
+    tags = iterable of (tag, type, value); qual = bytes of l_seq phred values or None (0xff: absent)"""
+    cig = parse_cigar(cigar) if isinstance(cigar, str) else list(cigar)
+    rlen = sum(l for op, l in cig if op in (0, 2, 3, 7, 8)) or 1
+    name = qname.encode() + b"\x00"
+    lseq = len(seq)
+    codes = [_SEQ_CODES.index(c) if c in _SEQ_CODES else 15 for c in seq.upper()]
+    if lseq & 1:
+        codes.append(0)
+    packed = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
+    aux = b""
+    for tag, typ, val in tags:
+        if typ == "Z":
+            aux += tag.encode() + b"Z" + val.encode() + b"\x00"
+        elif typ == "i":
+            aux += tag.encode() + b"i" + struct.pack("<i", val)
+        elif typ == "A":
+            aux += tag.encode() + b"A" + val.encode()
+        elif typ in "cCsSIf":
+            aux += tag.encode() + typ.encode() + struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "I": "I", "f": "f"}[typ], val)
+        elif typ == "H":
+            aux += tag.encode() + b"H" + val.encode() + b"\x00"
+        elif typ.startswith("B"):                                  # ("XB", "BS", [1, 2, 3]): array of subtype S
+            sub = typ[1]
+            fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
+            aux += tag.encode() + b"B" + sub.encode() + struct.pack("<I", len(val)) + struct.pack("<%d%s" % (len(val), fmt), *val)
+        else:
+            raise ValueError("unsupported tag type " + typ)
+    body = (struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, _reg2bin(pos, pos + rlen), len(cig), flag, lseq, mate_tid,
+                        mate_pos, tlen) + name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig) + packed +
+            (b"\xff" * lseq if qual is None else bytes(qual)) + aux)
+    return struct.pack("<i", len(body)) + body
+
+
 class BamWriter:
     """Write a BAM from Python values (test / synthetic-config tooling)."""
 
@@ -674,35 +709,7 @@ class BamWriter:
 
     def write(self, qname, flag, tid, pos, mapq, cigar, mate_tid, mate_pos, tlen, seq="", tags=()):
         """pos 0-based; cigar = string or list of (op, len); tags = iterable of (tag, type, value) with type Z/i/A"""
-        cig = parse_cigar(cigar) if isinstance(cigar, str) else list(cigar)
-        rlen = sum(l for op, l in cig if op in (0, 2, 3, 7, 8)) or 1
-        name = qname.encode() + b"\x00"
-        lseq = len(seq)
-        codes = [_SEQ_CODES.index(c) if c in _SEQ_CODES else 15 for c in seq.upper()]
-        if lseq & 1:
-            codes.append(0)
-        packed = bytes((codes[i] << 4) | codes[i + 1] for i in range(0, len(codes), 2))
-        aux = b""
-        for tag, typ, val in tags:
-            if typ == "Z":
-                aux += tag.encode() + b"Z" + val.encode() + b"\x00"
-            elif typ == "i":
-                aux += tag.encode() + b"i" + struct.pack("<i", val)
-            elif typ == "A":
-                aux += tag.encode() + b"A" + val.encode()
-            elif typ in "cCsSIf":
-                aux += tag.encode() + typ.encode() + struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "I": "I", "f": "f"}[typ], val)
-            elif typ == "H":
-                aux += tag.encode() + b"H" + val.encode() + b"\x00"
-            elif typ.startswith("B"):                                  # ("XB", "BS", [1, 2, 3]): array of subtype S
-                sub = typ[1]
-                fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[sub]
-                aux += tag.encode() + b"B" + sub.encode() + struct.pack("<I", len(val)) + struct.pack("<%d%s" % (len(val), fmt), *val)
-            else:
-                raise ValueError("unsupported tag type " + typ)
-        body = (struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, _reg2bin(pos, pos + rlen), len(cig), flag, lseq, mate_tid,
-                            mate_pos, tlen) + name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig) + packed +
-                b"\xff" * lseq + aux)
+        body = encode_record(qname, flag, tid, pos, mapq, cigar, mate_tid, mate_pos, tlen, seq, tags)[4:]
         if self.align_records and self._buf and len(self._buf) + 4 + len(body) > 0xff00:
             self._f.write(_bgzf_block(bytes(self._buf), self.level))
             self._buf = bytearray()

@@ -25,11 +25,10 @@
 #ifndef COV_RPL
 #define COV_RPL 8                                  // reads per lane per step (4 or 8)
 #endif
-#define COV_TILE (COV_THREADS * COV_RPL)           // 2048 reads per workgroup step
-#ifndef COV_STEPS
-#define COV_STEPS 8
+#ifndef COV_RPL1
+#define COV_RPL1 4                                 // the same in the small-bin flavour (cov_accumulate MODE 1)
 #endif
-#define COV_READS_PER_BLOCK (COV_TILE * COV_STEPS) // 16384
+#define COV_READS_PER_BLOCK 16384                  // consecutive reads per workgroup
 #ifndef COV_WIN
 #define COV_WIN 2048                               // LDS window, int64 bins (16 KiB)
 #endif
@@ -61,6 +60,9 @@ struct CovParams {
     unsigned magic;           // floor(x / bin_size) = mulhi(x, magic) >> shift for 0 <= x < 2^31
     int shift;                // -1: bin_size == 1
     int min_q;
+    int margin;               // bins: re-base the LDS window when a tile's last read starts this close to its end
+    unsigned xmax, m15;       // MODE 1: floor(x / bin_size) == (x * m15) >> k15 for 0 <= x < xmax (<= 2^15), 24-bit multiply
+    int k15;
     const unsigned long long *lut_main;  // [bin_size+1] fixed-point float32(b)/float32(bin_size)
     unsigned long long one;              // 1.0 in fixed point
     int *status;                         // [0] |= 1 on range error
@@ -119,39 +121,41 @@ __device__ __noinline__ void cov_global_add(unsigned long long *acc, int bin, un
     atomicAdd(&acc[bin], v);
 }
 
+template <int RPL>
 struct CovTile {
-    int s[COV_RPL], e[COV_RPL];
-    unsigned mq[COV_RPL / 4];   // 4 mapq bytes per word
-    unsigned fl[COV_RPL / 2];   // 2 flags per word
+    int s[RPL], e[RPL];
+    unsigned mq[RPL / 4];   // 4 mapq bytes per word
+    unsigned fl[RPL / 2];   // 2 flags per word
 };
 
-__device__ __forceinline__ CovTile cov_load(const CovItem &P, unsigned long long idx, unsigned long long r1) {
-    CovTile t;
-    if (P.aligned && idx + COV_RPL <= r1) {
+template <int RPL>
+__device__ __forceinline__ CovTile<RPL> cov_load(const CovItem &P, unsigned long long idx, unsigned long long r1) {
+    CovTile<RPL> t;
+    if (P.aligned && idx + RPL <= r1) {
 #pragma unroll
-        for (int k = 0; k < COV_RPL / 4; k++) {
+        for (int k = 0; k < RPL / 4; k++) {
             const int4 s4 = *reinterpret_cast<const int4 *>(P.start + idx + 4 * k);
             const int4 e4 = *reinterpret_cast<const int4 *>(P.end + idx + 4 * k);
             t.s[4 * k] = s4.x; t.s[4 * k + 1] = s4.y; t.s[4 * k + 2] = s4.z; t.s[4 * k + 3] = s4.w;
             t.e[4 * k] = e4.x; t.e[4 * k + 1] = e4.y; t.e[4 * k + 2] = e4.z; t.e[4 * k + 3] = e4.w;
         }
-#if COV_RPL == 8
-        const uint2 m2 = *reinterpret_cast<const uint2 *>(P.mapq + idx);
-        const uint4 f4 = *reinterpret_cast<const uint4 *>(P.flag + idx);
-        t.mq[0] = m2.x; t.mq[1] = m2.y;
-        t.fl[0] = f4.x; t.fl[1] = f4.y; t.fl[2] = f4.z; t.fl[3] = f4.w;
-#else
-        t.mq[0] = *reinterpret_cast<const unsigned *>(P.mapq + idx);
-        const uint2 f2 = *reinterpret_cast<const uint2 *>(P.flag + idx);
-        t.fl[0] = f2.x; t.fl[1] = f2.y;
-#endif
+        if (RPL == 8) {
+            const uint2 m2 = *reinterpret_cast<const uint2 *>(P.mapq + idx);
+            const uint4 f4 = *reinterpret_cast<const uint4 *>(P.flag + idx);
+            t.mq[0] = m2.x; t.mq[RPL / 4 - 1] = m2.y;
+            t.fl[0] = f4.x; t.fl[1] = f4.y; t.fl[RPL / 2 - 2] = f4.z; t.fl[RPL / 2 - 1] = f4.w;
+        } else {
+            t.mq[0] = *reinterpret_cast<const unsigned *>(P.mapq + idx);
+            const uint2 f2 = *reinterpret_cast<const uint2 *>(P.flag + idx);
+            t.fl[0] = f2.x; t.fl[1] = f2.y;
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < COV_RPL / 4; k++) t.mq[k] = 0;
+        for (int k = 0; k < RPL / 4; k++) t.mq[k] = 0;
 #pragma unroll
-        for (int k = 0; k < COV_RPL / 2; k++) t.fl[k] = 0;
+        for (int k = 0; k < RPL / 2; k++) t.fl[k] = 0;
 #pragma unroll
-        for (int j = 0; j < COV_RPL; j++) {
+        for (int j = 0; j < RPL; j++) {
             const bool ok = idx + j < r1;
             t.s[j] = ok ? P.start[idx + j] : 0;
             t.e[j] = ok ? P.end[idx + j] : 1;
@@ -162,15 +166,43 @@ __device__ __forceinline__ CovTile cov_load(const CovItem &P, unsigned long long
     return t;
 }
 
-template <bool LDS_LUT>
-__global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
+// MODE 0 (many reads per bin, e.g. --cov at 500 bp): contributions to bins K, K+1, K+2 are folded into three
+//   registers per lane and merged across the wave by a prefix scan over runs of equal K.
+// MODE 1 (few reads per bin, e.g. --sv at 50 bp, where a 150-bp read covers 3-5 bins and neighbouring lanes hardly
+//   ever share K): the "+1.0 for every bin strictly inside the read" (tiddit_coverage.pyx:71-72) becomes a
+//   difference pair — +1 at first_bin+1, -1 at last_bin — kept in the top 16 bits of the same 64-bit LDS window word
+//   that holds the bin's partial sums (low 48 bits), so a read of ANY length costs one ds_add_u64 for its last bin
+//   (partial - 2^48, read ready-made from an LDS table) plus register adds for its first bin (partial) and
+//   first_bin+1 (+2^48); the window is resolved by one prefix sum over the difference counts when it is spilled.
+//   Everything a read contributes is self-masked through its table index (entry 0 of every table is 0), so no
+//   predicate outlives the read that produced it.  Only reads whose bins all lie inside the window and before the
+//   contig's last bin take this path (the differences must cancel inside the window); the rest are replayed literally.
+#define COV_DBIT 48
+#define COV_LOWMASK ((1ull << COV_DBIT) - 1ull)
+#ifndef COV_WIN1
+#define COV_WIN1 2048                                 // MODE 1 window (16 KiB: eight workgroups per CU)
+#endif
+#define COV_DQMAX 256                               // MODE 1: a register-path read ends at most this many bins after K
+
+#ifndef COV_MIN_WAVES
+#define COV_MIN_WAVES 4                            // waves per SIMD the register allocation must allow (MODE 0)
+#endif
+#ifndef COV_MIN_WAVES1
+#define COV_MIN_WAVES1 4                           // ... MODE 1
+#endif
+template <bool LDS_LUT, int MODE, bool Z1, int RPL>
+__global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_WAVES) void cov_accumulate(CovParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
     // everything lives in the dynamic region (a static __shared__ in front of it would shift its
-    // base off 16-byte alignment): [0] window base bin, [2..) window, then the LUT pair
-    // (main table, then the contig's end-bin table, each bin_size+1 entries)
-    int *s_base = reinterpret_cast<int *>(smem);
-    unsigned long long *win = smem + 2;
-    unsigned long long *lutS = win + COV_WIN;
+    // base off 16-byte alignment): [0..11] scratch (4 scan words, then the bin of every tile's last read), [12..) window
+    // (+2 spare words), then the LUT pair
+    // (main table, then the contig's end-bin table, each bin_size+1 entries); MODE 1 adds three tables behind them
+    constexpr int WIN = MODE == 1 ? COV_WIN1 : COV_WIN;
+    constexpr int TILE = COV_THREADS * RPL;            // reads per workgroup step
+    int *s_wsum = reinterpret_cast<int *>(smem);
+    int *s_tbin = s_wsum + 4;                          // [COV_READS_PER_BLOCK / TILE] <= 16 entries
+    unsigned long long *win = smem + 12;
+    unsigned long long *lutS = win + WIN + 2;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -190,46 +222,66 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
     const unsigned long long r0 = (unsigned long long)blk * COV_READS_PER_BLOCK;
     const unsigned long long r1 = min(I.n, r0 + COV_READS_PER_BLOCK);
     const unsigned z = (unsigned)P.bin_size;
+    const int last_bin = I.nbins - 1;
+    auto div = [&](int x) { return Z1 ? x : (int)(__umulhi((unsigned)x, P.magic) >> P.shift); };
 
     // first tile's loads go out before the LDS set-up
-    CovTile cur = cov_load(I, r0 + (unsigned long long)tid * COV_RPL, r1);
+    CovTile<RPL> cur = cov_load<RPL>(I, r0 + (unsigned long long)tid * RPL, r1);
 
-    for (int i = tid; i < COV_WIN; i += COV_THREADS) win[i] = 0;
+    for (int i = tid; i < WIN + 2; i += COV_THREADS) win[i] = 0;
     if (LDS_LUT) {
         for (unsigned i = tid; i <= z; i += COV_THREADS) {
-            lutS[i] = P.lut_main[i];
+            const unsigned long long v = P.lut_main[i];
+            lutS[i] = v;
             lutS[i + z + 1] = I.lut_end[i];
+            if (MODE == 1) {
+                // tabA[i] = (v, 0), tabB[i] = (0, v): one 8-byte read yields the first-bin partial already routed to
+                // bin K (first word) or K+1 (second word); tabL[i] = v - 2^48: the last bin's partial with its -1;
+                // tabL[z+1] = 0 is where masked reads point
+                unsigned long long *tabA = lutS + 2 * (z + 1), *tabB = tabA + (z + 1), *tabL = tabB + (z + 1);
+                tabA[i] = v & 0xffffffffull;
+                tabB[i] = v << 32;
+                tabL[i] = v - (1ull << COV_DBIT);
+                if (i == 0) tabL[z + 1] = 0;
+            }
         }
     }
-    if (tid == 0) {
-        int s = I.start[r0];
+    // window base: the bin of the chunk's first read; every thread derives it from the same (scalar) load
+    auto bin_of_read = [&](unsigned long long idx) {
+        int s = I.start[idx];
         s = s < 0 ? 0 : s;
-        int b = cov_div(s, P.magic, P.shift);
-        *s_base = b < I.nbins ? b : I.nbins - 1;
+        const int b = div(s);
+        return b < I.nbins ? b : I.nbins - 1;
+    };
+    // bins of the tiles' last reads (for the window re-base below): one parallel round of loads instead of a
+    // dependent scalar load in every step
+    if (tid < COV_READS_PER_BLOCK / TILE) {
+        const unsigned long long tl = min(r0 + (unsigned long long)(tid + 1) * TILE, r1) - 1;
+        s_tbin[tid] = bin_of_read(tl);
     }
+    int base = bin_of_read(r0);
     __syncthreads();
-    const int base = *s_base;
-    const int last_bin = I.nbins - 1;
     // LUT[i] for i <= z: float32(i)/float32(z); LUT[z+1+i]: float32(i)/float32(end_bin_size).  LUT[0] == 0.
     auto lut = [&](unsigned i) -> unsigned long long {
         if (LDS_LUT) return lutS[i];
         return i <= z ? P.lut_main[i] : I.lut_end[i - z - 1];
     };
 
+    // plain (difference-free) contribution, any bin
     auto contribute = [&](int bin, unsigned long long v) {
         const unsigned off = (unsigned)(bin - base);
 #ifdef COV_EXP_NOATOMIC  // measurement variant (tools/build_variant.sh): everything but the LDS atomics — DESIGN.md §3.1 ceilings
         if (v == 0x1234567ull) win[0] = v;
 #else
-        if (off < COV_WIN) atomicAdd(&win[off], v);  // ds_add_u64 (bins past the contig end only ever see +x and -x)
+        if (off < (unsigned)WIN) atomicAdd(&win[off], v);  // ds_add_u64 (bins past the contig end only ever see +x and -x)
         else if ((unsigned)bin <= (unsigned)last_bin) cov_global_add(I.acc, bin, v);
 #endif
     };
 
     // the literal per-read update (tiddit_coverage.pyx:50-72) for reads the register path cannot hold
     auto slow_read = [&](int s, int e) {
-        const int fb = cov_div(s, P.magic, P.shift);
-        const int eb = cov_div(e - 1, P.magic, P.shift);
+        const int fb = div(s);
+        const int eb = div(e - 1);
         if (fb == eb) {
             contribute(fb, lut((unsigned)(e - s)));
         } else {
@@ -240,91 +292,194 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         }
     };
 
+    // spill the LDS window to the accumulators (coalesced 64-bit global atomics, zero bins skipped) and clear it
+    auto spill = [&]() {
+        __syncthreads();
+        if (MODE == 1) {
+            // resolve the difference counts: thread t owns window entries [PER*t, PER*t + PER)
+            constexpr int PER = WIN / COV_THREADS;
+            int d = 0;
+#pragma unroll
+            for (int k = 0; k < PER; k++) d += (int)((long long)win[tid * PER + k] >> COV_DBIT);
+            int incl = d;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            if (lane == 63) s_wsum[tid >> 6] = incl;
+            __syncthreads();
+            int run = incl - d;
+            for (int wv = 0; wv < (tid >> 6); wv++) run += s_wsum[wv];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const unsigned long long w = win[tid * PER + k];
+                run += (int)((long long)w >> COV_DBIT);
+                win[tid * PER + k] = (w & COV_LOWMASK) + (unsigned long long)(long long)run * P.one;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < WIN; i += COV_THREADS) {
+            const unsigned long long v = win[i];
+            if (v) {
+                if (base + i <= last_bin) atomicAdd(&I.acc[base + i], v);
+                win[i] = 0;
+            }
+        }
+    };
+
     unsigned nkept = 0;
     bool bad = false;
 
-    for (unsigned long long t0 = r0; t0 < r1; t0 += COV_TILE) {
+    for (unsigned long long t0 = r0; t0 < r1; t0 += TILE) {
         // software prefetch: the next tile's loads are in flight while this one is reduced
-        CovTile nxt = cur;
-        if (t0 + COV_TILE < r1) nxt = cov_load(I, t0 + COV_TILE + (unsigned long long)tid * COV_RPL, r1);
+        CovTile<RPL> nxt = cur;
+        if (t0 + TILE < r1) nxt = cov_load<RPL>(I, t0 + TILE + (unsigned long long)tid * RPL, r1);
 
-        int sv[COV_RPL], ev[COV_RPL];
-        unsigned mq[COV_RPL], fl[COV_RPL];
+        // window re-base (block-uniform): when this tile's last read starts near the window's end the window is spilled
+        // and moved to the previous tile's last read, so sparse streams / small bins stay on the LDS path
+        if (t0 != r0) {
+            const int step = (int)((t0 - r0) / TILE);
+            if (s_tbin[step] + P.margin >= base + WIN) {
+                const int nb = s_tbin[step - 1];
+                if (nb != base) {
+                    spill();
+                    __syncthreads();
+                    base = nb;
+                }
+            }
+        }
+
+        int sv[RPL], ev[RPL];
+        unsigned mq[RPL], fl[RPL];
 #pragma unroll
-        for (int j = 0; j < COV_RPL; j++) {
+        for (int j = 0; j < RPL; j++) {
             sv[j] = cur.s[j];
             ev[j] = cur.e[j];
             mq[j] = (cur.mq[j / 4] >> (8 * (j & 3))) & 0xffu;
             fl[j] = (cur.fl[j / 2] >> (16 * (j & 1))) & 0xffffu;
         }
 
-        // lane key K: first bin of the lane's first read (the only division of the step).  A read whose
-        // first bin is K or K+1 and whose last bin is at most one further is folded into the three
-        // registers a0,a1,a2 (bins K, K+1, K+2) without branches; anything else (reads spanning more
-        // bins, unsorted input) is flagged and replayed literally below.  Any K is correct; sorted
-        // input makes K non-decreasing across lanes so equal keys form runs.
-        const int K = cov_div(sv[0] < 0 ? 0 : sv[0], P.magic, P.shift);
+        // lane key K: first bin of the lane's first read (one division).  Any K is correct; sorted
+        // input makes K non-decreasing across lanes.
+        const int K = div(sv[0] < 0 ? 0 : sv[0]);
         const unsigned Kz = (unsigned)K * z;
         unsigned long long a0 = 0, a1 = 0, a2 = 0;
 #ifdef COV_EXP_LOADONLY  // measurement variant: the loads alone (the 0.79 "load-only" ceiling quoted in DESIGN.md §3.1)
-        for (int j = 0; j < COV_RPL; j++) a0 += (unsigned)(sv[j] + ev[j]) + mq[j] + fl[j];
+        for (int j = 0; j < RPL; j++) a0 += (unsigned)(sv[j] + ev[j]) + mq[j] + fl[j];
         if (a0 == 0x1234567ull) contribute(K, a0);
         cur = nxt;
         continue;
 #endif
         unsigned slowmask = 0;
+        if (MODE == 0) {
+            // A read whose first bin is K or K+1 and whose last bin is at most one further is folded into the three
+            // registers a0,a1,a2 (bins K, K+1, K+2) without branches; anything else (reads spanning more bins,
+            // unsorted input) is flagged and replayed literally below.
 #pragma unroll
-        for (int j = 0; j < COV_RPL; j++) {
-            const int s = sv[j], e = ev[j];
-            bool keep = !(fl[j] & 0x404u) && (int)mq[j] >= P.min_q;   // __main__.py:231-235 / tiddit_signal.pyx:171-181
-            const bool invalid = keep && (s < 0 || e <= s);
-            const unsigned rs = (unsigned)s - Kz;        // offsets from the start of bin K
-            const unsigned re = (unsigned)(e - 1) - Kz;
-            const unsigned r = (rs >= z) ? 1u : 0u;      // first bin = K + r   (rs < 2z on the register path)
-            const unsigned q = (re >= z ? 1u : 0u) + (re >= 2u * z ? 1u : 0u);  // last bin = K + q (re < 3z)
-            const bool over = keep && !invalid && (K + (int)q > last_bin) && re < 3u * z;
-            bad = bad || invalid || over;
-            keep = keep && !invalid && !over;
-            nkept += keep ? 1u : 0u;
-            const bool fast = rs < 2u * z && re < 3u * z && q - r <= 1u;
-            const bool ok = keep && fast;
-            slowmask |= (keep && !fast) ? (1u << j) : 0u;
-            const bool multi = q != r;
-            // bases in the first bin (:55 single-bin / :61 multi-bin) and in the last bin (:63, one short)
-            const unsigned bf = multi ? (r + 1u) * z - rs : (unsigned)(e - s);
-            const unsigned bl = re - q * z + ((K + (int)q == last_bin) ? z + 1u : 0u);   // :66-69 picks the end-bin table
-            const unsigned long long vF = lut(ok ? bf : 0u);                 // :57 / :62
-            const unsigned long long vL = lut((ok && multi) ? bl : 0u);      // :66-69
-            const bool r0_ = r == 0;
-            a0 += r0_ ? vF : 0ull;
-            a1 += r0_ ? vL : vF;
-            a2 += r0_ ? 0ull : vL;
-        }
-        if (slowmask) {
+            for (int j = 0; j < RPL; j++) {
+                const int s = sv[j], e = ev[j];
+                bool keep = !(fl[j] & 0x404u) && (int)mq[j] >= P.min_q;   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+                const bool invalid = keep && (s < 0 || e <= s);
+                const unsigned rs = (unsigned)s - Kz;        // offsets from the start of bin K
+                const unsigned re = (unsigned)(e - 1) - Kz;
+                const unsigned r = (rs >= z) ? 1u : 0u;      // first bin = K + r   (rs < 2z on the register path)
+                const unsigned q = (re >= z ? 1u : 0u) + (re >= 2u * z ? 1u : 0u);  // last bin = K + q (re < 3z)
+                const bool over = keep && !invalid && (K + (int)q > last_bin) && re < 3u * z;
+                bad = bad || invalid || over;
+                keep = keep && !invalid && !over;
+                nkept += keep ? 1u : 0u;
+                const bool fast = rs < 2u * z && re < 3u * z && q - r <= 1u;
+                const bool ok = keep && fast;
+                slowmask |= (keep && !fast) ? (1u << j) : 0u;
+                const bool multi = q != r;
+                // bases in the first bin (:55 single-bin / :61 multi-bin) and in the last bin (:63, one short)
+                const unsigned bf = multi ? (r + 1u) * z - rs : (unsigned)(e - s);
+                const unsigned bl = re - q * z + ((K + (int)q == last_bin) ? z + 1u : 0u);   // :66-69 picks the end-bin table
+                const unsigned long long vF = lut(ok ? bf : 0u);                 // :57 / :62
+                const unsigned long long vL = lut((ok && multi) ? bl : 0u);      // :66-69
+                const bool r0_ = r == 0;
+                a0 += r0_ ? vF : 0ull;
+                a1 += r0_ ? vL : vF;
+                a2 += r0_ ? 0ull : vL;
+            }
+            if (slowmask) {
 #pragma unroll
-            for (int j = 0; j < COV_RPL; j++)
-                if (slowmask & (1u << j)) {
-                    if (cov_div(ev[j] - 1, P.magic, P.shift) > last_bin) { bad = true; nkept--; }
-                    else slow_read(sv[j], ev[j]);
-                }
-        }
-
-        // wavefront merge: inclusive prefix sums of the three registers; a run [a..b] of equal K sums to
-        // P[b] - P[a-1], so run-tail lanes add +P[b] and run-head lanes add -P[a-1] (two's complement).
-        // (cross-lane reads happen with every lane active: a masked-off DPP source lane returns nothing)
-        wave_scan3_u64(a0, a1, a2);
-        const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
-        const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
-        const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(a0), q1 = dpp_u64<DPP_WAVE_SHR1>(a1), q2 = dpp_u64<DPP_WAVE_SHR1>(a2);
-        if (Knext != K) {  // run tail (lane 63 always: it reads ~K)
-            if (a0) contribute(K, a0);
-            if (a1) contribute(K + 1, a1);
-            if (a2) contribute(K + 2, a2);
-        }
-        if (Kprev != K && lane != 0) {  // run head
-            if (q0) contribute(K, 0ull - q0);
-            if (q1) contribute(K + 1, 0ull - q1);
-            if (q2) contribute(K + 2, 0ull - q2);
+                for (int j = 0; j < RPL; j++)
+                    if (slowmask & (1u << j)) {
+                        if (div(ev[j] - 1) > last_bin) { bad = true; nkept--; }
+                        else slow_read(sv[j], ev[j]);
+                    }
+            }
+            // wavefront merge: inclusive prefix sums of the three registers; a run [a..b] of equal K sums to
+            // P[b] - P[a-1], so run-tail lanes add +P[b] and run-head lanes add -P[a-1] (two's complement).
+            // (cross-lane reads happen with every lane active: a masked-off DPP source lane returns nothing)
+            wave_scan3_u64(a0, a1, a2);
+            const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
+            const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
+            const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(a0), q1 = dpp_u64<DPP_WAVE_SHR1>(a1), q2 = dpp_u64<DPP_WAVE_SHR1>(a2);
+            if (Knext != K) {  // run tail (lane 63 always: it reads ~K)
+                if (a0) contribute(K, a0);
+                if (a1) contribute(K + 1, a1);
+                if (a2) contribute(K + 2, a2);
+            }
+            if (Kprev != K && lane != 0) {  // run head
+                if (q0) contribute(K, 0ull - q0);
+                if (q1) contribute(K + 1, 0ull - q1);
+                if (q2) contribute(K + 2, 0ull - q2);
+            }
+        } else {
+            const unsigned long long *tabA = lutS + 2 * (z + 1), *tabL = tabA + 2 * (z + 1);
+            // a lane takes the window path when every bin its reads can reach there, K .. K + COV_DQMAX, lies inside the
+            // window and before the contig's last bin (whose denominator differs, :66-69)
+            const unsigned ko = (unsigned)(K - base);
+            const bool safe = ko < (unsigned)(WIN - COV_DQMAX - 2) && K + COV_DQMAX + 2 <= last_bin;
+            const unsigned kw = safe ? ko : 0u;
+            unsigned d1 = 0, d2 = 0;                         // reads that put their +1 on bin K+1 / K+2
+            unsigned long long vL[RPL];
+            unsigned woff[RPL];
+            // phase 1: table reads only (no LDS atomic in between, so nothing orders them behind one another)
+#pragma unroll
+            for (int j = 0; j < RPL; j++) {
+                const unsigned rs = (unsigned)sv[j] - Kz;    // offsets from the start of bin K: first base, one past the last base
+                const unsigned re1 = (unsigned)ev[j] - Kz;
+                const unsigned len = re1 - rs;               // e - s (wraps to a huge value when e <= s)
+                const bool cand = ((fl[j] & 0x404u) == 0) & ((int)mq[j] >= P.min_q);   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+                // window path: first bin K or K+1, at most xmax bases past the start of bin K (so the 24-bit multiply below
+                // is an exact division and the last bin is at most K + COV_DQMAX)
+                const bool fast = cand & safe & (rs < 2u * z) & (len - 1u < P.xmax) & (re1 <= P.xmax);
+                nkept += fast ? 1u : 0u;
+                slowmask |= (cand & !fast) ? (1u << j) : 0u;
+                const bool r1_ = rs >= z;                    // first bin = K + 1
+                const unsigned dq = (__umul24(re1, P.m15) - P.m15) >> P.k15;     // (e - 1 - K z) / z: last bin = K + dq
+                const bool multi = fast & (dq != (r1_ ? 1u : 0u));
+                const unsigned bf = min(len, (r1_ ? 2u * z : z) - rs);          // bases in the first bin (:55 / :61)
+                const unsigned long long vv = tabA[(fast ? bf : 0u) + (r1_ ? z + 1u : 0u)];   // (to bin K, to bin K+1)
+                a0 += (unsigned)vv;
+                a1 += (unsigned)(vv >> 32);
+                d1 += (multi & !r1_) ? 1u : 0u;
+                d2 += (multi & r1_) ? 1u : 0u;
+                // last bin: re1 - dq z - 1 bases (:63, one short) with the -1 of the difference pair; masked reads add 0 to the spare word
+                const unsigned bl1 = re1 - __umul24(dq, z);
+                vL[j] = tabL[multi ? bl1 - 1u : z + 1u];
+                woff[j] = multi ? kw + dq : (unsigned)WIN;
+            }
+#ifndef COV_EXP_NOATOMIC
+            // phase 2: the atomics
+#pragma unroll
+            for (int j = 0; j < RPL; j++) atomicAdd(&win[woff[j]], vL[j]);
+            atomicAdd(&win[kw], a0);
+            atomicAdd(&win[kw + 1], a1 + ((unsigned long long)d1 << COV_DBIT));
+            atomicAdd(&win[kw + 2], (unsigned long long)d2 << COV_DBIT);
+#endif
+            if (slowmask) {
+#pragma unroll
+                for (int j = 0; j < RPL; j++)
+                    if (slowmask & (1u << j)) {
+                        const int s = sv[j], e = ev[j];
+                        if (s < 0 || e <= s || div(e - 1) > last_bin) bad = true;
+                        else { nkept++; slow_read(s, e); }
+                    }
+            }
         }
         cur = nxt;
     }
@@ -336,12 +491,7 @@ __global__ __launch_bounds__(COV_THREADS) void cov_accumulate(CovParams P) {
         atomicAdd(P.kept + (size_t)((blockIdx.x * (COV_THREADS / 64) + (tid >> 6)) % COV_KEPT_SLOTS) * 16, (unsigned long long)nkept);
     if (bad) atomicOr(P.status, 1);
 
-    __syncthreads();
-    // coalesced spill of the LDS window
-    for (int i = tid; i < COV_WIN; i += COV_THREADS) {
-        const unsigned long long v = win[i];
-        if (v && base + i <= last_bin) atomicAdd(&I.acc[base + i], v);
-    }
+    spill();
 }
 
 __global__ void cov_finalize(const long long *__restrict__ acc, double *__restrict__ out, long long n, double inv_scale,
@@ -363,6 +513,9 @@ struct tdt_cov {
     int n_contigs = 0;
     int bin_size = 0;
     int S = 0;  // fixed-point fraction bits
+    bool small_bins = false;  // cov_accumulate MODE 1
+    unsigned xmax = 0, m15 = 0;
+    int k15 = 0;
     unsigned magic = 0;
     int shift = 0;
     std::vector<int64_t> len, nbins, off;  // off: accumulator offset of each contig
@@ -412,6 +565,25 @@ extern "C" int tdt_cov_create(tdt_ctx *ctx, const int64_t *contig_len, int n_con
     c->bin_size = bin_size;
     const int L = tdt_ceil_log2_u64((uint64_t)bin_size);
     c->S = 23 + L + 1;
+    {
+        // MODE 1 needs the float32 quotients to fit 32 bits (S <= 31: bin_size <= 128) and an exact 24-bit division
+        const char *env = getenv("TIDDIT_COV_MODE");   // 0 / 1 force a kernel flavour (A/B measurements)
+        const bool can = bin_size >= 2 && c->S <= 31;
+        c->small_bins = can;
+        if (env && env[0] == '0') c->small_bins = false;
+        if (can) {
+            c->k15 = 15 + L;
+            c->m15 = (unsigned)(((1ull << c->k15) + (unsigned)bin_size - 1) / (unsigned)bin_size);
+            const unsigned lim = (unsigned)COV_DQMAX * (unsigned)bin_size;
+            c->xmax = lim < 32768u ? lim : 32768u;
+            for (unsigned x = 0; x < c->xmax; x++)
+                if (((x * c->m15) >> c->k15) != x / (unsigned)bin_size) {
+                    tdt_set_error("internal: 24-bit division self-check failed for d=%d x=%u", bin_size, x);
+                    delete c;
+                    return TDT_E_ARG;
+                }
+        }
+    }
     if (L == 0) {
         c->shift = -1;
         c->magic = 0;
@@ -565,12 +737,23 @@ static int cov_launch_items(tdt_cov *c, const CovItem &single, const CovItem *d_
     P.one = 1ull << c->S;
     P.status = c->d_status;
     P.kept = c->d_kept;
+    const bool small = c->small_bins;
+    P.margin = small ? COV_DQMAX + 8 : 640 / c->bin_size + 4;
+    P.xmax = c->xmax;
+    P.m15 = c->m15;
+    P.k15 = c->k15;
     const bool lds_lut = c->bin_size + 1 <= COV_LUT_LDS_MAX;
-    const size_t lds = 16 + (size_t)COV_WIN * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0);
-    if (lds_lut)
-        hipLaunchKernelGGL(cov_accumulate<true>, dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    const size_t lds = 96 + ((size_t)(small ? COV_WIN1 : COV_WIN) + 2) * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0) +
+                       (small ? (3 * ((size_t)c->bin_size + 1) + 1) * 8 : 0);
+    // small bins: few reads share a bin, a read covers several -> difference-pair kernel
+    if (small)
+        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (lds_lut && c->shift >= 0)
+        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (lds_lut)
+        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else
-        hipLaunchKernelGGL(cov_accumulate<false>, dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     TDT_CHECK_LAUNCH();
     return TDT_OK;
 }

@@ -247,3 +247,407 @@ def write_random_bam(path, seed):
                 int(rng.integers(-5000, 5000)), "".join(rng.choice(list("ACGTN"), lseq)), tuple(tags))
     w.close()
     return n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# WGS-shaped paired-end BAM with planted structural variants (BASELINE configs[3]: `tiddit --sv --skip_assembly`)
+HUMAN_MB = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]   # GRCh38 chr1..22, X, Y
+
+
+def wgs_contigs(total_mb, decoys=True):
+    """24 chromosomes with GRCh38's relative lengths scaled to `total_mb` in all (lengths are not multiples of any bin size),
+    plus chrM and two unplaced scaffolds shorter than tiddit's default --min_contig (10000)."""
+    scale = total_mb / float(sum(HUMAN_MB))
+    names = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+    contigs = [(n, int(mb * scale * 1e6) // 1000 * 1000 + 137 + 11 * i) for i, (n, mb) in enumerate(zip(names, HUMAN_MB))]
+    if decoys:
+        contigs += [("chrM", 16569), ("chrUn_KI270302v1", 2274), ("chrUn_KI270304v1", 2165)]
+    return contigs
+
+
+def write_fasta(path, contigs, seed=100, width=60):
+    """reference FASTA for `contigs` (synth.gen_sequence per contig) -> {name: uint8 sequence}"""
+    from .synth import gen_sequence
+    seqs = {}
+    with open(path, "wb") as f:
+        for i, (name, L) in enumerate(contigs):
+            s = gen_sequence(L, seed=seed + i)
+            seqs[name] = s
+            f.write((">%s\n" % name).encode())
+            nfull = L // width
+            body = np.empty((nfull, width + 1), dtype=np.uint8)
+            body[:, :width] = s[:nfull * width].reshape(nfull, width)
+            body[:, width] = 10
+            f.write(body.tobytes())
+            if L > nfull * width:
+                f.write(s[nfull * width:].tobytes() + b"\n")
+    return seqs
+
+
+_NIB = np.zeros(256, dtype=np.uint8) + 15
+for _c, _v in zip(b"=ACMGRSVTWYHKDBN", range(16)):
+    _NIB[_c] = _v
+    _NIB[_c | 0x20] = _v
+
+
+def write_wgs_sv_bam(path, contigs, depth=30, read_len=150, insert=400, insert_sd=40, seed=7, sv_per_mb=3.0, noise_pair_frac=1e-3,
+                     level=1, threads=8, sample="WGS", ref_seqs=None, chunk=1 << 18):
+    """Coordinate-sorted paired-end BAM shaped like a 30x short-read WGS run, everything derived from `seed`:
+      * FR pairs at `depth` over every contig (98 % of the records; fixed-size records built with numpy), 2 % duplicates,
+        12 % of the reads below mapq 60, a random half of the pairs with read 2 leftmost;
+      * per-pair variations written record by record: soft-clipped reads (clip candidates of tiddit_signal.worker :190-197),
+        reads with a deletion in the CIGAR (reference_end > pos + l_seq), supplementary (SA-tagged, 0x800) and secondary (0x100)
+        extra alignments, pairs with an unmapped mate;
+      * planted events at `sv_per_mb` per Mb — deletions, tandem duplications, inversions (both junctions), inter-chromosomal
+        translocations — each with 4..14 discordant pairs and 0..8 split reads whose primary carries an SA tag and whose
+        supplementary alignment is present as its own record; a fifth of the SA tags list a second alignment, some point at
+        low-mapq alignments, some fragments have SA tags on both mates (one qname, two split rows);
+      * noise: `noise_pair_frac` of the pairs have the mate far away on the same contig or on another contig;
+      * a tail of unplaced unmapped pairs.
+    ref_seqs: {name: uint8 ASCII sequence} — reads are then cut from it (as an aligner would report them); otherwise random bases.
+    -> dict(events=[...], n_records=...)"""
+    import os
+    import struct
+    from concurrent.futures import ThreadPoolExecutor
+    from .bamio import _BGZF_EOF, _bgzf_block, _reg2bin
+    rl = read_len
+    ncon = len(contigs)
+    lens = np.array([l for _, l in contigs], dtype=np.int64)
+    span = insert + 6 * insert_sd
+    big = [t for t in range(ncon) if lens[t] > 60 * span]
+    n_pairs = [int(l * depth / (2 * rl)) if l > 4 * span else 0 for l in lens]
+    pair_base = np.concatenate([[0], np.cumsum(n_pairs)])
+    specials = [[] for _ in range(ncon + 1)]          # per tid (last: unplaced): (pos, record bytes)
+    erng = np.random.default_rng([seed, 1 << 20])
+    pool = np.array([1, 2, 4, 8], np.uint8)[erng.integers(0, 4, 1 << 16, dtype=np.uint8)]
+    pool = ((pool[0::2] << 4) | pool[1::2]).tobytes()
+    qpool = np.minimum(40, 2 + (38 * np.sqrt(erng.integers(60, 256, 1 << 15) / 255.0)).astype(np.int64)).astype(np.uint8).tobytes()
+    half = (rl + 1) // 2
+
+    def packed_seq(tid, pos, n, rng):
+        """4-bit packed bases of n query bases starting at reference pos (no reference: random)"""
+        if ref_seqs is not None and tid >= 0:
+            s = ref_seqs[contigs[tid][0]]
+            seg = s[max(0, pos):max(0, pos) + n]
+            nib = _NIB[seg]
+            if len(nib) < n + (n & 1):
+                nib = np.concatenate([nib, np.full(n + (n & 1) - len(nib), 1, np.uint8)])
+            nib = nib[:n + (n & 1)].copy()
+            if n & 1:
+                nib[n] = 0
+            return ((nib[0::2] << 4) | nib[1::2]).tobytes()
+        o = int(rng.integers(0, len(pool) - half - 1))
+        return pool[o:o + (n + 1) // 2]
+
+    def enc(rng, qname, flag, tid, pos, mapq, cigar, mtid, mpos, tlen, aux=b"", lseq=rl):
+        """cigar: list of (op, len) (hard clips do not count towards lseq)"""
+        rlen = sum(l for op, l in cigar if op in (0, 2, 3, 7, 8)) or 1
+        name = qname.encode() + b"\x00"
+        o = int(rng.integers(0, len(qpool) - lseq - 1))
+        body = (struct.pack("<iiBBHHHiiii", tid, pos, len(name), mapq, _reg2bin(pos, pos + rlen) if pos >= 0 else 4680, len(cigar), flag, lseq,
+                            mtid, mpos, tlen) + name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cigar) +
+                packed_seq(tid, pos, lseq, rng) + qpool[o:o + lseq] + aux)
+        return struct.pack("<i", len(body)) + body
+
+    def sa_tag(entries):
+        return b"SAZ" + "".join("%s,%d,%s,%s,%d,%d;" % e for e in entries).encode() + b"\x00"
+
+    def cig_str(cig):
+        return "".join("%d%s" % (l, "MIDNSHP=X"[op]) for op, l in cig)
+
+    M, S, H, D = 0, 4, 5, 2
+
+    # ---------------- planted events + noise pairs (main thread, one RNG) ----------------
+    events = []
+    weights = lens[big] / lens[big].sum() if big else None
+    n_events = int(round(sv_per_mb * lens[big].sum() / 1e6)) if big else 0
+
+    def put(tid, pos, rec):
+        specials[tid if tid >= 0 else ncon].append((pos, rec))
+
+    def pair(qn, tA, pA, revA, cigA, tB, pB, revB, cigB, mapqA=60, mapqB=60, auxA=b"", auxB=b"", first_is_A=True, extraA=0, extraB=0):
+        endA = pA + sum(l for op, l in cigA if op in (0, 2))
+        endB = pB + sum(l for op, l in cigB if op in (0, 2))
+        if tA == tB:
+            lo, hi = min(pA, pB), max(endA, endB)
+            tl = hi - lo
+            tlA = tl if pA <= pB else -tl
+            tlB = -tlA
+        else:
+            tlA = tlB = 0
+        fA = 0x1 | (0x40 if first_is_A else 0x80) | (0x10 if revA else 0) | (0x20 if revB else 0) | extraA
+        fB = 0x1 | (0x80 if first_is_A else 0x40) | (0x10 if revB else 0) | (0x20 if revA else 0) | extraB
+        lA = sum(l for op, l in cigA if op in (0, 1, 4))
+        lB = sum(l for op, l in cigB if op in (0, 1, 4))
+        put(tA, pA, enc(erng, qn, fA, tA, pA, mapqA, cigA, tB, pB, tlA, auxA, lA))
+        put(tB, pB, enc(erng, qn, fB, tB, pB, mapqB, cigB, tA, pA, tlB, auxB, lB))
+
+    def supplementary(qn, tid, pos, rev, cig, mt, mp, mrev, sa, first):
+        f = 0x1 | 0x800 | (0x40 if first else 0x80) | (0x10 if rev else 0) | (0x20 if mrev else 0)
+        lq = sum(l for op, l in cig if op in (0, 1, 4))
+        put(tid, pos, enc(erng, qn, f, tid, pos, 60, cig, mt, mp, 0, sa, lq))
+
+    full = [(M, rl)]
+    for ev in range(n_events):
+        kind = ("DEL", "DEL", "DUP", "INV", "BND")[int(erng.integers(0, 5))]
+        tA = big[int(erng.choice(len(big), p=weights))]
+        LA = int(lens[tA])
+        size = int(np.exp(erng.uniform(np.log(3 * span), np.log(40 * span))))
+        a = int(erng.integers(4 * span, LA - 4 * span - size))
+        b = a + size
+        cA = contigs[tA][0]
+        n_disc = int(erng.integers(4, 15))
+        n_split = int(erng.integers(0, 9))
+        low_event = erng.random() < 0.08                    # an event in a repeat: its reads map ambiguously
+        def mq():
+            return int(erng.integers(0, 12)) if low_event else (60 if erng.random() < 0.9 else int(erng.integers(3, 60)))
+        def frag():
+            return int(np.clip(erng.normal(insert, insert_sd), 2 * rl + 20, span))
+        rec = {"type": kind, "chrA": cA, "posA": a, "chrB": cA, "posB": b, "n_disc": n_disc, "n_split": n_split}
+        if kind == "BND":
+            tB = big[int(erng.choice(len(big), p=weights))]
+            while tB == tA and len(big) > 1:
+                tB = big[int(erng.choice(len(big), p=weights))]
+            b = int(erng.integers(4 * span, int(lens[tB]) - 4 * span))
+            revB = bool(erng.integers(0, 2))
+            rec.update(chrB=contigs[tB][0], posB=b)
+        for k in range(n_disc + n_split):
+            is_split = k >= n_disc
+            ins = frag()
+            qn = "%s%d_%d" % (kind.lower(), ev, k)
+            first = bool(erng.integers(0, 2))
+            # the split read's left part keeps j bases before the junction
+            j = int(erng.integers(30, rl - 30)) if is_split else 0
+            second_sa = [("chrUn_KI270302v1", int(erng.integers(1, 2000)), "+", "%dM%dS" % (rl // 2, rl - rl // 2), 0, 3)] if erng.random() < 0.2 else []
+            sa_mq = 60 if erng.random() < 0.85 else int(erng.integers(0, 8))
+            if kind == "DEL":
+                pA = a - j if is_split else int(erng.integers(a - ins + rl, a - rl + 1))
+                pB = pA + ins - rl + size
+                if is_split:
+                    cigA, cigS = [(M, j), (S, rl - j)], [(H, j), (M, rl - j)]
+                    auxA = sa_tag([(cA, b + 1, "+", cig_str([(S, j), (M, rl - j)]), sa_mq, 0)] + second_sa)
+                    supplementary(qn, tA, b, False, cigS, tA, pB, True, sa_tag([(cA, pA + 1, "+", cig_str(cigA), 60, 0)]), first)
+                    both = erng.random() < 0.15           # the mate is split too (second junction-spanning read of the fragment)
+                    pair(qn, tA, pA, False, cigA, tA, pB, True, full, mq(), mq(), auxA,
+                         sa_tag([(cA, a - 40 + 1, "-", "%dM%dS" % (40, rl - 40), 60, 1)]) if both else b"", first)
+                else:
+                    pair(qn, tA, pA, False, full, tA, pB, True, full, mq(), mq(), first_is_A=first)
+            elif kind == "DUP":
+                pA = b - j if is_split else int(erng.integers(b - ins + rl, b - rl + 1))     # forward read at the end of the first copy
+                pB = a + (pA + ins - rl - b)                                                 # its mate at the start of the second
+                if pB < a:
+                    pB = a
+                if is_split:
+                    cigA, cigS = [(M, j), (S, rl - j)], [(H, j), (M, rl - j)]
+                    auxA = sa_tag([(cA, a + 1, "+", cig_str([(S, j), (M, rl - j)]), sa_mq, 0)] + second_sa)
+                    supplementary(qn, tA, a, False, cigS, tA, pB, True, sa_tag([(cA, pA + 1, "+", cig_str(cigA), 60, 0)]), first)
+                    pair(qn, tA, pA, False, cigA, tA, pB, True, full, mq(), mq(), auxA, b"", first)
+                else:
+                    pair(qn, tA, pA, False, full, tA, pB, True, full, mq(), mq(), first_is_A=first)
+            elif kind == "INV":
+                if k % 2 == 0:            # junction at a: forward read before a, mate inside the inverted segment reads forward
+                    pA = a - j if is_split else int(erng.integers(a - ins + rl, a - rl + 1))
+                    pB = max(a, b - (pA + ins - rl - a) - rl)
+                    if is_split:
+                        cigA = [(M, j), (S, rl - j)]
+                        sp = b - (rl - j)
+                        auxA = sa_tag([(cA, sp + 1, "-", cig_str([(M, rl - j), (S, j)]), sa_mq, 0)] + second_sa)
+                        supplementary(qn, tA, sp, True, [(M, rl - j), (H, j)], tA, pB, False, sa_tag([(cA, pA + 1, "+", cig_str(cigA), 60, 0)]), first)
+                        pair(qn, tA, pA, False, cigA, tA, pB, False, full, mq(), mq(), auxA, b"", first)
+                    else:
+                        pair(qn, tA, pA, False, full, tA, pB, False, full, mq(), mq(), first_is_A=first)
+                else:                     # junction at b: both reads reverse
+                    sA = int(erng.integers(b - ins + rl, b - rl + 1))
+                    pA = min(b - rl, a + (b - sA - rl))
+                    pB = sA + ins - rl
+                    pair(qn, tA, pA, True, full, tA, pB, True, full, mq(), mq(), first_is_A=first)
+            else:                         # BND
+                pA = a - j if is_split else int(erng.integers(a - ins + rl, a - rl + 1))
+                off = pA + ins - rl - a
+                pB = b + off if not revB else b - off - rl
+                if is_split:
+                    cigA = [(M, j), (S, rl - j)]
+                    if not revB:
+                        sp, scig, shard = b, [(S, j), (M, rl - j)], [(H, j), (M, rl - j)]
+                    else:
+                        sp, scig, shard = b - (rl - j), [(M, rl - j), (S, j)], [(M, rl - j), (H, j)]
+                    auxA = sa_tag([(contigs[tB][0], sp + 1, "-" if revB else "+", cig_str(scig), sa_mq, 0)] + second_sa)
+                    supplementary(qn, tB, sp, revB, shard, tB, pB, not revB, sa_tag([(cA, pA + 1, "+", cig_str(cigA), 60, 0)]), first)
+                    pair(qn, tA, pA, False, cigA, tB, pB, not revB, full, mq(), mq(), auxA, b"", first)
+                else:
+                    pair(qn, tA, pA, False, full, tB, pB, not revB, full, mq(), mq(), first_is_A=first)
+        events.append(rec)
+    # noise pairs: mate far away on the same contig, or on another contig
+    n_noise = int(noise_pair_frac * sum(n_pairs)) if big else 0
+    for k in range(n_noise):
+        tA = big[int(erng.choice(len(big), p=weights))]
+        pA = int(erng.integers(0, int(lens[tA]) - rl))
+        tB = tA if erng.random() < 0.6 else big[int(erng.choice(len(big), p=weights))]
+        pB = int(erng.integers(0, int(lens[tB]) - rl))
+        pair("noise%d" % k, tA, pA, bool(erng.integers(0, 2)), full, tB, pB, bool(erng.integers(0, 2)), full,
+             60 if erng.random() < 0.7 else int(erng.integers(0, 60)), 60 if erng.random() < 0.7 else int(erng.integers(0, 60)))
+    for k in range(40):                   # unplaced unmapped pairs at the end of the file
+        for fl in (0x1 | 0x4 | 0x8 | 0x40, 0x1 | 0x4 | 0x8 | 0x80):
+            put(-1, -1, enc(erng, "unmapped%d" % k, fl, -1, -1, 0, [], -1, -1, 0))
+
+    # ---------------- per contig: bulk pairs + per-pair variations, interleaved with the specials by position ----------------
+    rec_dt = np.dtype([("block_size", "<i4"), ("tid", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"), ("bin", "<u2"),
+                       ("n_cigar", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("mate_tid", "<i4"), ("mate_pos", "<i4"), ("tlen", "<i4"),
+                       ("name", "S12"), ("cigar", "<u4"), ("seq", "u1", (half,)), ("qual", "u1", (rl,))])
+    R = rec_dt.itemsize
+    qual_lut = np.sort(np.minimum(40, 2 + (38 * np.sqrt(np.arange(256) / 255.0)).astype(np.int64)).astype(np.uint8))
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % c for c in contigs) + "@RG\tID:rg1\tSM:%s\n" % sample
+    tb = text.encode()
+    head = b"BAM\x01" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", ncon)
+    for name, ln in contigs:
+        nb = name.encode() + b"\x00"
+        head += struct.pack("<i", len(nb)) + nb + struct.pack("<i", ln)
+
+    def names_of(ids):
+        digits = (ids[:, None] // (10 ** np.arange(9, -1, -1, dtype=np.int64))[None, :] % 10 + 48).astype(np.uint8)
+        return np.concatenate([np.full((len(ids), 1), ord("p"), np.uint8), digits, np.zeros((len(ids), 1), np.uint8)], axis=1).view("S12")[:, 0]
+
+    counts = [0] * (ncon + 1)
+
+    def contig_job(tid):
+        name, L = contigs[tid]
+        L = int(L)
+        rng = np.random.default_rng([seed, tid])
+        npair = n_pairs[tid]
+        sp = specials[tid]
+        part = "%s.part%03d" % (path, tid)
+        if npair:
+            posA = rng.integers(0, L - span, npair).astype(np.int64)
+            ins = np.clip(rng.normal(insert, insert_sd, npair), rl + 1, span).astype(np.int64)
+            posB = posA + ins - rl
+            u = rng.random(npair)
+            firstA = rng.random(npair) < 0.5
+            ids = pair_base[tid] + np.arange(npair, dtype=np.int64)
+            mapqA = np.where(rng.random(npair) < 0.88, 60, rng.integers(0, 60, npair)).astype(np.uint8)
+            mapqB = np.where(rng.random(npair) < 0.88, 60, rng.integers(0, 60, npair)).astype(np.uint8)
+            dupA = np.where(rng.random(npair) < 0.02, 0x400, 0)
+            dupB = np.where(rng.random(npair) < 0.02, 0x400, 0)
+            flagA = 0x1 | 0x2 | 0x20 | np.where(firstA, 0x40, 0x80) | dupA
+            flagB = 0x1 | 0x2 | 0x10 | np.where(firstA, 0x80, 0x40) | dupB
+            # per-pair variations: A (and for the unmapped-mate pairs B) leave the bulk arrays
+            cat = np.zeros(npair, dtype=np.uint8)
+            for c, p in ((1, 0.005), (2, 0.007), (3, 0.008), (4, 0.009), (5, 0.0095)):
+                cat[(u < p) & (cat == 0)] = c
+            nm = names_of(ids)
+            for i in np.flatnonzero(cat):
+                c, qn, pA, pB, tl = int(cat[i]), nm[i].decode(), int(posA[i]), int(posB[i]), int(ins[i])
+                fA, fB, mA = int(flagA[i]), int(flagB[i]), int(mapqA[i])
+                if c == 1:                                   # soft clip on either side
+                    k = int(rng.integers(26, 61))
+                    cig = [(S, k), (M, rl - k)] if rng.random() < 0.5 else [(M, rl - k), (S, k)]
+                    sp.append((pA, enc(rng, qn, fA, tid, pA, mA, cig, tid, pB, tl)))
+                elif c == 2:                                 # deletion inside the read
+                    d = int(rng.integers(1, 31))
+                    sp.append((pA, enc(rng, qn, fA, tid, pA, mA, [(M, 70), (D, d), (M, rl - 70)], tid, pB, tl)))
+                elif c == 3:                                 # chimeric read: primary with SA + its supplementary alignment elsewhere
+                    k = int(rng.integers(40, 80))
+                    q = int(rng.integers(0, L - rl))
+                    sa = sa_tag([(name, q + 1, "+", "%dS%dM" % (k, rl - k), int(rng.choice([60, 60, 60, 20, 0])), 1)])
+                    sp.append((pA, enc(rng, qn, fA & ~0x2, tid, pA, mA, [(M, k), (S, rl - k)], tid, pB, tl, sa)))
+                    sp.append((q, enc(rng, qn, (fA & ~0x2) | 0x800, tid, q, 60, [(H, k), (M, rl - k)], tid, pB, 0,
+                                      sa_tag([(name, pA + 1, "+", "%dM%dS" % (k, rl - k), mA, 0)]), rl - k)))
+                elif c == 4:                                 # secondary alignment of A somewhere else
+                    q = int(rng.integers(0, L - rl))
+                    sp.append((pA, enc(rng, qn, fA, tid, pA, mA, full, tid, pB, tl)))
+                    sp.append((q, enc(rng, qn, fA | 0x100, tid, q, 0, full, tid, pB, 0)))
+                else:                                        # mate unmapped: B sits at A's position without a CIGAR
+                    fa = 0x1 | 0x8 | (fA & 0xc0)
+                    sp.append((pA, enc(rng, qn, fa, tid, pA, mA, full, tid, pA, 0)))
+                    sp.append((pA, enc(rng, qn, 0x1 | 0x4 | (fB & 0xc0), tid, pA, 0, [], tid, pA, 0)))
+            keepA = cat == 0
+            keepB = cat != 5
+            pos = np.concatenate([posA[keepA], posB[keepB]])
+            mate = np.concatenate([posB[keepA], posA[keepB]])
+            tl = np.concatenate([ins[keepA], -ins[keepB]])
+            flag = np.concatenate([flagA[keepA], flagB[keepB]])
+            mapq = np.concatenate([mapqA[keepA], mapqB[keepB]])
+            nm = np.concatenate([nm[keepA], nm[keepB]])
+            order = np.argsort(pos, kind="stable")
+            pos, mate, tl, flag, mapq, nm = pos[order], mate[order], tl[order], flag[order], mapq[order], nm[order]
+        else:
+            pos = np.zeros(0, dtype=np.int64)
+        sp.sort(key=lambda r: r[0])                          # stable: equal positions keep generation order
+        sp_pos = np.array([r[0] for r in sp], dtype=np.int64)
+        sp_at = np.searchsorted(pos, sp_pos, side="right")   # special k goes in front of bulk record sp_at[k]
+        counts[tid] = len(pos) + len(sp)
+        ref_nib = None
+        if ref_seqs is not None and len(pos):
+            ref_nib = np.concatenate([_NIB[ref_seqs[name]], np.full(rl + 2, 1, np.uint8)])
+        with open(part, "wb") as f:
+            pend = bytearray(head if tid == 0 else b"")
+            k = 0
+
+            def flush(final=False):
+                nblk = len(pend) // 0xff00 if not final else -(-len(pend) // 0xff00)
+                for o in range(0, nblk * 0xff00, 0xff00):
+                    f.write(_bgzf_block(bytes(pend[o:o + 0xff00]), level))
+                del pend[:nblk * 0xff00]
+
+            for lo in range(0, len(pos), chunk):
+                hi = min(len(pos), lo + chunk)
+                m = hi - lo
+                a = np.zeros(m, dtype=rec_dt)
+                a["block_size"] = R - 4
+                a["tid"], a["pos"], a["l_name"] = tid, pos[lo:hi], 12
+                a["mapq"], a["n_cigar"], a["l_seq"] = mapq[lo:hi], 1, rl
+                a["flag"] = flag[lo:hi]
+                a["mate_tid"], a["mate_pos"], a["tlen"] = tid, mate[lo:hi], tl[lo:hi]
+                e1 = pos[lo:hi] + rl - 1
+                b = np.full(m, 0, dtype=np.int64)
+                done = np.zeros(m, dtype=bool)
+                for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+                    same = ~done & ((pos[lo:hi] >> shift) == (e1 >> shift))
+                    b[same] = base + (pos[lo:hi][same] >> shift)
+                    done |= same
+                a["bin"] = b
+                a["name"] = nm[lo:hi]
+                a["cigar"] = (rl << 4) | 0
+                if ref_nib is not None:
+                    nib = ref_nib[pos[lo:hi, None] + np.arange(rl + (rl & 1))[None, :]]
+                    mism = rng.random(nib.shape) < 0.003
+                    nib = np.where(mism, np.roll(nib, 1, axis=1), nib)
+                else:
+                    nib = np.array([1, 2, 4, 8], np.uint8)[rng.integers(0, 4, (m, rl + (rl & 1)), dtype=np.uint8)]
+                if rl & 1:
+                    nib[:, rl] = 0
+                a["seq"] = (nib[:, 0::2] << 4) | nib[:, 1::2]
+                q = np.repeat(qual_lut[rng.integers(96, 256, (m, (rl + 9) // 10), dtype=np.uint8)], 10, axis=1)[:, :rl]
+                a["qual"] = np.where(rng.random((m, rl)) < 0.1, qual_lut[rng.integers(0, 256, (m, rl), dtype=np.uint8)], q)
+                buf = memoryview(a.tobytes())
+                prev = lo
+                while k < len(sp) and sp_at[k] < hi:
+                    at = int(sp_at[k])
+                    pend += buf[(prev - lo) * R:(at - lo) * R]
+                    pend += sp[k][1]
+                    prev = at
+                    k += 1
+                pend += buf[(prev - lo) * R:]
+                flush()
+            while k < len(sp):
+                pend += sp[k][1]
+                k += 1
+            flush(final=True)
+        return part
+
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        parts = list(ex.map(contig_job, range(ncon)))
+    tail = b"".join(r[1] for r in specials[ncon])
+    counts[ncon] = len(specials[ncon])
+    with open(path, "wb") as out:
+        for part in parts:
+            with open(part, "rb") as f:
+                while True:
+                    blk = f.read(64 << 20)
+                    if not blk:
+                        break
+                    out.write(blk)
+            os.remove(part)
+        for o in range(0, len(tail), 0xff00):
+            out.write(_bgzf_block(tail[o:o + 0xff00], level))
+        out.write(_BGZF_EOF)
+    return {"events": events, "n_records": int(sum(counts)), "n_noise_pairs": n_noise, "n_bulk_pairs": int(sum(n_pairs))}
