@@ -1,0 +1,97 @@
+"""BASELINE configs[3] on the GPU: `tiddit --sv --skip_assembly` end to end on a WGS-shaped synthetic BAM (24 chromosomes with
+GRCh38's relative lengths + chrM + two scaffolds below --min_contig, 30x, 150-bp pairs, planted DEL/DUP/INV/BND with SA-tagged
+split reads; tests/sv_e2e_common.py regenerates it from the fixture's seeds).  Everything the run leaves behind is compared with
+tests/golden/sv_e2e.json: signal tables and clip FASTA (restatement of tiddit_signal.pyx), 50-bp coverage of every contig,
+GC bins, the ploidy table (compiled tiddit_coverage_analysis) and the ENTIRE candidates dictionary of the compiled
+tiddit_cluster.main — keys, breakpoints, regions, insertion order."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cluster_oracle, signal_oracle
+
+from sv_e2e_common import load_fixture, materialise
+
+pytestmark = pytest.mark.gpu
+
+
+def h(t):
+    return hashlib.sha256(t.encode()).hexdigest()
+
+
+@pytest.fixture(scope="module", params=["sv_e2e_small.json", "sv_e2e.json"])
+def run(request, golden_dir, tmp_path_factory):
+    from tiddit_amd import __main__ as cli
+    fx = load_fixture(golden_dir, request.param)
+    d = str(tmp_path_factory.mktemp("e2e"))
+    bam, fa, contigs = materialise(fx, d, threads=min(16, os.cpu_count() or 1))
+    out = os.path.join(d, "run")
+    P = fx["params"]
+    cli.main(["--sv", "--bam", bam, "--ref", fa, "-o", out, "--skip_assembly", "-s", str(P["n_reads_stats"])])
+    return fx, bam, fa, contigs, out
+
+
+def test_signal_files(run):
+    fx, bam, fa, contigs, out = run
+    assert h(open(out + "_tiddit/discordants_WGS.tab").read()) == fx["discordants_sha256"]
+    assert h(open(out + "_tiddit/splits_WGS.tab").read()) == fx["splits_sha256"]
+    assert h(open(out + "_tiddit/clips_WGS.fa").read()) == fx["clips_sha256"]
+
+
+def test_ploidy_table(run):
+    """determine_ploidy (tiddit_coverage_analysis.pyx:9-41): device GC bins + device masked medians -> the reference's table, byte for byte"""
+    fx, bam, fa, contigs, out = run
+    assert open(out + ".ploidies.tab").read() == fx["ploidies_tab"]
+
+
+def test_candidates_whole_dictionary(run):
+    from tiddit_amd import tiddit_cluster
+    fx, bam, fa, contigs, out = run
+    P = fx["params"]
+    names = [n for n, _ in contigs]
+    cand = tiddit_cluster.main(out, names, dict(contigs), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"],
+                               fx["library"]["percentile_insert_size"], P["min_contig"], True, P["min_reads"])
+    assert cluster_oracle.summary(cand) == fx["candidates"]
+    assert h(cluster_oracle.canonical(cand)) == fx["candidates_sha256"]
+    # what the CLI wrote is the same table
+    rows = [l.rstrip("\n").split("\t") for l in open(out + ".candidates.tab") if not l.startswith("#")]
+    want = [[r[0], str(r[3]), r[1], str(r[4]), str(r[2])] + [str(x) for x in r[5:]] for r in fx["candidates"]]
+    assert rows == want
+
+
+def test_coverage_gc_and_library(run):
+    from tiddit_amd import tiddit_gc, tiddit_signal, tiddit_stats
+    fx, bam, fa, contigs, out = run
+    P = fx["params"]
+    lib = tiddit_stats.statistics(bam, fa, P["min_q"], 100000, P["n_reads_stats"])
+    for k, v in fx["library"].items():
+        assert lib[k] == v, (k, lib[k], v)
+    header, chroms, cov, data, splits, clips = tiddit_signal.scan_signals(bam, P["min_q"], lib["percentile_insert_size"], P["min_contig"],
+                                                                          P["min_anchor_len"], P["min_clip_len"], 50)
+    assert list(cov) == list(fx["coverage_sha256"])
+    for c in cov:
+        assert hashlib.sha256(cov[c].astype("<f8").tobytes()).hexdigest() == fx["coverage_sha256"][c], c
+    gc = tiddit_gc.main(fa, [n for n, _ in contigs], 1, 50, 0.5)
+    for c, want in fx["gc_sha256"].items():
+        assert hashlib.sha256(np.ascontiguousarray(gc[c]).tobytes()).hexdigest() == want, c
+
+
+def test_live_oracle_on_the_same_file(run, tmp_path):
+    """the restatements run here, on this machine's copy of the file: signal tables, coverage and candidates of the product run equal them"""
+    from tiddit_amd import tiddit_cluster
+    fx, bam, fa, contigs, out = run
+    if fx["params"]["total_mb"] > 8:
+        pytest.skip("the fixture's checksums cover the large file; the live oracle pass runs on the small one")
+    P = fx["params"]
+    max_ins = fx["library"]["percentile_insert_size"]
+    cov, disc, split, clips, each, n = signal_oracle.signal_main_file(bam, P["min_q"], max_ins, "WGS", P["min_contig"], P["min_anchor_len"], P["min_clip_len"])
+    assert open(out + "_tiddit/discordants_WGS.tab").read() == disc
+    assert open(out + "_tiddit/splits_WGS.tab").read() == split
+    assert open(out + "_tiddit/clips_WGS.fa").read() == clips
+    for c, txt in each.items():
+        assert open(out + "_tiddit/clips/%s.fa" % c).read() == txt
+    names = [n_ for n_, _ in contigs]
+    args = (names, dict(contigs), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"], max_ins, P["min_contig"], True, P["min_reads"])
+    assert cluster_oracle.canonical(tiddit_cluster.main(out, *args)) == cluster_oracle.canonical(cluster_oracle.main(out, *args))

@@ -1,0 +1,110 @@
+"""CPU side of BASELINE configs[3]: the oracle pieces of the --sv path are pinned to the fixture the compiled reference produced
+(tests/golden/sv_e2e_small.json), and the product's host stages that need no GPU are checked against the same numbers."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import cluster_oracle, signal_oracle
+
+from sv_e2e_common import load_fixture, materialise
+
+
+def h(t):
+    return hashlib.sha256(t.encode()).hexdigest()
+
+
+def _jsonable(c):               # the encoding tests/golden/make_golden.py stores candidates dictionaries in
+    if isinstance(c, dict):
+        return {str(k): _jsonable(v) for k, v in c.items()}
+    if isinstance(c, set):
+        return {"__set__": sorted(_jsonable(x) for x in c)}
+    if isinstance(c, (list, tuple)):
+        return [_jsonable(x) for x in c]
+    if isinstance(c, (np.integer,)):
+        return int(c)
+    if isinstance(c, (np.floating,)):
+        return float(c)
+    return c
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir, tmp_path_factory):
+    fx = load_fixture(golden_dir, "sv_e2e_small.json")
+    d = str(tmp_path_factory.mktemp("sv_small"))
+    bam, fa, contigs = materialise(fx, d, threads=4)
+    return fx, bam, fa, contigs, d
+
+
+def test_cluster_oracle_reproduces_the_reference_cases(golden_dir, tmp_path):
+    """oracle/cluster_oracle.py against tiddit_cluster.main's own outputs (six hand-built .tab pairs, tests/golden/cluster.json)"""
+    g = json.load(open(os.path.join(golden_dir, "cluster.json")))
+    for t in g["find_discordant_pos"]:
+        frag = ["q", "1", "1", "100", "250", t["revA"], "900", "1050", t["revB"]]
+        assert list(cluster_oracle.find_discordant_pos(frag, t["is_mp"])) == t["out"]
+    for k, case in enumerate(g["cases"]):
+        prefix = str(tmp_path / ("c%d" % k))
+        os.makedirs(prefix + "_tiddit")
+        open(prefix + "_tiddit/discordants_S.tab", "w").write("".join(l + "\n" for l in case["discordants_tab"]))
+        open(prefix + "_tiddit/splits_S.tab", "w").write("".join(l + "\n" for l in case["splits_tab"]))
+        cand = cluster_oracle.main(prefix, case["chromosomes"], case["contig_length"], ["S"], case["is_mp"], case["epsilon"], case["m"],
+                                   case["max_ins_len"], case["min_contig"], True, case["min_reads"])
+        # same keys, same values AND same insertion order (the order defines the VCF SV ids downstream)
+        assert json.dumps(_jsonable(cand)) == json.dumps(case["candidates"]), k
+
+
+def test_signal_oracle_file_scale_equals_per_read_literal(small):
+    """signal_main_file (C record walk + C predicate chain, only marked reads parsed) == signal_main (every read a Python object)"""
+    fx, bam, fa, contigs, d = small
+    hdr, reads = signal_oracle.parse_bam(bam)
+    max_ins = fx["library"]["percentile_insert_size"]
+    P = fx["params"]
+    wcov, wdisc, wsplit, wclips, weach = signal_oracle.signal_main(hdr, reads, P["min_q"], int(max_ins), "WGS", P["min_contig"], P["min_anchor_len"], P["min_clip_len"])
+    cov, disc, split, clips, each, n = signal_oracle.signal_main_file(bam, P["min_q"], max_ins, "WGS", P["min_contig"], P["min_anchor_len"], P["min_clip_len"])
+    assert n == len(reads) == fx["n_records"]
+    assert disc == wdisc and split == wsplit and clips == wclips and each == weach
+    assert list(cov) == list(wcov) and all(np.array_equal(cov[c], wcov[c]) for c in cov)
+    # ... and both equal what the fixture was computed from
+    assert h(disc) == fx["discordants_sha256"] and h(split) == fx["splits_sha256"] and h(clips) == fx["clips_sha256"]
+    for c in cov:
+        assert hashlib.sha256(cov[c].astype("<f8").tobytes()).hexdigest() == fx["coverage_sha256"][c], c
+    assert fx["discordants_rows"] > 300 and fx["splits_rows"] > 100 and fx["clips_entries"] > 500
+
+
+def test_cluster_oracle_reproduces_the_reference_candidates(small, tmp_path):
+    """the restatement on the e2e .tab files == the compiled tiddit_cluster.main (whole nested dictionary, insertion order included)"""
+    fx, bam, fa, contigs, d = small
+    P = fx["params"]
+    cov, disc, split, clips, each, n = signal_oracle.signal_main_file(bam, P["min_q"], fx["library"]["percentile_insert_size"], "WGS",
+                                                                      P["min_contig"], P["min_anchor_len"], P["min_clip_len"], want_clips=False)
+    prefix = str(tmp_path / "o")
+    os.makedirs(prefix + "_tiddit")
+    open(prefix + "_tiddit/discordants_WGS.tab", "w").write(disc)
+    open(prefix + "_tiddit/splits_WGS.tab", "w").write(split)
+    names = [n_ for n_, _ in contigs]
+    cand = cluster_oracle.main(prefix, names, dict(contigs), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"],
+                               fx["library"]["percentile_insert_size"], P["min_contig"], True, P["min_reads"])
+    assert cluster_oracle.summary(cand) == fx["candidates"]
+    assert h(cluster_oracle.canonical(cand)) == fx["candidates_sha256"]
+    # the planted events come back: every DEL/DUP/INV/BND with enough support has a candidate within the clustering distance
+    found = 0
+    for ev in fx["events"]:
+        for row in fx["candidates"]:
+            if {row[0], row[1]} == {ev["chrA"], ev["chrB"]} and min(abs(row[3] - ev["posA"]) + abs(row[4] - ev["posB"]), abs(row[3] - ev["posB"]) + abs(row[4] - ev["posA"])) < 1000:
+                found += 1
+                break
+    assert found >= 0.8 * len(fx["events"])
+
+
+def test_product_statistics_equal_the_reference(small, monkeypatch):
+    """tiddit_amd.tiddit_stats.statistics (vectorised on the host-decoded arrays) == tiddit_stats.py of the reference (fixture)"""
+    fx, bam, fa, contigs, d = small
+    monkeypatch.setenv("TIDDIT_HOST_INGEST", "1")
+    from tiddit_amd import tiddit_stats
+    for n_reads in (fx["params"]["n_reads_stats"],):
+        lib = tiddit_stats.statistics(bam, fa, fx["params"]["min_q"], 100000, n_reads)
+        for k, v in fx["library"].items():
+            assert lib[k] == v, (k, lib[k], v)

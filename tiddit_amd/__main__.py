@@ -5,8 +5,7 @@ Same two modes and the same flags as the reference driver (tiddit/__main__.py:22
 repository implements — library statistics, signal extraction + coverage (device), GC (device), ploidy,
 clustering (device) — and writes the signal ``.tab`` files, ``{o}.ploidies.tab`` and
 ``{o}.candidates.tab``.  Variant typing / filtering / VCF (tiddit_variant.pyx) and local assembly are out
-of scope: if the reference package is importable its ``tiddit_variant`` is handed the
-candidates, otherwise the run stops after the candidates table and says so.
+of scope: the run stops after the candidates table and says so.
 """
 import argparse
 import os
@@ -110,6 +109,9 @@ def run_cov(args):
         tiddit_coverage.print_coverage(coverage_data, bam_header, args.z, "bed", args.o + ".bed")
 
 
+STAGE_SECONDS = {}          # wall seconds of the last run_sv, stage by stage (bench.py reads it)
+
+
 def write_candidates(path, contigs, sv_clusters):
     with open(path, "w") as f:
         f.write("#chrA\tposA\tchrB\tposB\tcluster\tN_discordants\tN_splits\tN_contigs\tstartA\tendA\tstartB\tendB\n")
@@ -167,20 +169,29 @@ def run_sv(args, version):
             quit()
     min_mapq = args.q
     max_ins_len = 100000
+    T = STAGE_SECONDS
+    T.clear()
+    t = time.time()
     library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s)
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
+    T["library statistics"] = time.time() - t
 
     t = time.time()
     coverage_data = tiddit_signal.main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
                                        False, args.min_anchor_len, args.min_clip_len)
     print("extracted signals in:")
     print(t - time.time())
+    T["signal extraction + coverage"] = time.time() - t
+    T.update({"  " + k: v for k, v in tiddit_signal.STAGE_SECONDS.items()})
+    t = time.time()
     gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
+    T["GC bins"] = time.time() - t
     t = time.time()
     library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,
                                                         bam_header, gc_dictionary)
     print("calculated coverage in:")
     print(time.time() - t)
+    T["ploidy (masked medians)"] = time.time() - t
     if not args.e:
         args.e = int(library["avg_insert_size"] / 2.0)
     if not args.e:
@@ -190,7 +201,11 @@ def run_sv(args, version):
                                       args.skip_assembly, args.r)
     print("generated clusters in")
     print(time.time() - t)
+    T["clustering"] = time.time() - t
+    T.update({"  " + k: v for k, v in tiddit_cluster.STAGE_SECONDS.items()})
+    t = time.time()
     write_candidates(prefix + ".candidates.tab", contigs, sv_clusters)
+    T["candidates table"] = time.time() - t
     print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
 
 

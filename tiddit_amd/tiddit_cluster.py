@@ -51,6 +51,9 @@ def _new_candidate():
 _KIND = {"D": "discordants", "S": "splits", "A": "contigs"}
 
 
+STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
+
+
 def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly):
     """Parse discordants_/splits_/contigs_{sample}.tab in the reference's order (:46-137).
     -> signals[chrA][chrB] = list of records, positions[chrA][chrB] = list of [posA, posB, i]."""
@@ -165,7 +168,12 @@ def _breakpoints_from_discordants(cand, is_mp):
 
 
 def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
+    import time
+    t0 = time.time()
     signals, positions = _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly)
+    STAGE_SECONDS.clear()
+    STAGE_SECONDS["parse .tab"] = time.time() - t0
+    t0 = time.time()
 
     order = [(a, b) for a in chromosomes if a in positions for b in chromosomes if b in positions[a]]
     bucket_arrays = [numpy.array(positions[a][b], dtype=numpy.int64) for a, b in order]
@@ -176,6 +184,8 @@ def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins
         sharded = False
     labels = cluster_buckets_sharded(bucket_arrays, epsilon, m) if sharded else cluster_buckets(bucket_arrays, epsilon, m)
 
+    STAGE_SECONDS["sort + DBSCAN (device)"] = time.time() - t0
+    t0 = time.time()
     candidates = {}
     for chrA in chromosomes:           # candidates[chrA] exists for every chrA that has signals (:141-145)
         if chrA in positions:
@@ -234,4 +244,5 @@ def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins
                 cand["endB"] = max(B["end"])
                 cand["startA"] = min(A["start"])
                 cand["endA"] = max(A["end"])
+    STAGE_SECONDS["regroup + breakpoints"] = time.time() - t0
     return candidates

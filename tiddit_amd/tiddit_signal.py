@@ -206,6 +206,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
 
 
 _SCAN_CACHE = {}
+STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 
 
 def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bin_size, skip_index, min_anchor_len, min_clip_len):
@@ -232,6 +233,9 @@ def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_con
     t = time.time()
     header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
         bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
+    STAGE_SECONDS.clear()
+    STAGE_SECONDS["scan (ingest, coverage, predicates, rows)"] = time.time() - t
+    t1 = time.time()
     all_contigs = [c["SN"] for c in header["SQ"]]
     data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
     splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
@@ -279,4 +283,5 @@ def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_con
         for path in clip_fasta:
             for line in open(path):
                 f.write(line)
+    STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
     return coverage_data
