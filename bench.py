@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--gc-len", type=int, default=3_000_000_000, help="reference bases for the GC histogram pass")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--no-next", action="store_true", help="skip the small next-row kernels (masked medians, regional evidence counts)")
+    ap.add_argument("--no-sv-e2e", action="store_true", help="skip BASELINE configs[3]: tiddit --sv --skip_assembly on a WGS-shaped synthetic BAM")
+    ap.add_argument("--sv-mb", type=int, default=240, help="genome size (Mb, 24 chromosomes with GRCh38's relative lengths, 30x 150-bp pairs) of that BAM")
     ap.add_argument("--ingest-mb", type=int, default=8, help="Mb per contig (2 contigs, 30x, 100-bp reads) of the BAM the ingest pass reads")
     return ap.parse_args()
 
@@ -529,10 +531,90 @@ def main():
             nres["region"]["parity_checked"] = True
         result["next_rows"] = nres
 
+    # ---- BASELINE configs[3]: `tiddit --sv --skip_assembly` end to end, from the BAM file to the candidates table (rank 0)
+    if not args.no_sv_e2e and rank == 0:
+        result["sv_e2e"] = sv_e2e(args, ctx, world == 1 and not args.no_cpu_baseline)
+
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+
+
+def sv_e2e(args, ctx, with_oracle):
+    """One `tiddit --sv --skip_assembly` run (tiddit_amd.__main__, the CLI a user calls) on a synthetic WGS-shaped BAM
+    (tiddit_amd.synth_bam.write_wgs_sv_bam: 24 chromosomes + chrM + two short scaffolds, 30x, planted DEL/DUP/INV/BND), file in the
+    page cache, with the per-stage wall the CLI records; then the CPU restatement of the same path (oracle/signal_oracle.py +
+    oracle/cluster_oracle.py, one core) on the same file, timed, and every output compared with it."""
+    import contextlib
+    import hashlib
+    import io
+    import shutil
+    from tiddit_amd import __main__ as cli, synth_bam
+    mb = args.sv_mb
+    d = "/tmp/tiddit_bench_sv_%d" % mb
+    bam, fa = os.path.join(d, "WGS.bam"), os.path.join(d, "ref.fa")
+    contigs = synth_bam.wgs_contigs(mb)
+    t_gen = None
+    if not (os.path.exists(bam) and os.path.exists(fa)):
+        os.makedirs(d, exist_ok=True)
+        t0 = time.perf_counter()
+        seqs = synth_bam.write_fasta(fa, contigs)
+        synth_bam.write_wgs_sv_bam(bam + ".tmp", contigs, threads=min(32, os.cpu_count() or 1), ref_seqs=seqs)
+        del seqs
+        os.replace(bam + ".tmp", bam)
+        t_gen = time.perf_counter() - t0
+    out = os.path.join(d, "run")
+    walls, stages = [], None
+    for rep in range(2):                                            # first pass warms the page cache and the device buffers
+        shutil.rmtree(out + "_tiddit", ignore_errors=True)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            cli.main(["--sv", "--bam", bam, "--ref", fa, "-o", out, "--skip_assembly", "--force_overwrite"])
+        ctx.sync()
+        walls.append(time.perf_counter() - t0)
+        stages = dict(cli.STAGE_SECONDS)
+    res = {"metric": "tiddit --sv --skip_assembly end to end (BAM file -> candidates table), wall seconds", "wall_s": walls[-1],
+           "first_pass_wall_s": walls[0], "stage_seconds": {k: round(v, 4) for k, v in stages.items()},
+           "config": {"workload": "BASELINE configs[3]: %d-Mb genome (24 chromosomes + chrM + 2 scaffolds), 30x 150-bp pairs, planted DEL/DUP/INV/BND at 3 per Mb; "
+                                  "%.0f MB BAM (zlib level 1, reads cut from the reference), file in the page cache" % (mb, os.path.getsize(bam) / 1e6)},
+           "bam_generation_s": t_gen, "candidates": sum(1 for l in open(out + ".candidates.tab") if not l.startswith("#"))}
+    if with_oracle:
+        import oracle
+        from oracle import cluster_oracle, signal_oracle
+        from tiddit_amd import tiddit_cluster, tiddit_stats
+        with contextlib.redirect_stdout(io.StringIO()):
+            lib = tiddit_stats.statistics(bam, fa, 5, 100000, 25000000)
+        max_ins = lib["percentile_insert_size"]
+        t0 = time.perf_counter()
+        cov, disc, split, clips, each, n_rec = signal_oracle.signal_main_file(bam, 5, max_ins, "WGS", 10000, 60, 25)
+        t_sig = time.perf_counter() - t0
+        ok = (open(out + "_tiddit/discordants_WGS.tab").read() == disc and open(out + "_tiddit/splits_WGS.tab").read() == split and
+              open(out + "_tiddit/clips_WGS.fa").read() == clips)
+        if not ok:
+            raise SystemExit("PARITY FAILURE: signal tables / clip FASTA differ from the CPU restatement")
+        names = [n for n, _ in contigs]
+        eps = int(lib["avg_insert_size"] / 2.0) or 50
+        cargs = (names, dict(contigs), ["WGS"], lib["mp"], eps, 3, max_ins, 10000, True, 3)
+        t0 = time.perf_counter()
+        want = cluster_oracle.main(out, *cargs)
+        t_cl = time.perf_counter() - t0
+        got = tiddit_cluster.main(out, *cargs)
+        if cluster_oracle.canonical(got) != cluster_oracle.canonical(want):
+            raise SystemExit("PARITY FAILURE: candidates differ from the CPU restatement")
+        from tiddit_amd import tiddit_signal
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, chroms, gcov, _, _, _ = tiddit_signal.scan_signals(bam, 5, max_ins, 10000, 60, 25, 50)
+        for c in cov:
+            if not np.array_equal(gcov[c], cov[c]):
+                raise SystemExit("PARITY FAILURE: 50-bp coverage of %s differs from the CPU restatement" % c)
+        res["records"] = int(n_rec)
+        res["records_per_sec"] = n_rec / walls[-1]
+        res["cpu_baseline"] = {"value": t_sig + t_cl, "unit": "s", "cores": 1, "kind": "port",
+                               "sample": "the same file: signal extraction + coverage %.1f s (zlib inflate, C record walk + tiddit_signal.worker chain, Python rows), "
+                                         "clustering %.1f s (C DBSCAN restatement + Python regroup); library statistics, GC and ploidy not included" % (t_sig, t_cl)}
+        res["parity_checked"] = "signal tables, clip FASTA, 50-bp coverage of every contig and the whole candidates dictionary equal the CPU restatement"
+    return res
 
 
 if __name__ == "__main__":

@@ -349,7 +349,6 @@ def signal_main_file(path, min_q, max_ins, sample_id, min_contig, min_anchor_len
     max_ins = int(max_ins)                 # `int max_ins` (:230)
     header, sq, raw = inflate_bam(path)
     f = oracle.bam_walk(raw)
-    rawb = raw.tobytes() if len(raw) < (1 << 31) else raw
     tid = f["tid"]
     chromosomes = [c["SN"] for c in sq if c["LN"] >= min_contig]
     names = [c["SN"] for c in sq]
@@ -374,7 +373,9 @@ def signal_main_file(path, min_q, max_ins, sample_id, min_contig, min_anchor_len
         clips, d, sp = [], [], []
         for k in np.flatnonzero(act & 0xe):
             a = int(act[k])
-            read, _ = parse_record(rawb, int(g["rec_off"][sel_lo + k]), sq)
+            off = int(g["rec_off"][sel_lo + k])
+            bs = int(raw[off:off + 4].view("<i4")[0])
+            read, _ = parse_record(raw[off:off + 4 + bs].tobytes(), 0, sq)
             read_chromosome, mate_chromosome = read.reference_name, read.next_reference_name
             if a & 2 and want_clips:
                 clips.append([">{}|{}|{}\n".format(read.query_name, read_chromosome, read.reference_start + 1), read.query_sequence + "\n"])

@@ -43,6 +43,7 @@ struct tdt_ctx {
     tdt_buf scratch[TDT_NSCRATCH];
     tdt_buf pinned[TDT_NPINNED];
     int *d_async_err = nullptr;  // device word kernels OR into (bounded-spin timeouts); checked by tdt_ctx_sync
+    void *tile_flags_zeroed = nullptr;   // clustering: the status block that has been zeroed once (its users re-zero it themselves)
 };
 
 int tdt_scratch(tdt_ctx *ctx, int slot, size_t bytes, void **out);

@@ -41,6 +41,7 @@ __device__ __forceinline__ int db_bucket(const int *__restrict__ boff, int nb, i
 __device__ __forceinline__ unsigned db_absdiff(unsigned a, unsigned b) { return a > b ? a - b : b - a; }
 
 #include "tdt_dbscan_fused.h"
+#include "tdt_dbscan_tile.h"
 
 // ---------------------------------------------------------------------------------------- scan
 // In-place inclusive scan of a u32 array: reduce tiles -> scan the tile sums (one block) -> apply.
@@ -435,28 +436,115 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
     unsigned *d_cpos = (unsigned *)carve(N * 4);
     unsigned *d_lflag = (unsigned *)carve(N * 4);
 
-    // bucket offsets: stage through pinned memory so the copy is truly asynchronous
-    void *h_stage = nullptr;
-    rc = tdt_pinned(ctx, 0, (size_t)(nb + 1) * 4 + 64, &h_stage);
-    if (rc) return rc;
-    TDT_HIP(hipStreamSynchronize(st));  // previous call may still be reading the pinned block
-    int *h_boff = (int *)h_stage;
-    for (int b = 0; b <= nb; b++) h_boff[b] = (int)bucket_off[b];
-    TDT_HIP(hipMemcpyAsync(d_boff, h_boff, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
-    TDT_HIP(hipMemsetAsync(d_runbase, 0, (size_t)(nb + 1) * 4, st));
-    TDT_HIP(hipMemsetAsync(d_cnt, 0, 256, st));
+    // bucket offsets: stage through pinned memory so the copy is truly asynchronous.  (Not needed by the one-bucket tile path,
+    // which therefore never waits for the stream.)
+    bool prologue_done = false;
+    auto prologue = [&]() -> int {
+        if (prologue_done) return TDT_OK;
+        prologue_done = true;
+        void *h_stage = nullptr;
+        int rc2 = tdt_pinned(ctx, 0, (size_t)(nb + 1) * 4 + 64, &h_stage);
+        if (rc2) return rc2;
+        TDT_HIP(hipStreamSynchronize(st));  // previous call may still be reading the pinned block
+        int *h_boff = (int *)h_stage;
+        for (int b = 0; b <= nb; b++) h_boff[b] = (int)bucket_off[b];
+        TDT_HIP(hipMemcpyAsync(d_boff, h_boff, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
+        TDT_HIP(hipMemsetAsync(d_runbase, 0, (size_t)(nb + 1) * 4, st));
+        TDT_HIP(hipMemsetAsync(d_cnt, 0, 256, st));
+        return TDT_OK;
+    };
 
     const int blocks1 = n ? (n + DB_THREADS - 1) / DB_THREADS : 1;
     const int blocks4 = n ? (n + DB_TILE - 1) / DB_TILE : 1;
     const int blocks_nb = (std::max(n, nb) + DB_THREADS - 1) / DB_THREADS;
     if (n == 0) {
         // empty input: every bucket reports cluster_id -1
+        rc = prologue();
+        if (rc) return rc;
         hipLaunchKernelGGL(dbx_final, dim3(blocks_nb), dim3(DB_THREADS), 0, st, (const int *)d_xlab, 0, (const int *)d_boff, nb,
                            (const unsigned *)d_runbase, d_labels, (long long *)d_last_id);
         TDT_CHECK_LAUNCH();
         return TDT_OK;
     }
     const bool fused = m <= DBF_M_MAX;
+    static const bool no_tile = getenv("TIDDIT_DBSCAN_LAUNCHES") != nullptr;     // measurement switch: the multi-launch path only
+    if (fused && !no_tile && n < 0x7fff0000) {
+        // tile-resident pass (tdt_dbscan_tile.h): three launches; falls through to the multi-launch path below when an
+        // x-cluster is too large for it
+        const int ntt = (n + DT_T - 1) / DT_T;
+        const size_t sz_flags = 256, sz_agg = db_align((size_t)ntt * 4), sz_b = db_align((size_t)(nb + 1) * 4);
+        void *tb = nullptr;
+        rc = tdt_scratch(ctx, 9, sz_flags + 2 * sz_b + 2 * sz_agg + 2 * sz_b, &tb);
+        if (rc) return rc;
+        char *q = (char *)tb;
+        unsigned *t_flags = (unsigned *)q; q += sz_flags;
+        unsigned *t_brun = (unsigned *)q; q += sz_b;
+        unsigned *t_bext = (unsigned *)q; q += sz_b;
+        unsigned *t_aggR = (unsigned *)q; q += sz_agg;
+        unsigned *t_aggE = (unsigned *)q; q += sz_agg;
+        unsigned *t_runbase = (unsigned *)q; q += sz_b;
+        unsigned *t_extbase = (unsigned *)q; q += sz_b;
+        if (nb > 1) {
+            rc = prologue();
+            if (rc) return rc;
+        }
+        if (ctx->tile_flags_zeroed != tb) {       // first use of this block; afterwards the kernel that reports the status re-zeroes it
+            TDT_HIP(hipMemsetAsync(t_flags, 0, sz_flags, st));
+            ctx->tile_flags_zeroed = tb;
+        }
+        DtParams TP;
+        TP.x = d_x;
+        TP.y = d_y;
+        TP.n = n;
+        TP.boff = d_boff;
+        TP.nb = nb;
+        TP.eps32 = eps > 0xffffffffull ? 0xffffffffu : (unsigned)eps;
+        TP.wide = eps > 0xffffffffull;
+        TP.m = m;
+        TP.lab = (unsigned long long *)d_labels;
+        TP.aggR = t_aggR;
+        TP.aggE = t_aggE;
+        TP.brun = t_brun;
+        TP.bext = t_bext;
+        TP.flags = t_flags;
+        void *hp = nullptr;
+        rc = tdt_pinned(ctx, 2, 64, &hp);
+        if (rc) return rc;
+        volatile unsigned *hw = (volatile unsigned *)hp;
+        static std::atomic<unsigned> tile_seq{0};
+        unsigned seq = ++tile_seq;
+        if (seq == 0) seq = ++tile_seq;                                    // never 0
+        hw[1] = 0;
+        if (nb == 1 && mode == 0) hipLaunchKernelGGL((dbt_tile<true, false>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
+        else if (nb == 1) hipLaunchKernelGGL((dbt_tile<true, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
+        else if (mode == 0) hipLaunchKernelGGL((dbt_tile<false, false>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
+        else hipLaunchKernelGGL((dbt_tile<false, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
+        TDT_CHECK_LAUNCH();
+        if (nb == 1) {
+            hipLaunchKernelGGL(dbt_finish1, dim3(ntt), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
+                               (const unsigned *)t_aggE, ntt, (long long *)d_last_id, t_flags, hw, seq);
+        } else {
+            hipLaunchKernelGGL(dbt_scan, dim3(1), dim3(1024), 0, st, t_aggR, t_aggE, ntt, (const int *)d_boff, nb, n, (const unsigned *)t_brun,
+                               (const unsigned *)t_bext, t_runbase, t_extbase, (long long *)d_last_id, mode, t_flags, hw, seq);
+            hipLaunchKernelGGL(dbt_finish, dim3((n + 511) / 512), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
+                               (const unsigned *)t_aggE, (const int *)d_boff, nb, (const unsigned *)t_runbase, (const unsigned *)t_extbase);
+        }
+        TDT_CHECK_LAUNCH();
+        // the one word that says whether the pass stands comes back through pinned memory (a hipStreamSynchronize wake-up costs
+        // more than the whole pass); dbt_scan stores it as soon as the tile kernel is done
+        bool seen = false;
+        for (long spin = 0; spin < 4000000; spin++) {
+            if (hw[1] == seq) {
+                seen = true;
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        if (!seen) TDT_HIP(hipStreamSynchronize(st));
+        if (hw[0] == 0) return TDT_OK;
+    }
+    rc = prologue();
+    if (rc) return rc;
     if (fused) {
         // ballot-mask tiles; cross-tile prefixes from a one-workgroup scan between launches
         const int ntf = (n + DBF_TILE - 1) / DBF_TILE;

@@ -1,0 +1,603 @@
+// Tile-resident clustering pass.  Included by tdt_dbscan.hip; used when m <= DBF_M_MAX and no x-cluster has more than
+// DB_SMALL members (the rare other cases fall back to the multi-launch path in tdt_dbscan.hip).
+//
+// The closed form of DBSCAN.py (see the header of tdt_dbscan.hip) has exactly two global dependencies: the number of
+// x-runs before a point (its x id) and, for the relabelling of sub-runs, the number of runs of the whole bucket plus the
+// number of extra sub-runs before the point (DBSCAN.py:112-122).  Everything else is local to an x-cluster, and x-clusters
+// are contiguous index ranges.  So ONE launch does all the local work with the tile in LDS:
+//
+//   dbt_tile    a workgroup stages DT_NW words (2048 points) of x and y, OWNS the x-clusters that start in all but its last two words
+//               (a cluster may run on into the two halo words: it has at most DB_SMALL = 128 members) and computes for them
+//               the window masks p (DBSCAN.py:41-51), runs / labelled masks (:52-62), the stable y order of every cluster
+//               (:76-81), the y window masks (:90-99), sub-run starts and sub-run numbers (:101-110).  Every point gets its
+//               final -1.0 or an 8-byte CODE written into the label array: (kind, owner-tile flag, tile-local index).
+//               Per tile it leaves two counts: x-runs started, extra sub-runs.
+//               (The first workgroup of the NEXT launch stores the word that tells the host whether a cluster was too large for
+//               this path into pinned memory: no extra launch, no stream synchronisation, no per-workgroup fence.)
+//   dbt_finish1 (one bucket) code -> float64 id: a workgroup per tile sums the count arrays itself (its two prefixes, the totals).
+//   dbt_scan + dbt_finish (several buckets) one workgroup scans the counts and forms the per-bucket bases and last_id; then
+//               code -> float64 id with ids restarting per bucket.
+//
+// All predicates are ballot masks (lane = point), the word-level algebra runs with lane = word, as in tdt_dbscan_fused.h.
+#pragma once
+
+#define DT_THREADS 256
+#define DT_WAVES (DT_THREADS / 64)
+#ifndef DT_NW
+#define DT_NW 32                            // staged words per tile
+#endif
+#define DT_OW (DT_NW - 2)                   // owned words: clusters starting here are this tile's
+#define DT_S (DT_NW * 64)                   // 4096 staged positions
+#define DT_T (DT_OW * 64)                   // 3968 owned positions
+#define DT_WPW (DT_NW / DT_WAVES)           // words per wave
+#define DT_XS (DT_S + 64 + DBF_M_MAX + 8)   // x staged for [t0-64, t0+S+m+...)
+#define DT_CODE_PREV (1ull << 62)           // the position belongs to the NEXT tile's range: its owner is tile(position) - 1
+#define DT_CODE_EXTRA (1ull << 61)          // index counts extra sub-run starts (else: x-run index)
+#define DT_MINUS1 0xbff0000000000000ull     // bits of -1.0
+
+struct DtParams {
+    const unsigned *x, *y;
+    int n;
+    const int *boff;
+    int nb;
+    unsigned eps32;
+    int wide;                 // eps > 2^32-1: every 32-bit distance qualifies
+    int m;
+    unsigned long long *lab;  // n words: codes or -1.0
+    unsigned *aggR, *aggE;    // per tile: x-runs started in the owned words, extra sub-run starts of the owned clusters
+    unsigned *brun, *bext;    // per bucket whose first point lies in the tile: the two counts in front of that point
+    unsigned *flags;          // [0] != 0: some x-cluster is too large for this path
+};
+
+// the kernel that follows the tile kernel tells the host whether the pass stands (no extra launch, no stream synchronisation)
+__device__ __forceinline__ void dt_signal_host(unsigned *flags, volatile unsigned *host, unsigned seq) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && host) {
+        host[0] = flags[0];
+        flags[0] = 0;                      // ready for the next call (nothing else touches it before the next tile kernel)
+        __threadfence_system();
+        host[1] = seq;
+    }
+}
+
+// bits [pos+1, pos+cnt] of the bit stream formed by words w0 (holding pos), w1, w2; 1 <= cnt <= 64
+__device__ __forceinline__ ull dt_bits_after(ull w0, ull w1, ull w2, int bit, int cnt) {
+    // stream position of bit+1 inside w0; shifts by 64 are avoided by splitting
+    const int s = bit + 1;                                  // 1..64
+    ull v = s < 64 ? (w0 >> s) | (w1 << (64 - s)) : w1;
+    (void)w2;
+    return cnt >= 64 ? v : v & ((1ull << cnt) - 1ull);
+}
+
+template <bool ONE_BUCKET, bool XONLY>
+__global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
+    __shared__ __attribute__((aligned(16))) unsigned xs[DT_XS];        // x, later the y values in sorted order
+    __shared__ __attribute__((aligned(16))) unsigned yv[DT_S];
+    __shared__ unsigned short ordl[DT_S], segA[DT_S], segE[DT_S];
+    __shared__ ull PM[DT_NW + 2], ST[DT_NW], FM[DT_NW], TL[DT_NW], PY[DT_NW + 1], SY[DT_NW], FY[DT_NW], EB[DT_NW], BM[DT_NW + 3];
+    __shared__ unsigned runBase[DT_NW + 1], extBase[DT_NW + 1];
+    __shared__ unsigned s_owned, s_b0, s_b1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int n = P.n, m = P.m;
+    const int t0 = tile * DT_T;          // the host takes this path only for n < 2^31 - 2^16: int arithmetic cannot overflow
+    const int sh0 = t0 - 64;
+    unsigned *ysrt = xs;
+
+    // ---- stage x [t0-64, ...) and y [t0, t0+S) with 16-byte loads, zero outside the array
+    {
+        constexpr int NCX = (DT_XS / 4 + DT_THREADS - 1) / DT_THREADS;
+        uint4 v[NCX];
+#pragma unroll
+        for (int k = 0; k < NCX; k++) {
+            const int c = tid + k * DT_THREADS;
+            const int g = sh0 + 4 * c;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (c < DT_XS / 4) {
+                if (g >= 0 && g + 4 <= n) v[k] = *reinterpret_cast<const uint4 *>(P.x + g);
+                else {
+                    v[k].x = (g >= 0 && g < n) ? P.x[g] : 0u;
+                    v[k].y = (g + 1 >= 0 && g + 1 < n) ? P.x[g + 1] : 0u;
+                    v[k].z = (g + 2 >= 0 && g + 2 < n) ? P.x[g + 2] : 0u;
+                    v[k].w = (g + 3 >= 0 && g + 3 < n) ? P.x[g + 3] : 0u;
+                }
+            }
+        }
+        uint4 w[DT_S / 4 / DT_THREADS];
+        if (!XONLY) {
+#pragma unroll
+            for (int k = 0; k < DT_S / 4 / DT_THREADS; k++) {
+                const int c = tid + k * DT_THREADS;
+                const int g = t0 + 4 * c;
+                w[k] = make_uint4(0, 0, 0, 0);
+                if (g + 4 <= n) w[k] = *reinterpret_cast<const uint4 *>(P.y + g);
+                else {
+                    w[k].x = g < n ? P.y[g] : 0u;
+                    w[k].y = g + 1 < n ? P.y[g + 1] : 0u;
+                    w[k].z = g + 2 < n ? P.y[g + 2] : 0u;
+                    w[k].w = g + 3 < n ? P.y[g + 3] : 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCX; k++) {
+            const int c = tid + k * DT_THREADS;
+            if (c < DT_XS / 4) *reinterpret_cast<uint4 *>(xs + 4 * c) = v[k];
+        }
+        if (!XONLY) {
+#pragma unroll
+            for (int k = 0; k < DT_S / 4 / DT_THREADS; k++) *reinterpret_cast<uint4 *>(yv + 4 * (tid + k * DT_THREADS)) = w[k];
+        }
+    }
+    // bucket boundaries (first points of buckets, and n) inside [t0-64, t0+S+128) as a bit stream: BM word k covers
+    // positions [t0-64+64k, ...)
+    if (!ONE_BUCKET) {
+        if (tid < DT_NW + 3) BM[tid] = 0;
+        if (tid == 0) {
+            int lo = 0, hi = P.nb;                 // first boundary index with boff[b] >= sh0
+            if (P.boff[0] >= sh0) hi = 0;
+            else {
+                while (hi - lo > 1) {              // boff[lo] < sh0 <= boff[hi]  (boff[nb] = n; a tile exists only for t0 < n)
+                    const int mid = (lo + hi) >> 1;
+                    if (P.boff[mid] < sh0) lo = mid;
+                    else hi = mid;
+                }
+            }
+            int b1 = hi;
+            while (b1 <= P.nb && P.boff[b1] < sh0 + 64 * (DT_NW + 3)) b1++;
+            s_b0 = (unsigned)hi;
+            s_b1 = (unsigned)b1;
+        }
+        __syncthreads();
+        for (unsigned b = s_b0 + tid; b < s_b1; b += DT_THREADS) {
+            const int off = P.boff[b] - sh0;
+            atomicOr(&BM[off >> 6], 1ull << (off & 63));
+        }
+    }
+    __syncthreads();
+
+    // ---- x pass: p words -1 .. NW-1   (PM[1 + W]; PM[0] = the word before the tile)
+    auto p_word = [&](int W) -> ull {
+        const int i = t0 + 64 * W + lane;                     // global index
+        const int o = 64 * W + lane + 64;                     // xs index
+        const unsigned xi = xs[o];
+        bool p;
+        if (ONE_BUCKET) {
+            const int cnt = min(i + m, n - 1) - i;                // window members (data[i+1:i+m+1] truncated at the end, :43)
+            unsigned maxd = 0;
+            if (m <= 4) {
+                const unsigned v1 = xs[o + 1], v2 = xs[o + 2], v3 = xs[o + 3], v4 = xs[o + 4];
+                maxd = db_absdiff(v1, xi);
+                maxd = cnt >= 2 ? max(maxd, db_absdiff(v2, xi)) : maxd;
+                maxd = cnt >= 3 ? max(maxd, db_absdiff(v3, xi)) : maxd;
+                maxd = cnt >= 4 ? max(maxd, db_absdiff(v4, xi)) : maxd;
+            } else {
+                for (int q = 1; q <= m; q++) maxd = q <= cnt ? max(maxd, db_absdiff(xs[o + q], xi)) : maxd;
+            }
+            p = i >= 0 && i + m <= n && (P.wide || maxd < P.eps32);              // i <= n-m (:39)
+        } else {
+            // boundaries at positions i+1 .. i+m: one among the first m-1 ends the bucket inside the window (no p); one at
+            // i+m exactly truncates the window by one member
+            const int k = (64 * W + lane + 64) >> 6, bit = (64 * W + lane + 64) & 63;
+            const ull nb_bits = dt_bits_after(BM[k], BM[k + 1], 0, bit, m);
+            const bool cut = (nb_bits & ((1ull << (m - 1)) - 1ull)) != 0;
+            const int cnt = m - (int)((nb_bits >> (m - 1)) & 1ull);
+            unsigned maxd = 0;
+            for (int q = 1; q <= m; q++) maxd = q <= cnt ? max(maxd, db_absdiff(xs[o + q], xi)) : maxd;
+            p = i >= 0 && i < n && !cut && (P.wide || maxd < P.eps32);
+        }
+        return __ballot(p);
+    };
+#pragma unroll 4
+    for (int s = 0; s < DT_WPW; s++) {
+        const int W = wave * DT_WPW + s;
+        const ull w = p_word(W);
+        if (lane == 0) PM[1 + W] = w;
+    }
+    if (wave == 0) {
+        const ull w = p_word(-1);
+        if (lane == 0) PM[0] = w;
+    }
+    __syncthreads();
+
+    // ---- lane = word: run starts, labelled mask, cluster tails; counts of starts before every word
+    if (wave == 0) {
+        const int W = lane;
+        const bool act = W < DT_NW;
+        const ull cur = act ? PM[1 + W] : 0ull, prev = act ? PM[W] : 0ull;
+        const int g0 = t0 + 64 * W;
+        const ull valid = g0 >= n ? 0ull : (n - g0 >= 64 ? ~0ull : dbf_lt(n - g0));
+        const ull st = cur & ~((cur << 1) | (prev >> 63));                 // a run starts: p and not p before (:52-57)
+        const ull f = dbf_smear(cur, prev, m) & valid;                     // label != -1: some p in [i-m+1, i]  (:58-62)
+        // f / st of the next word's first position (the last word's cluster is closed by force: a cluster reaching the end of
+        // the staged range has more than DB_SMALL members, since it started in the owned words)
+        ull fnx = __shfl_down(f, 1), snx = __shfl_down(st, 1);
+        if (W == DT_NW - 1) { fnx = 0; snx = 0; }
+        const ull fn = (f >> 1) | (fnx << 63), sn = (st >> 1) | (snx << 63);
+        const ull tl = f & ~(fn & ~sn);                                    // last member: the next point is unlabelled or starts a run
+        if (act) {
+            ST[W] = st;
+            FM[W] = f;
+            TL[W] = tl;
+        }
+        unsigned c = (unsigned)dbf_popc(st), incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (act) runBase[W] = incl - c;
+        const unsigned owned = __shfl(incl, DT_OW - 1);
+        if (lane == 0) {
+            s_owned = owned;
+            P.aggR[tile] = owned;
+        }
+    }
+    __syncthreads();
+    const unsigned n_owned = s_owned;
+
+    // ---- lane = point: cluster ids and extents.  cid = index (1-based) of the point's cluster among the runs started in the
+    // staged range; 1..n_owned are this tile's.  Packed per point for the later steps: cid << 1 | labelled.
+    unsigned info[DT_WPW];
+#pragma unroll
+    for (int s = 0; s < DT_WPW; s++) {
+        const int W = wave * DT_WPW + s;
+        const int q = 64 * W + lane;
+        const ull st = dbf_uni(ST[W]), f = dbf_uni(FM[W]), tl = dbf_uni(TL[W]);
+        const unsigned cid = runBase[W] + dbf_cnt_le(st, lane);
+        const bool lab = (f >> lane) & 1ull;
+        const bool mine = lab && cid >= 1 && cid <= n_owned;
+        info[s] = mine ? (cid << 1 | 1u) : 0u;
+        if (mine && ((st >> lane) & 1ull)) segA[cid - 1] = (unsigned short)q;
+        if (mine && ((tl >> lane) & 1ull)) segE[cid - 1] = (unsigned short)(q + 1);
+        if (XONLY) {
+            if (mine && q == DT_S - 1) atomicOr(P.flags, 1u);     // the cluster may run past the staged range: not this path's case
+            const int g = t0 + q;
+            if (g < n) {
+                if (mine) P.lab[g] = (q >= DT_T ? DT_CODE_PREV : 0ull) | (ull)(cid - 1);
+                else if (!lab && q < DT_T) P.lab[g] = DT_MINUS1;
+            }
+        }
+    }
+    if (XONLY) {
+        if (!ONE_BUCKET) {
+            for (unsigned b = s_b0 + tid; b < s_b1; b += DT_THREADS) {
+                const int off = P.boff[b] - t0;
+                if (off >= 0 && off < DT_T && P.boff[b] < n) {
+                    const int W = off >> 6, bit = off & 63;
+                    P.brun[b] = runBase[W] + (unsigned)dbf_popc(ST[W] & dbf_lt(bit));
+                    P.bext[b] = 0;
+                }
+            }
+        }
+        if (tid == 0) P.aggE[tile] = 0;
+        return;
+    }
+    __syncthreads();
+
+#ifdef DT_ABL_STOP_AFTER_X
+    if (segA[tid] == 0x1234u) P.lab[tid] = 1;
+    return;
+#endif
+    // ---- stable y order inside every owned cluster (:76-81): rank = members sorting before the point
+    unsigned ext[DT_WPW];      // a | e << 16 of the point's cluster (0: not a member of an owned small cluster)
+    bool large = false;
+#pragma unroll
+    for (int s = 0; s < DT_WPW; s++) {
+        ext[s] = 0;
+        if (info[s]) {
+            const unsigned cid = info[s] >> 1;
+            const int a = segA[cid - 1], e = segE[cid - 1];
+            if (e - a > DB_SMALL) large = true;
+            else ext[s] = (unsigned)a | ((unsigned)e << 16);
+        }
+    }
+    __syncthreads();           // every x read is done: xs becomes ysrt
+#pragma unroll
+    for (int s = 0; s < DT_WPW; s++) {
+        const int W = wave * DT_WPW + s;
+        const int q = 64 * W + lane;
+        if (ext[s]) {
+            const int a = ext[s] & 0xffff, e = ext[s] >> 16;
+            const unsigned yq = yv[q];
+            int rank = 0;
+#ifdef DT_ABL_NORANK
+            rank = q - a;
+            if (false)
+#endif
+            // 8 members per trip: clamped, independent LDS loads (a cluster of the usual size is done in one trip; the wave runs
+            // as long as its largest cluster)
+            for (int j0 = a; j0 < e; j0 += 8) {
+                unsigned v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = yv[min(j0 + k, e - 1)];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int j = j0 + k;
+                    rank += (j < e) && ((v[k] < yq) || (v[k] == yq && j < q));
+                }
+            }
+            ysrt[a + rank] = yq;
+            ordl[a + rank] = (unsigned short)q;
+        }
+    }
+    if (large) atomicOr(P.flags, 1u);
+    __syncthreads();
+
+#ifdef DT_ABL_STOP_AFTER_RANK
+    if (ysrt[tid] == 0x12345u) P.lab[tid] = 1;
+    return;
+#endif
+    // ---- y pass on the sorted values: window test with m-1 following members (:90-99)
+#pragma unroll
+    for (int s = 0; s < DT_WPW; s++) {
+        const int W = wave * DT_WPW + s;
+        const int q = 64 * W + lane;
+        bool py = false;
+        if (ext[s]) {
+            const int e = ext[s] >> 16;
+            if (q + m <= e) py = P.wide || (ysrt[q + m - 1] - ysrt[q] < P.eps32);
+        }
+        const ull w = __ballot(py);
+        if (lane == 0) PY[1 + W] = w;
+    }
+    if (tid == 0) PY[0] = 0;
+    __syncthreads();
+    if (wave == 0) {   // lane = word: sub-run starts (a cluster head always starts one), labelled mask, starts before every word
+        const int W = lane;
+        ull sy = 0;
+        if (W < DT_NW) {
+            const ull cur = PY[1 + W], prev = PY[W], h = ST[W];
+            sy = cur & (h | ~((cur << 1) | (prev >> 63)));
+            SY[W] = sy;
+            FY[W] = dbf_smear(cur, prev, m);
+        }
+        const unsigned c = (unsigned)dbf_popc(sy);
+        unsigned incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (W < DT_NW) extBase[W] = incl - c;      // (the array holds the extra-start counts later)
+    }
+    __syncthreads();
+    // sub-run number of a member = sub-run starts in [a, q] = starts up to q minus starts before the cluster's head, which the
+    // head publishes; a start that is not the first of its cluster is an EXTRA (:112-122)
+    unsigned short *cHead = segA;                  // the cluster extents live in registers by now
+    unsigned sub[DT_WPW];
+#pragma unroll
+    for (int s = 0; s < DT_WPW; s++) {
+        const int W = wave * DT_WPW + s;
+        const int q = 64 * W + lane;
+        const ull sy = dbf_uni(SY[W]);
+        sub[s] = extBase[W] + dbf_cnt_le(sy, lane);
+        if (ext[s] && (int)(ext[s] & 0xffff) == q) cHead[(info[s] >> 1) - 1] = (unsigned short)(sub[s] - (unsigned)((sy >> lane) & 1ull));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DT_WPW; s++) {
+        const int W = wave * DT_WPW + s;
+        bool extra = false;
+        if (ext[s]) {
+            sub[s] -= cHead[(info[s] >> 1) - 1];
+            extra = ((SY[W] >> lane) & 1ull) && sub[s] >= 2;
+        }
+        const ull w = __ballot(extra);
+        if (lane == 0) EB[W] = w;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned c = lane < DT_NW ? (unsigned)dbf_popc(EB[lane]) : 0u;
+        unsigned incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane < DT_NW) extBase[lane] = incl - c;
+        if (lane == 63) P.aggE[tile] = incl;
+    }
+    __syncthreads();
+
+    // ---- results: -1.0 or a code, written at the member's ORIGINAL position (labels come back in input order)
+#pragma unroll
+    for (int s = 0; s < DT_WPW; s++) {
+        const int W = wave * DT_WPW + s;
+        const int q = 64 * W + lane;
+        if (ext[s]) {
+            const unsigned dq = ordl[q];                       // the point sorted to position q
+            const int g = t0 + (int)dq;
+            ull code = DT_MINUS1;
+            if ((FY[W] >> lane) & 1ull) {
+                const ull prevf = dq >= DT_T ? DT_CODE_PREV : 0ull;
+                if (sub[s] == 1) code = prevf | (ull)((info[s] >> 1) - 1u);                       // sub-run 1 keeps the x id
+                else code = prevf | DT_CODE_EXTRA | (ull)(extBase[W] + dbf_cnt_le(EB[W], lane));  // k-th extra start of the bucket
+            }
+            P.lab[g] = code;
+        } else if (!info[s] && q < DT_T && t0 + q < n && !((FM[W] >> lane) & 1ull)) {
+            P.lab[t0 + q] = DT_MINUS1;                          // not in any x-cluster
+        }
+    }
+    if (!ONE_BUCKET) {
+        for (unsigned b = s_b0 + tid; b < s_b1; b += DT_THREADS) {
+            const int off = P.boff[b] - t0;
+            if (off >= 0 && off < DT_T && P.boff[b] < n) {
+                const int W = off >> 6, bit = off & 63;
+                P.brun[b] = runBase[W] + (unsigned)dbf_popc(ST[W] & dbf_lt(bit));
+                P.bext[b] = extBase[W] + (unsigned)dbf_popc(EB[W] & dbf_lt(bit));
+            }
+        }
+    }
+}
+
+// exclusive scans of the per-tile counts; bases of every bucket; last_id; the host's status word
+__global__ __launch_bounds__(1024) void dbt_scan(unsigned *aggR, unsigned *aggE, int nt, const int *__restrict__ boff, int nb, int n,
+                                                 const unsigned *__restrict__ brun, const unsigned *__restrict__ bext,
+                                                 unsigned *__restrict__ runbase, unsigned *__restrict__ extbase, long long *__restrict__ last_id,
+                                                 int xonly, unsigned *__restrict__ flags, volatile unsigned *host, unsigned seq) {
+    __shared__ unsigned wr[16], we[16], cr, ce;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dt_signal_host(flags, host, seq);
+    if (tid == 0) {
+        cr = 0;
+        ce = 0;
+    }
+    __syncthreads();
+    for (int base = 0; base < nt; base += 1024) {
+        const int i = base + tid;
+        const unsigned r = i < nt ? aggR[i] : 0u, e = i < nt ? aggE[i] : 0u;
+        unsigned sr = r, se = e;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned a = __shfl_up(sr, d), b = __shfl_up(se, d);
+            if (lane >= d) {
+                sr += a;
+                se += b;
+            }
+        }
+        if (lane == 63) {
+            wr[wave] = sr;
+            we[wave] = se;
+        }
+        __syncthreads();
+        unsigned or_ = cr, oe = ce;
+        for (int w = 0; w < wave; w++) {
+            or_ += wr[w];
+            oe += we[w];
+        }
+        if (i < nt) {
+            aggR[i] = or_ + sr - r;
+            aggE[i] = oe + se - e;
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            cr = or_ + sr;
+            ce = oe + se;
+        }
+        __syncthreads();
+    }
+    const unsigned totR = cr, totE = ce;
+    for (int b = tid; b <= nb; b += 1024) {
+        const int s = boff[b];
+        unsigned rb = totR, eb = totE;
+        if (s < n) {
+            const int t = s / DT_T;
+            rb = aggR[t] + brun[b];
+            eb = aggE[t] + bext[b];
+        }
+        runbase[b] = rb;
+        extbase[b] = eb;
+    }
+    __syncthreads();
+    if (last_id)
+        for (int b = tid; b < nb; b += 1024)
+            last_id[b] = (long long)(runbase[b + 1] - runbase[b]) - 1 + (xonly ? 0ll : (long long)(extbase[b + 1] - extbase[b]));
+}
+
+__global__ __launch_bounds__(256) void dbt_finish(unsigned long long *__restrict__ lab, int n, const unsigned *__restrict__ preR,
+                                                  const unsigned *__restrict__ preE, const int *__restrict__ boff, int nb,
+                                                  const unsigned *__restrict__ runbase, const unsigned *__restrict__ extbase) {
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i0 >= n) return;
+    ull w[2];
+    const bool two = i0 + 2 <= n && (((size_t)lab) & 15) == 0;
+    if (!two && i0 + 1 < n) {          // unaligned label array: element-wise
+        for (int k = 0; k < 2; k++) {
+            const int i = i0 + k;
+            const ull c = lab[i];
+            if (c >> 63) continue;
+            const int t = i / DT_T - (int)((c >> 62) & 1ull);
+            const int b = db_bucket(boff, nb, i);
+            const unsigned rb = runbase[b];
+            const double id = (c & DT_CODE_EXTRA) ? (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + (unsigned)c - extbase[b]))
+                                                  : (double)(preR[t] + (unsigned)c - rb);
+            lab[i] = (ull)__double_as_longlong(id);
+        }
+        return;
+    }
+    if (two) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lab + i0);
+        w[0] = v.x;
+        w[1] = v.y;
+    } else {
+        w[0] = lab[i0];
+        w[1] = DT_MINUS1;
+    }
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (w[k] >> 63) continue;                                  // -1.0 stays
+        const int i = i0 + k;
+        const int t = i / DT_T - (int)((w[k] >> 62) & 1ull);
+        const unsigned v = (unsigned)w[k];
+        const int b = db_bucket(boff, nb, i);
+        const unsigned rb = runbase[b];
+        double id;
+        if (w[k] & DT_CODE_EXTRA) id = (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + v - extbase[b]));
+        else id = (double)(preR[t] + v - rb);
+        w[k] = (ull)__double_as_longlong(id);
+        any = true;
+    }
+    if (!any) return;
+    if (two) *reinterpret_cast<ulonglong2 *>(lab + i0) = make_ulonglong2(w[0], w[1]);
+    else lab[i0] = w[0];
+}
+
+// one bucket: no scan launch — every workgroup sums the per-tile counts it needs (those before its tile, and all of them)
+__global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restrict__ lab, int n, const unsigned *__restrict__ aggR,
+                                                   const unsigned *__restrict__ aggE, int nt, long long *__restrict__ last_id,
+                                                   unsigned *__restrict__ flags, volatile unsigned *host, unsigned seq) {
+    __shared__ unsigned red[4][6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dt_signal_host(flags, host, seq);
+    const int tile = blockIdx.x;
+    // A: tiles < tile-1, B: tile-1, T: all
+    unsigned rA = 0, rB = 0, rT = 0, eA = 0, eB = 0, eT = 0;
+    for (int i = tid; i < nt; i += 256) {
+        const unsigned r = aggR[i], e = aggE[i];
+        rT += r;
+        eT += e;
+        if (i < tile - 1) { rA += r; eA += e; }
+        if (i == tile - 1) { rB = r; eB = e; }
+    }
+    unsigned v[6] = {rA, rB, rT, eA, eB, eT};
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        for (int d = 32; d > 0; d >>= 1) v[k] += __shfl_xor(v[k], d);
+        if (lane == 0) red[wave][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    const unsigned preR[2] = {v[0], v[0] + v[1]}, preE[2] = {v[3], v[3] + v[4]};     // [0]: the previous tile's, [1]: this tile's
+    const long long R1 = (long long)v[2] - 1;
+    if (tile == 0 && tid == 0 && last_id) last_id[0] = R1 + (long long)v[5];
+    const int i0 = tile * DT_T;
+    const bool al = (((size_t)lab) & 15) == 0;
+    for (int o = tid * 2; o < DT_T; o += 512) {
+        const int i = i0 + o;
+        if (i >= n) break;
+        ull w[2];
+        const bool two = al && i + 2 <= n;
+        if (two) {
+            const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(lab + i);
+            w[0] = q.x;
+            w[1] = q.y;
+        } else {
+            w[0] = lab[i];
+            w[1] = i + 1 < n ? lab[i + 1] : DT_MINUS1;
+        }
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (w[k] >> 63) continue;                                  // -1.0 stays
+            const int sel = 1 - (int)((w[k] >> 62) & 1ull);
+            const unsigned c = (unsigned)w[k];
+            const double id = (w[k] & DT_CODE_EXTRA) ? (double)(R1 + (long long)(preE[sel] + c)) : (double)(preR[sel] + c);
+            w[k] = (ull)__double_as_longlong(id);
+            any = true;
+        }
+        if (!any) continue;
+        if (two) *reinterpret_cast<ulonglong2 *>(lab + i) = make_ulonglong2(w[0], w[1]);
+        else {
+            lab[i] = w[0];
+            if (i + 1 < n) lab[i + 1] = w[1];
+        }
+    }
+}
