@@ -7,7 +7,7 @@ HBM when the timed region starts:
     30x 150-bp coordinate-sorted alignment stream (600 M reads), 500-bp bins, --cov read filter
     (q 20): reset accumulators -> ONE cov_accumulate launch over all 24 contigs -> ONE int64->float64 pass;
   * clustering (reported under "dbscan"): BASELINE configs[2] — gen_points(5_000_000), one chr pair,
-    e=500 l=3, x pass + y pass (16 launches); with N>1 ranks every rank clusters its own bucket and
+    e=500 l=3, x pass + y pass (two launches); with N>1 ranks every rank clusters its own bucket and
     the label arrays are all-gathered over RCCL.
 Weak scaling: every rank owns a full-size shard (its own sample's stream / bucket).
 
@@ -313,7 +313,7 @@ def main():
                  "ms_per_step": 1e3 * t_db / args.steps,
                  "config": {"workload": "BASELINE configs[2]: gen_points(%d) one chr pair, e=500 l=3, per GPU%s"
                                         % (n, "; int32 labels all-gathered over RCCL" if world > 1 else "")},
-                 "roofline": {"bound": "hbm", "kernel": "tdt_dbscan_device (16 launches)", "achieved": db_ach, "peak": HBM_PEAK_GBS,
+                 "roofline": {"bound": "hbm", "kernel": "tdt_dbscan_device: dbt_tile + dbt_finish1 (2 launches)", "achieved": db_ach, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": db_ach / HBM_PEAK_GBS, "traffic": None, "avg_pass_ms": k_ms,
                               "algorithmic_bytes_per_pass": 16.0 * n}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -333,6 +333,56 @@ def main():
                                                        "sample": "first %d points, literal `clusters == cluster` mask per x-cluster "
                                                                  "(DBSCAN.py:72) in C" % ns}}
             dbres["parity_checked"] = True
+        # tiddit_cluster.main's call (tiddit_cluster.pyx:140-154): host int64 (posA, posB) of every (chrA,chrB) bucket in signal order ->
+        # stable sort by posA + DBSCAN.main per bucket, labels back on the host.  Wall clock of the synchronous C call.
+        if rank == 0:
+            def time_sort_dbscan(posA, posB, off):
+                nn = len(posA)
+                perm = np.empty(nn, dtype=np.uint32)
+                labs = np.empty(nn, dtype=np.float64)
+                ts = []
+                for _ in range(1 + max(3, min(args.steps, 10))):
+                    t1 = time.perf_counter()
+                    _native.check(ctx.lib.tdt_sort_dbscan(ctx.handle, _native.ptr(posA), _native.ptr(posB), nn, _native.ptr(off), len(off) - 1,
+                                                          500.0, 3, _native.ptr(perm), _native.ptr(labs)))
+                    ts.append(time.perf_counter() - t1)
+                return sorted(ts[1:])[len(ts[1:]) // 2], perm, labs
+            by_signal = pts[np.argsort(pts[:, 2], kind="stable")]                   # arrival order, as the .tab files list the signals
+            pa, pb = np.ascontiguousarray(by_signal[:, 0]), np.ascontiguousarray(by_signal[:, 1])
+            t_one, perm1, lab1 = time_sort_dbscan(pa, pb, np.array([0, n], dtype=np.int64))
+            # ~300 buckets shaped like a human WGS run: 24 intra-chromosomal buckets hold most signals, 276 inter-chromosomal ones the rest
+            rng = np.random.default_rng(99)
+            w_in = np.array([248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57], dtype=np.float64)
+            sizes = np.concatenate([(0.85 * n * w_in / w_in.sum()).astype(np.int64), (0.15 * n * rng.dirichlet(np.ones(276) * 0.7)).astype(np.int64)])
+            order = rng.permutation(len(sizes))
+            sizes = sizes[order]
+            offm = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+            nm = int(offm[-1])
+            pam, pbm = pa[:nm].copy(), pb[:nm].copy()
+            t_many, permm, labm = time_sort_dbscan(pam, pbm, offm)
+            sres = {"metric": "tdt_sort_dbscan from host int64 columns (what tiddit_cluster.main calls), signals/sec",
+                    "one_bucket": {"signals": n, "ms": 1e3 * t_one, "value": n / t_one},
+                    "many_buckets": {"signals": nm, "buckets": int(len(sizes)), "largest_bucket": int(sizes.max()), "ms": 1e3 * t_many, "value": nm / t_many},
+                    "unit": "signals/s", "note": "includes the H2D copy of 16 B/signal, the device radix sort by (bucket, posA), both clustering passes and the D2H copy of 12 B/signal"}
+            if world == 1 and not args.no_cpu_baseline:
+                import oracle
+                o1 = np.argsort(pa, kind="stable")
+                w1 = oracle.dbscan_main(np.stack([pa[o1], pb[o1], o1], 1).astype(np.int64), 500, 3)
+                if not (np.array_equal(perm1, o1.astype(np.uint32)) and np.array_equal(lab1, w1)):
+                    raise SystemExit("PARITY FAILURE: tdt_sort_dbscan (one bucket) differs from stable argsort + the CPU oracle")
+                t1 = time.perf_counter()
+                for b in range(len(sizes)):
+                    lo, hi = int(offm[b]), int(offm[b + 1])
+                    if hi == lo:
+                        continue
+                    ob = np.argsort(pam[lo:hi], kind="stable")
+                    wb = oracle.dbscan_main(np.stack([pam[lo:hi][ob], pbm[lo:hi][ob], ob], 1).astype(np.int64), 500, 3)
+                    if not (np.array_equal(permm[lo:hi], (ob + lo).astype(np.uint32)) and np.array_equal(labm[lo:hi], wb)):
+                        raise SystemExit("PARITY FAILURE: tdt_sort_dbscan bucket %d differs from stable argsort + the CPU oracle" % b)
+                sres["cpu_baseline"] = {"value": nm / (time.perf_counter() - t1), "unit": "signals/s", "cores": 1, "kind": "port",
+                                        "sample": "the same %d buckets: numpy stable argsort + oracle C DBSCAN per bucket" % len(sizes)}
+                sres["parity_checked"] = True
+            dbres["sort_dbscan"] = sres
         result["dbscan"] = dbres
 
     # ---------------------------------------------------------------- GC / N-mask histogram (50-bp bins, cutoff 0.5)

@@ -43,6 +43,8 @@ struct tdt_ctx {
     tdt_buf scratch[TDT_NSCRATCH];
     tdt_buf pinned[TDT_NPINNED];
     int *d_async_err = nullptr;  // device word kernels OR into (bounded-spin timeouts); checked by tdt_ctx_sync
+    unsigned tile_calls = 0;             // clustering: parity selects one of two group-sum arrays
+    int tile_groups_max = 0;             // ... and how many of their entries have ever been used
     void *tile_flags_zeroed = nullptr;   // clustering: the status block that has been zeroed once (its users re-zero it themselves)
 };
 

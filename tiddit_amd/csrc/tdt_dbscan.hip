@@ -14,6 +14,7 @@
 #include "tdt_common.h"
 
 #include <atomic>
+#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -474,10 +475,17 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         const int ntt = (n + DT_T - 1) / DT_T;
         const size_t sz_flags = 256, sz_agg = db_align((size_t)ntt * 4), sz_b = db_align((size_t)(nb + 1) * 4);
         void *tb = nullptr;
-        rc = tdt_scratch(ctx, 9, sz_flags + 2 * sz_b + 2 * sz_agg + 2 * sz_b, &tb);
+        const size_t sz_grp = db_align((size_t)2 * DT_GRPMAX * 4);
+        // the status block and the two group-sum arrays keep their contents from call to call: their own fixed-size allocation
+        void *ts = nullptr;
+        rc = tdt_scratch(ctx, 20, sz_flags + 2 * sz_grp, &ts);
+        if (rc) return rc;
+        unsigned *t_flags = (unsigned *)ts;
+        unsigned *t_grp0 = (unsigned *)((char *)ts + sz_flags);
+        unsigned *t_grp1 = (unsigned *)((char *)ts + sz_flags + sz_grp);
+        rc = tdt_scratch(ctx, 21, 4 * sz_b + 2 * sz_agg, &tb);
         if (rc) return rc;
         char *q = (char *)tb;
-        unsigned *t_flags = (unsigned *)q; q += sz_flags;
         unsigned *t_brun = (unsigned *)q; q += sz_b;
         unsigned *t_bext = (unsigned *)q; q += sz_b;
         unsigned *t_aggR = (unsigned *)q; q += sz_agg;
@@ -488,9 +496,10 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
             rc = prologue();
             if (rc) return rc;
         }
-        if (ctx->tile_flags_zeroed != tb) {       // first use of this block; afterwards the kernel that reports the status re-zeroes it
+        if (ctx->tile_flags_zeroed != ts) {       // first use of this block; afterwards the kernel that reports the status re-zeroes it
             TDT_HIP(hipMemsetAsync(t_flags, 0, sz_flags, st));
-            ctx->tile_flags_zeroed = tb;
+            TDT_HIP(hipMemsetAsync(t_grp0, 0, 2 * sz_grp, st));
+            ctx->tile_flags_zeroed = ts;
         }
         DtParams TP;
         TP.x = d_x;
@@ -507,6 +516,8 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         TP.brun = t_brun;
         TP.bext = t_bext;
         TP.flags = t_flags;
+        const bool odd = nb == 1 && (ctx->tile_calls++ & 1u) != 0;     // (only the one-bucket kernels touch the group sums)
+        TP.grp = odd ? t_grp1 : t_grp0;
         void *hp = nullptr;
         rc = tdt_pinned(ctx, 2, 64, &hp);
         if (rc) return rc;
@@ -521,8 +532,9 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         else hipLaunchKernelGGL((dbt_tile<false, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
         TDT_CHECK_LAUNCH();
         if (nb == 1) {
+            ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
             hipLaunchKernelGGL(dbt_finish1, dim3(ntt), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
-                               (const unsigned *)t_aggE, ntt, (long long *)d_last_id, t_flags, hw, seq);
+                               (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, t_flags, hw, seq);
         } else {
             hipLaunchKernelGGL(dbt_scan, dim3(1), dim3(1024), 0, st, t_aggR, t_aggE, ntt, (const int *)d_boff, nb, n, (const unsigned *)t_brun,
                                (const unsigned *)t_bext, t_runbase, t_extbase, (long long *)d_last_id, mode, t_flags, hw, seq);
@@ -777,20 +789,34 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     }
     if (n == 0) return TDT_OK;
     TDT_HIP(hipSetDevice(ctx->device));
-    int64_t amin = posA[0], amax = posA[0], bmin = posB[0], bmax = posB[0];
-    for (size_t i = 0; i < n; i++) {
-        amin = std::min(amin, posA[i]);
-        amax = std::max(amax, posA[i]);
-        bmin = std::min(bmin, posB[i]);
-        bmax = std::max(bmax, posB[i]);
-    }
+    // column ranges and the 32-bit offsets: host passes over n elements, spread over the host threads
+    const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)tdt_host_thread_count(), n / (1u << 16) + 1));
+    auto par = [&](auto &&fn) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nth; t++) th.emplace_back([&, t] { fn(t, n * (size_t)t / nth, n * (size_t)(t + 1) / nth); });
+        fn(0, 0, n / nth);
+        for (auto &x : th) x.join();
+    };
+    std::vector<int64_t> lo_a(nth, posA[0]), hi_a(nth, posA[0]), lo_b(nth, posB[0]), hi_b(nth, posB[0]);
+    par([&](int t, size_t i0, size_t i1) {
+        int64_t a0 = posA[0], a1 = posA[0], b0 = posB[0], b1 = posB[0];
+        for (size_t i = i0; i < i1; i++) {
+            a0 = std::min(a0, posA[i]);
+            a1 = std::max(a1, posA[i]);
+            b0 = std::min(b0, posB[i]);
+            b1 = std::max(b1, posB[i]);
+        }
+        lo_a[t] = a0; hi_a[t] = a1; lo_b[t] = b0; hi_b[t] = b1;
+    });
+    const int64_t amin = *std::min_element(lo_a.begin(), lo_a.end()), amax = *std::max_element(hi_a.begin(), hi_a.end());
+    const int64_t bmin = *std::min_element(lo_b.begin(), lo_b.end()), bmax = *std::max_element(hi_b.begin(), hi_b.end());
     if ((unsigned __int128)((__int128)amax - amin) > 0xfffffffeull || (unsigned __int128)((__int128)bmax - bmin) > 0xfffffffeull) {
         tdt_set_error("tdt_sort_dbscan: coordinate span >= 2^32 is outside the device path's domain");
         return TDT_E_UNSUPPORTED;
     }
     hipStream_t st = ctx->stream;
     void *h = nullptr, *d = nullptr;
-    const size_t hb = n * 8 + (size_t)(nb + 1) * 4 + 64;
+    const size_t hb = n * 12 + (size_t)(nb + 1) * 4 + 64;     // in: two 32-bit columns; out: labels (8 B) + order (4 B) per signal
     int rc = tdt_pinned(ctx, 1, hb, &h);
     if (rc) return rc;
     // device: x,y (in), xs,ys (sorted), perm, keys in/out, labels, boff
@@ -810,11 +836,13 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     double *dlab = (double *)p; p += szN8;
     int *dboff = (int *)p;
     uint32_t *hx = (uint32_t *)h, *hy = hx + n;
-    int *hboff = (int *)(hy + n);
-    for (size_t i = 0; i < n; i++) {
-        hx[i] = (uint32_t)(posA[i] - amin);
-        hy[i] = (uint32_t)(posB[i] - bmin);
-    }
+    int *hboff = (int *)((char *)h + n * 12);
+    par([&](int, size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) {
+            hx[i] = (uint32_t)(posA[i] - amin);
+            hy[i] = (uint32_t)(posB[i] - bmin);
+        }
+    });
     for (int b = 0; b <= nb; b++) hboff[b] = (int)bucket_off[b];
     TDT_HIP(hipMemcpyAsync(dx, hx, n * 4, hipMemcpyHostToDevice, st));
     TDT_HIP(hipMemcpyAsync(dy, hy, n * 4, hipMemcpyHostToDevice, st));
@@ -834,9 +862,16 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     TDT_CHECK_LAUNCH();
     rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, nullptr);
     if (rc) return rc;
+    // results come back through the pinned block (its input columns are consumed by now), then go to the caller's arrays on the host threads
+    double *hlab = (double *)h;
+    uint32_t *hperm = (uint32_t *)((char *)h + n * 8);
+    TDT_HIP(hipMemcpyAsync(hlab, dlab, n * 8, hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipMemcpyAsync(hperm, dperm, n * 4, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipStreamSynchronize(st));
-    TDT_HIP(hipMemcpy(perm_out, dperm, n * 4, hipMemcpyDeviceToHost));
-    TDT_HIP(hipMemcpy(labels_out, dlab, n * 8, hipMemcpyDeviceToHost));
+    par([&](int, size_t i0, size_t i1) {
+        memcpy(labels_out + i0, hlab + i0, (i1 - i0) * 8);
+        memcpy(perm_out + i0, hperm + i0, (i1 - i0) * 4);
+    });
     return TDT_OK;
 }
 

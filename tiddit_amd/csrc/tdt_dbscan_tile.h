@@ -34,6 +34,8 @@
 #define DT_CODE_PREV (1ull << 62)           // the position belongs to the NEXT tile's range: its owner is tile(position) - 1
 #define DT_CODE_EXTRA (1ull << 61)          // index counts extra sub-run starts (else: x-run index)
 #define DT_MINUS1 0xbff0000000000000ull     // bits of -1.0
+#define DT_GRP 64                           // tiles per group of the two-level count sums (one-bucket path)
+#define DT_GRPMAX 20000                     // groups: 2^31 points / (DT_GRP * smallest tile)
 
 struct DtParams {
     const unsigned *x, *y;
@@ -47,6 +49,7 @@ struct DtParams {
     unsigned *aggR, *aggE;    // per tile: x-runs started in the owned words, extra sub-run starts of the owned clusters
     unsigned *brun, *bext;    // per bucket whose first point lies in the tile: the two counts in front of that point
     unsigned *flags;          // [0] != 0: some x-cluster is too large for this path
+    unsigned *grp;            // one-bucket path: sums of aggR / aggE over groups of DT_GRP tiles ([2][DT_GRPMAX], zero on entry)
 };
 
 // the kernel that follows the tile kernel tells the host whether the pass stands (no extra launch, no stream synchronisation)
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         if (lane == 0) {
             s_owned = owned;
             P.aggR[tile] = owned;
+            if (ONE_BUCKET && owned) atomicAdd(&P.grp[tile / DT_GRP], owned);
         }
     }
     __syncthreads();
@@ -392,7 +396,10 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
             if (lane >= d) incl += o;
         }
         if (lane < DT_NW) extBase[lane] = incl - c;
-        if (lane == 63) P.aggE[tile] = incl;
+        if (lane == 63) {
+            P.aggE[tile] = incl;
+            if (ONE_BUCKET && incl) atomicAdd(&P.grp[DT_GRPMAX + tile / DT_GRP], incl);
+        }
     }
     __syncthreads();
 
@@ -539,22 +546,39 @@ __global__ __launch_bounds__(256) void dbt_finish(unsigned long long *__restrict
     else lab[i0] = w[0];
 }
 
-// one bucket: no scan launch — every workgroup sums the per-tile counts it needs (those before its tile, and all of them)
+// one bucket: no scan launch — every workgroup sums the counts it needs itself: whole groups of DT_GRP tiles from the group sums
+// the tile kernel accumulated, single tiles inside its own group.  `grp_next` is the group array of the NEXT call (the two
+// alternate): workgroup 0 clears it.
 __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restrict__ lab, int n, const unsigned *__restrict__ aggR,
-                                                   const unsigned *__restrict__ aggE, int nt, long long *__restrict__ last_id,
+                                                   const unsigned *__restrict__ aggE, int nt, const unsigned *__restrict__ grp,
+                                                   unsigned *__restrict__ grp_next, int ng_clear, long long *__restrict__ last_id,
                                                    unsigned *__restrict__ flags, volatile unsigned *host, unsigned seq) {
     __shared__ unsigned red[4][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    dt_signal_host(flags, host, seq);
     const int tile = blockIdx.x;
+    dt_signal_host(flags, host, seq);
+    const int ng = (nt + DT_GRP - 1) / DT_GRP;
+    if (tile == 0)
+        for (int i = tid; i < ng_clear; i += 256) {
+            grp_next[i] = 0;
+            grp_next[DT_GRPMAX + i] = 0;
+        }
     // A: tiles < tile-1, B: tile-1, T: all
+    const int gA = (tile - 1) / DT_GRP;            // group of tile-1 (tile 0: no tile before it)
     unsigned rA = 0, rB = 0, rT = 0, eA = 0, eB = 0, eT = 0;
-    for (int i = tid; i < nt; i += 256) {
-        const unsigned r = aggR[i], e = aggE[i];
+    for (int g = tid; g < ng; g += 256) {
+        const unsigned r = grp[g], e = grp[DT_GRPMAX + g];
         rT += r;
         eT += e;
-        if (i < tile - 1) { rA += r; eA += e; }
-        if (i == tile - 1) { rB = r; eB = e; }
+        if (tile > 0 && g < gA) { rA += r; eA += e; }
+    }
+    if (tile > 0) {
+        const int i = gA * DT_GRP + tid;           // the tiles of group gA in front of tile-1, and tile-1 itself
+        if (tid < DT_GRP && i <= tile - 1) {
+            const unsigned r = aggR[i], e = aggE[i];
+            if (i < tile - 1) { rA += r; eA += e; }
+            else { rB = r; eB = e; }
+        }
     }
     unsigned v[6] = {rA, rB, rT, eA, eB, eT};
 #pragma unroll
