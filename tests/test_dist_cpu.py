@@ -173,3 +173,62 @@ def test_sharded_bam_seams_and_exact_allreduce_gloo_world2(tmp_path):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _bench_worker(rank, world, port, q):
+    """the N-rank clustering step of bench.py (bench.shared_step over bench.shared_bucket_sizes), the oracle standing in for the
+    device call of every rank's share"""
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    import bench
+    import oracle
+    from tiddit_amd import synth
+    from tiddit_amd.dist import shard_buckets
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sizes = bench.shared_bucket_sizes(30000)
+        assert len(sizes) == 300 and 0.9 * 30000 < sizes.sum() <= 30000
+        owned = shard_buckets(sizes, world)
+        loads = [int(sum(sizes[b] for b in o)) for o in owned]
+        assert max(loads) - min(loads) <= sizes.max()                 # bin packing by signal count
+        pts = lambda b: synth.gen_points(int(sizes[b]), L=3_000_000, seed=1000 + b)
+        calls = []
+
+        def cluster_local(ids):
+            calls.append(list(ids))
+            out = [oracle.dbscan_main(pts(b), 500, 3) for b in ids if sizes[b]]
+            return torch.from_numpy(np.concatenate(out) if out else np.zeros(0))
+
+        from tiddit_amd.dist import split_gathered
+        labels = split_gathered(sizes, *bench.shared_step(sizes, cluster_local, True))
+        assert calls == [owned[rank]]                                 # a rank only ever clusters its own share ...
+        for b in range(len(sizes)):                                   # ... and ends up with every bucket's labels
+            want = oracle.dbscan_main(pts(b), 500, 3) if sizes[b] else np.zeros(0)
+            assert np.array_equal(labels[b].numpy(), want), b
+        one = split_gathered(sizes, *bench.shared_step(sizes, lambda ids: torch.from_numpy(np.concatenate([oracle.dbscan_main(pts(b), 500, 3) for b in ids if sizes[b]])), False))
+        assert all(np.array_equal(one[b].numpy(), labels[b].numpy()) for b in range(len(sizes)))
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_shared_clustering_step_gloo_world2():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

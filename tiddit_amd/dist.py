@@ -45,7 +45,18 @@ def allgatherv(t, group=None):
     return [out[r * mx:r * mx + counts[r]] for r in range(world)]
 
 
-def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None, wire_dtype="int32"):
+def split_gathered(bucket_sizes, owned, parts):
+    """per-rank label arrays (rank r: its buckets in owned[r] order, concatenated) -> list over ALL buckets"""
+    labels = [None] * len(bucket_sizes)
+    for r, p in enumerate(parts):
+        off = 0
+        for b in owned[r]:
+            labels[b] = p[off:off + int(bucket_sizes[b])]
+            off += int(bucket_sizes[b])
+    return labels
+
+
+def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None, wire_dtype="int32", flat=False):
     """Cluster every bucket on its owner rank, then all-gather the labels.
 
     Labels are integers (-1 or a cluster id < 2^31) carried in float64 like the reference returns them; on
@@ -54,7 +65,7 @@ def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None, wire_dt
     bucket_sizes : number of signals of every bucket (identical on all ranks)
     cluster_local(bucket_ids) -> 1-D float64 tensor with the labels of those buckets, concatenated
                    in the given order (on the GPU path: tdt_dbscan_device over the rank's buckets)
-    -> list over ALL buckets of label tensors, identical on every rank.
+    -> list over ALL buckets of label tensors, identical on every rank (flat=True: (owned, per-rank wire arrays) instead).
     """
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -65,14 +76,10 @@ def cluster_buckets_distributed(bucket_sizes, cluster_local, group=None, wire_dt
     out_dtype = mine.dtype
     if wire_dtype is not None:
         mine = mine.to(getattr(torch, wire_dtype))
-    parts = [p.to(out_dtype) for p in allgatherv(mine, group)]
-    labels = [None] * len(bucket_sizes)
-    for r in range(world):
-        off = 0
-        for b in owned[r]:
-            labels[b] = parts[r][off:off + int(bucket_sizes[b])]
-            off += int(bucket_sizes[b])
-    return labels
+    parts = allgatherv(mine, group)
+    if flat:                       # the gathered per-rank arrays as they arrived (split_gathered gives the per-bucket view)
+        return owned, parts
+    return split_gathered(bucket_sizes, owned, [p.to(out_dtype) for p in parts])
 
 
 # ------------------------------------------------------------------------------------------------------------------
