@@ -125,6 +125,25 @@ int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, si
 int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
                     double eps, int m, uint32_t *perm_out, double *labels_out);
 
+/* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) ------------------------------------- *
+ * The clustering path shards by (chrA,chrB) bucket (tiddit_cluster.pyx:140-154 keeps no cross-bucket state): every rank
+ * clusters its buckets with tdt_dbscan_device / tdt_sort_dbscan and ONE variable-count all-gather of the label arrays gives
+ * every rank the whole cluster set.  When one BAM is read as byte-range shards (tdt_ingest_push_bounded) every rank bins
+ * its reads into a full-genome histogram and ONE sum all-reduce of the float64 bins finishes it — the bins are multiples of
+ * 2^-S below 2^53, so the sum is exact and bit-identical to the single-GPU result.
+ * tdt_comm_unique_id: rank 0 obtains the 128-byte RCCL id and hands it to the other ranks by whatever channel launched them
+ * (MPI, a file, torch.distributed); tdt_comm_init is collective over the `world` ranks, each with its own context/GPU.
+ * tdt_allgatherv: rank r contributes counts[r] elements of elem_bytes; they arrive at d_recv + displs[r]*elem_bytes on every
+ * rank (counts/displs are HOST arrays, identical on all ranks; counts[rank] == send_count).  Both calls are asynchronous on the
+ * context stream.  RCCL is bound at run time (an instance already in the process, e.g. PyTorch's, is reused). */
+typedef struct tdt_comm tdt_comm;
+int tdt_comm_unique_id(uint8_t *id128);
+int tdt_comm_init(tdt_ctx *ctx, const uint8_t *id128, int rank, int world, tdt_comm **out);
+int tdt_comm_destroy(tdt_comm *comm);
+int tdt_allgatherv(tdt_comm *comm, const void *d_send, size_t send_count, void *d_recv, const size_t *counts, const size_t *displs,
+                   int elem_bytes);
+int tdt_allreduce_sum_f64(tdt_comm *comm, double *d_buf, size_t n);
+
 /* ---- discordant-pair candidate selection ------------------------------------------------------ *
  * Replaces the per-read predicate chain of tiddit_signal.worker (tiddit_signal.pyx:171-211): a read is a
  * discordant-pair signal iff its contig is processed (contig_ok[tid], = LN >= min_contig) and it is mapped,

@@ -600,3 +600,26 @@ def test_gc_from_fasta_layout_equals_stripped(tmp_path, width, eol):
             assert np.array_equal(got, oracle.binned_gc(s, z, 0.5)), (name, z)
     g = tiddit_gc.main(path, ["a", "d"], 1, 50, 0.5)
     assert np.array_equal(g["a"], oracle.binned_gc(seqs["a"], 50, 0.5)) and np.array_equal(g["d"], oracle.binned_gc(seqs["d"], 50, 0.5))
+
+
+def test_comm_abi_single_rank_group(ctx):
+    """tdt_comm_* (RCCL bound at run time): a one-rank communicator on this GPU — the variable-count all-gather and the float64
+    sum all-reduce are the identity; (more ranks need more GPUs: the N-rank layout logic is covered by the gloo tests)"""
+    torch = pytest.importorskip("torch")
+    from tiddit_amd.comm import Comm
+    dev = torch.device("cuda:0")
+    c = Comm(0, 1, Comm.unique_id(), ctx)
+    src = torch.arange(1000, dtype=torch.int32, device=dev) * 3 - 7
+    dst = torch.zeros(1000, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    c.allgatherv(src.data_ptr(), dst.data_ptr(), [1000], 4)
+    bins = torch.rand(4096, dtype=torch.float64, device=dev)
+    want = bins.clone()
+    torch.cuda.synchronize()
+    c.allreduce_sum_f64(bins.data_ptr(), bins.numel())
+    ctx.sync()
+    assert torch.equal(dst, src) and torch.equal(bins, want)
+    empty = torch.zeros(1, dtype=torch.int32, device=dev)
+    c.allgatherv(0, empty.data_ptr(), [0], 4)
+    ctx.sync()
+    c.close()

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libtiddit_hip.so")
-SOURCES = ["tdt_ctx.hip", "tdt_coverage.hip", "tdt_gc.hip", "tdt_dbscan.hip", "tdt_sort.hip", "tdt_bam.hip", "tdt_format.hip", "tdt_bgzf.hip", "tdt_inflate.hip", "tdt_inflate2.hip", "tdt_ingest.hip", "tdt_signal.hip", "tdt_median.hip", "tdt_region.hip"]
+SOURCES = ["tdt_ctx.hip", "tdt_coverage.hip", "tdt_gc.hip", "tdt_dbscan.hip", "tdt_sort.hip", "tdt_bam.hip", "tdt_format.hip", "tdt_bgzf.hip", "tdt_inflate.hip", "tdt_inflate2.hip", "tdt_ingest.hip", "tdt_signal.hip", "tdt_median.hip", "tdt_region.hip", "tdt_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 
@@ -34,7 +34,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
     if relink or not os.path.exists(SO):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO, "-lz", "-lpthread"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", SO, "-lz", "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
