@@ -165,6 +165,18 @@ int tdt_signal_select_device(tdt_ctx *ctx, const uint16_t *d_flag, const uint8_t
 int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t *gc, const int64_t *seg_off, int nseg, double *lower,
                        double *upper, int64_t *count);
 
+/* ---- region means of the coverage bins per SV candidate --------------------------------------------- *
+ * Replaces the per-candidate numpy.average calls of tiddit_variant.define_variant (tiddit_variant.pyx:265-283: avg_a / avg_b over
+ * the 50-bp bins [start/50, end/50]; :307-315: covM over the bins between the breakpoints with gc != -1).  cov / gc are the
+ * concatenated float64 coverage bins / int8 GC bins; segment q = [seg_lo[q], seg_hi[q]) indexes them (seg_lo/seg_hi/masked are
+ * HOST arrays in both entry points); masked[q] != 0 keeps only the bins with gc > -1 (order preserved).  mean[q] equals
+ * numpy.average of that slice BIT FOR BIT (numpy's chunked pairwise summation order is reproduced), NaN for an empty one;
+ * count[q] = number of bins averaged (the reference falls back to the contig's coverage when covM has <= 4 of them). */
+int tdt_segment_means(tdt_ctx *ctx, const double *cov, const int8_t *gc, int64_t total, const int64_t *seg_lo, const int64_t *seg_hi,
+                      const uint8_t *masked, size_t nq, double *mean, int64_t *count);
+int tdt_segment_means_device(tdt_ctx *ctx, const double *d_cov, const int8_t *d_gc, const int64_t *seg_lo, const int64_t *seg_hi,
+                             const uint8_t *masked, size_t nq, double *d_mean, int64_t *d_count);
+
 /* ---- regional evidence counts per SV candidate --------------------------------------------------- *
  * Replaces the per-candidate BAM re-scan of tiddit_variant.get_region (tiddit_variant.pyx:54-151).  The arrays
  * are ONE contig's coordinate-sorted alignment records (has_sa[i] != 0 iff the record carries an SA tag, tid = the

@@ -401,3 +401,57 @@ int64_t orc_signal_worker(int64_t n, const int32_t *tid, const int32_t *pos, con
     }
     return updates;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * numpy.average of a contiguous float64 slice — tiddit_variant.pyx:265-283 (avg_a, avg_b: mean of the 50-bp coverage bins of
+ * [start/50, end/50]) and :307-315 (covM: mean of the bins between the breakpoints whose gc != -1).  numpy.average(a) is
+ * a.mean() = numpy.add.reduce(a) / len(a); the reduction of a contiguous float64 array is numpy's PAIRWISE summation
+ * (numpy/_core/src/umath/loops_utils.h.src, pairwise_sum_DOUBLE): blocks of at most 128 elements are summed with eight
+ * interleaved accumulators, larger ranges are split in halves (the first a multiple of 8); the array is fed to that routine
+ * in chunks of 8192 elements.  Restated here so that the
+ * device kernel can be held to numpy's exact result; tests compare BOTH with numpy itself (third-party dependency of the
+ * reference, importable everywhere).
+ * ---------------------------------------------------------------------------------------- */
+static double orc_pairwise(const double *a, int64_t n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return orc_pairwise(a, n2) + orc_pairwise(a + n2, n - n2);
+    }
+}
+
+/* mean of a[0..n) the way numpy.add.reduce + true_divide produce it; NaN for n == 0 (numpy.average of an empty slice).
+ * The reduction runs over the ufunc machinery's buffer-size chunks of 8192 elements: the result starts at the identity 0.0 and
+ * every chunk's pairwise sum is added in order (probed against numpy 2.2 on views of every alignment: this, and only this,
+ * decomposition matches on all of them). */
+double orc_np_mean(const double *a, int64_t n) {
+    if (n <= 0) return NAN;
+    double res = 0.0;
+    for (int64_t o = 0; o < n; o += 8192) res += orc_pairwise(a + o, n - o < 8192 ? n - o : 8192);
+    return res / (double)n;
+}
+
+/* covM's masked mean: the elements with gc > -1, compacted in order (boolean indexing), then numpy.average; *kept = how many */
+double orc_np_masked_mean(const double *a, const int8_t *gc, int64_t n, int64_t *kept) {
+    double *tmp = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (gc[i] > -1) tmp[k++] = a[i];
+    *kept = k;
+    double m = orc_np_mean(tmp, k);
+    free(tmp);
+    return m;
+}

@@ -623,3 +623,76 @@ def test_comm_abi_single_rank_group(ctx):
     c.allgatherv(0, empty.data_ptr(), [0], 4)
     ctx.sync()
     c.close()
+
+
+def test_segment_means_equal_numpy_average_bit_for_bit(ctx):
+    """tiddit_variant.pyx:265-283,307-315: numpy.average of coverage slices / of the gc-masked slice.  The kernel reproduces
+    numpy's chunked pairwise summation order, so the float64 means are identical, not merely close."""
+    import warnings
+    from tiddit_amd import tiddit_region
+    rng = np.random.default_rng(3)
+    cov = {"chr1": rng.gamma(30, 1.0, 2_500_000) * rng.choice([1e-3, 1.0, 1e3], 2_500_000), "chr2": rng.gamma(5, 2.0, 70_001), "tiny": np.zeros(3)}
+    gc = {k: np.where(rng.random(len(v) + 2) < 0.15, -1, 41).astype(np.int8) for k, v in cov.items()}
+    table = tiddit_region.BinTable(cov, gc)
+    segs, masked = [], []
+    for n in list(range(0, 140)) + [255, 256, 257, 1000, 8191, 8192, 8193, 16384, 16385, 20000, 100_001, 1 << 20, 2_400_000]:
+        for off in (0, 1, 3, 5):
+            segs.append(("chr1", off, off + n))
+            masked.append(len(segs) % 2)
+    segs += [("chr2", 69_990, 80_000), ("chr2", 500, 400), ("tiny", 0, 10), ("tiny", 5, 9), ("chr2", 0, 70_001)]
+    masked += [0, 1, 1, 0, 1]
+    mean, count = tiddit_region.region_means(table, segs, masked)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, (c, s, e) in enumerate(segs):
+            a = cov[c][s:e]
+            if masked[i]:
+                a = a[gc[c][s:e][:len(a)] > -1]
+            want = np.average(a) if len(a) else np.nan
+            assert count[i] == len(a), (i, segs[i])
+            assert (mean[i] == want) or (np.isnan(mean[i]) and np.isnan(want)), (i, segs[i], mean[i], want)
+            o = oracle.np_masked_mean(cov[c][s:e], gc[c][s:e][:len(cov[c][s:e])])[0] if masked[i] else oracle.np_mean(cov[c][s:e])
+            assert (o == want) or (np.isnan(o) and np.isnan(want))
+
+
+def test_candidate_means_follow_define_variant(ctx):
+    import math
+    import warnings
+    from tiddit_amd import tiddit_region
+    rng = np.random.default_rng(8)
+    cov = {"chr1": rng.gamma(30, 1.0, 40_000), "chr10": rng.gamma(30, 1.0, 9_000)}
+    gc = {k: np.where(rng.random(len(v)) < 0.3, -1, 41).astype(np.int8) for k, v in cov.items()}
+    lib = {"avg_coverage_chr1": 29.5, "avg_coverage_chr10": 31.0}
+    cl = {"chr1": {"chr1": {}, "chr10": {}}}
+    for k in range(60):
+        a = int(rng.integers(1000, 1_900_000))
+        b = a + int(rng.choice([120, 700, 1000, 1100, 5000, 90_000]))
+        if k % 7 == 0:
+            a, b = b, a
+        cl["chr1"]["chr1"][k] = {"posA": a, "posB": b, "startA": min(a, b) - 300, "endA": min(a, b) + 5, "startB": max(a, b) - 2, "endB": max(a, b) + 310}
+    cl["chr1"]["chr10"][3] = {"posA": 5000, "posB": 7000, "startA": 4700, "endA": 5001, "startB": 6990, "endB": 7300}
+    cl["chr1"]["chr1"][99] = {"posA": 1_999_990, "posB": 2_100_000, "startA": 1_999_700, "endA": 2_000_400, "startB": 2_099_000, "endB": 2_100_000}   # past the contig end
+    got = tiddit_region.candidate_means(cl, cov, gc, lib)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for chrA in cl:
+            for chrB in cl[chrA]:
+                for cid, c in cl[chrA][chrB].items():
+                    posA, posB = c["posA"], c["posB"]
+                    if chrA == chrB and posA > posB:
+                        posA, posB = posB, posA
+                    s, e = int(math.floor(c["startA"] / 50.0)), int(math.floor(c["endA"] / 50.0)) + 1
+                    avg_a = np.average(cov[chrA][s:e])
+                    s, e = int(math.floor(c["startB"] / 50.0)), int(math.floor(c["endB"] / 50.0)) + 1
+                    avg_b = np.average(cov[chrB][s:e])
+                    if chrA != chrB:
+                        covM = 0
+                    elif abs(posB - posA) < 1000:
+                        covM = None
+                    else:
+                        s, e = int(math.floor(posA / 50.0)), int(math.floor(posB / 50.0)) + 1
+                        between = cov[chrA][s:e][gc[chrA][s:e] > -1]
+                        covM = np.average(between) if len(between) > 4 else lib["avg_coverage_" + chrA]
+                    g = got[(chrA, chrB, cid)]
+                    same = lambda x, y: (x is None and y is None) or x == y or (x is not None and y is not None and np.isnan(x) and np.isnan(y))
+                    assert same(g["avg_a"], avg_a) and same(g["avg_b"], avg_b) and same(g["covM"], covM), (chrA, chrB, cid, g, avg_a, avg_b, covM)

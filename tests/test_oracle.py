@@ -133,3 +133,21 @@ def test_dbscan_gen_1m(golden_dir):
         pytest.skip("1M reference labels not generated (make_golden.py --slow)")
     lab = oracle.dbscan_main(synth.gen_points(1_000_000), g["eps"], g["m"])
     assert sha(lab.astype("<f8")) == g["labels_sha256"]
+
+
+def test_np_mean_restatement_equals_numpy():
+    """orc_np_mean / orc_np_masked_mean (numpy's chunked pairwise summation, tiddit_variant.pyx:265-283,307-315) against numpy itself"""
+    import warnings
+    rng = np.random.default_rng(1)
+    for n in list(range(0, 140)) + [255, 256, 257, 1000, 8191, 8192, 8193, 9000, 16384, 16385, 20000, 100001, (1 << 20) + 7]:
+        for off in (0, 1, 3):
+            big = rng.gamma(30, 1.0, n + 17) * rng.choice([1e-3, 1.0, 1e3], n + 17)
+            v = big[off:off + n]
+            g = np.where(rng.random(n) < 0.2, -1, 40).astype(np.int8)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want, wantm = np.average(v), np.average(v[g > -1])
+            got = oracle.np_mean(v)
+            gotm, k = oracle.np_masked_mean(v, g)
+            assert got == want or (np.isnan(got) and np.isnan(want)), (n, off)
+            assert (gotm == wantm or (np.isnan(gotm) and np.isnan(wantm))) and k == int((g > -1).sum()), (n, off)

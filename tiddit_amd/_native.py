@@ -64,6 +64,8 @@ SYMBOLS = {
     "tdt_signal_select": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, ctypes.POINTER(_sz)]),
     "tdt_signal_select_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, _P]),
     "tdt_masked_medians": (_i, [_P, _P, _P, _P, _i, _P, _P, _P]),
+    "tdt_segment_means": (_i, [_P, _P, _P, _i64, _P, _P, _P, _sz, _P, _P]),
+    "tdt_segment_means_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _P]),
     "tdt_region_counts": (_i, [_P] * 9 + [_sz, _i, _i64, _P, _P, _P, _sz, _i, _i64, _P]),
     "tdt_region_counts_device": (_i, [_P] * 9 + [_sz, _i, _i, _i64, _P, _P, _P, _sz, _i, _i64, _P]),
     "tdt_format_coverage": (_i, [_P, _sz, ctypes.c_char_p, _i64, _i64, _i, _P, _sz, ctypes.POINTER(_sz)]),

@@ -87,3 +87,78 @@ def get_region(table, chrom, start, end, bp, min_q, max_ins, contig_number=None)
     coverage = bases / (end - start + 1)
     frac_low_q = low_q / float(n_reads) if n_reads > 0 else 0
     return (coverage, frac_low_q, n_discs, n_splits, crossing_f, crossing_r)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Region means of the coverage bins (tiddit_variant.pyx:265-283, 307-315)
+class BinTable:
+    """The 50-bp coverage bins (and GC bins) of every contig, concatenated once — the arrays the segment-mean kernel indexes."""
+
+    def __init__(self, coverage_data, gc=None):
+        self.offset, self.length = {}, {}
+        o = 0
+        for name, bins in coverage_data.items():
+            self.offset[name], self.length[name] = o, len(bins)
+            o += len(bins)
+        self.cov = numpy.ascontiguousarray(numpy.concatenate([numpy.asarray(b, dtype=numpy.float64) for b in coverage_data.values()])
+                                           if coverage_data else numpy.zeros(0))
+        self.gc = None
+        if gc is not None:
+            self.gc = numpy.ascontiguousarray(numpy.concatenate([numpy.asarray(gc[n][:len(coverage_data[n])], dtype=numpy.int8) for n in coverage_data]))
+            if len(self.gc) != len(self.cov):
+                raise IndexError("gc array shorter than its coverage array")
+
+    def segment(self, chrom, s, e):
+        """the index range Python's ``coverage_data[chrom][s:e]`` selects (non-negative s, e), as offsets into the concatenation"""
+        n, o = self.length[chrom], self.offset[chrom]
+        s, e = min(max(int(s), 0), n), min(max(int(e), 0), n)
+        return o + s, o + max(s, e)
+
+
+def region_means(table, segments, masked=None, ctx=None):
+    """segments: list of (chrom, s, e) bin slices; masked[i] truthy: only bins with gc > -1 count (needs table.gc).
+    -> (float64 means — numpy.average of the slice, bit for bit; nan for an empty one —, int64 counts of the bins averaged)"""
+    ctx = ctx or _native.default_context()
+    nq = len(segments)
+    lo = numpy.empty(nq, dtype=numpy.int64)
+    hi = numpy.empty(nq, dtype=numpy.int64)
+    for i, (chrom, s, e) in enumerate(segments):
+        lo[i], hi[i] = table.segment(chrom, s, e)
+    m = numpy.zeros(nq, dtype=numpy.uint8) if masked is None else numpy.ascontiguousarray(masked, dtype=numpy.uint8)
+    mean = numpy.empty(nq, dtype=numpy.float64)
+    count = numpy.empty(nq, dtype=numpy.int64)
+    _native.check(ctx.lib.tdt_segment_means(ctx.handle, _native.ptr(table.cov), _native.ptr(table.gc) if table.gc is not None else None,
+                                            len(table.cov), _native.ptr(lo), _native.ptr(hi), _native.ptr(m), nq, _native.ptr(mean), _native.ptr(count)))
+    return mean, count
+
+
+def candidate_means(sv_clusters, coverage_data, gc, library, bin_size=50):
+    """The three coverage means tiddit_variant.define_variant forms for every candidate (:265-283, :307-315), all candidates of all
+    chromosome pairs in ONE device call: -> {(chrA, chrB, cluster): {"avg_a", "avg_b", "covM" (None where the reference takes it
+    from get_region instead: breakpoints closer than 1000 bp; 0 for inter-chromosomal candidates)}}"""
+    import math
+    table = BinTable(coverage_data, gc)
+    keys, segs, masked = [], [], []
+    for chrA in sv_clusters:
+        for chrB in sv_clusters[chrA]:
+            for cid, c in sv_clusters[chrA][chrB].items():
+                posA, posB = c["posA"], c["posB"]
+                if chrA == chrB and posA > posB:
+                    posA, posB = posB, posA
+                keys.append((chrA, chrB, cid, posA, posB))
+                segs.append((chrA, int(math.floor(c["startA"] / float(bin_size))), int(math.floor(c["endA"] / float(bin_size))) + 1))
+                segs.append((chrB, int(math.floor(c["startB"] / float(bin_size))), int(math.floor(c["endB"] / float(bin_size))) + 1))
+                between = chrA == chrB and abs(posB - posA) >= 1000
+                segs.append((chrA, int(math.floor(posA / float(bin_size))), int(math.floor(posB / float(bin_size))) + 1) if between else (chrA, 0, 0))
+                masked += [0, 0, 1 if between else 0]
+    mean, count = region_means(table, segs, masked) if segs else (numpy.zeros(0), numpy.zeros(0, dtype=numpy.int64))
+    out = {}
+    for i, (chrA, chrB, cid, posA, posB) in enumerate(keys):
+        if chrA != chrB:
+            covM = 0
+        elif abs(posB - posA) < 1000:
+            covM = None
+        else:
+            covM = mean[3 * i + 2] if count[3 * i + 2] > 4 else library["avg_coverage_{}".format(chrA)]
+        out[(chrA, chrB, cid)] = {"avg_a": mean[3 * i], "avg_b": mean[3 * i + 1], "covM": covM}
+    return out
