@@ -156,6 +156,23 @@ int tdt_signal_select_device(tdt_ctx *ctx, const uint16_t *d_flag, const uint8_t
                              const int32_t *d_mate_tid, const int32_t *d_tlen, size_t n, const uint8_t *d_contig_ok, int n_contigs,
                              int min_q, int64_t max_ins, uint32_t *d_out_idx, uint64_t *d_count);
 
+/* The WHOLE per-read chain of tiddit_signal.worker (tiddit_signal.pyx:171-221) on a decoded batch resident in HBM.  d_arrays14 =
+ * the pointer table of tdt_ingest_arrays (tdt_bam_decode's field order, then the raw record bytes); contig_ok is a HOST array.
+ * Every read gets an action byte — 2: clipped read for local assembly (:190-197), 4: carries an SA tag, SA_analysis is called
+ * (:199-202), 8: a discordant-pair row is appended (:204-221) — and the reads with any bit set are compacted in stream order
+ * with their fields and raw record bytes, so that the host touches only those.  tdt_signal_scan returns how many (*n_sel) and
+ * their total record bytes; tdt_signal_scan_result copies them out: meta = n_sel records of 28 bytes {uint32 index in the
+ * batch; int32 tid, pos, end, mate_tid, sa_rel (offset of the SA:Z string inside the record, -1 without); uint16 flag; uint8
+ * action; uint8 0}, raw_end[k] = end offset of record k inside raw (record k starts at raw_end[k-1], its block_size field
+ * first).  The result of the calling thread's last scan is kept until its next one. */
+int tdt_signal_scan(tdt_ctx *ctx, const void *const *d_arrays14, size_t n, const uint8_t *contig_ok, int n_contigs, int min_q, int64_t max_ins,
+                    int min_anchor_len, int min_clip_len, size_t *n_sel, size_t *raw_bytes);
+int tdt_signal_scan_result(tdt_ctx *ctx, void *meta, uint32_t *raw_end, uint8_t *raw);
+/* The clips.append entries of worker (:192-197) as text: for the selected records `which[0..m)` (indices into the arrays of
+ * tdt_signal_scan_result) `>query_name|contig|pos+1\nSEQUENCE\n`, concatenated.  Two-call protocol like tdt_format_coverage. */
+int tdt_format_clips(const void *meta, const uint32_t *raw_end, const uint8_t *raw, const uint32_t *which, size_t m, const char *contig,
+                     char *out, size_t out_cap, size_t *out_len);
+
 /* ---- masked medians of the coverage bins -------------------------------------------------------- *
  * Replaces the per-bin Python loop + numpy.median of determine_ploidy (tiddit_coverage_analysis.pyx:14-27).
  * cov/gc are the concatenated float64 bins / int8 GC bins; segment s = [seg_off[2s], seg_off[2s+1]) (segments may

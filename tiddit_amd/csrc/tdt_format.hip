@@ -238,3 +238,57 @@ extern "C" int tdt_fasta_write_fai(const char *fasta_path, const char *fai_path)
     fclose(o);
     return TDT_OK;
 }
+
+// ---- clip FASTA entries (tiddit_signal.pyx:192-197): ">{query_name}|{contig}|{pos+1}\n{query_sequence}\n" for selected records
+extern "C" int tdt_format_clips(const void *meta_, const uint32_t *raw_end, const uint8_t *raw, const uint32_t *which, size_t m, const char *contig,
+                                char *out, size_t out_cap, size_t *out_len) {
+    if (!out_len || (m && (!meta_ || !raw_end || !raw || !which || !contig))) {
+        tdt_set_error("tdt_format_clips: bad argument");
+        return TDT_E_ARG;
+    }
+    static const char SEQ[] = "=ACMGRSVTWYHKDBN";
+    const uint8_t *meta = (const uint8_t *)meta_;
+    const size_t clen = strlen(contig);
+    size_t need = 0;
+    for (size_t k = 0; k < m; k++) {
+        const uint32_t r = which[k];
+        const uint8_t *rec = raw + (r ? raw_end[r - 1] : 0u) + 4;
+        int32_t lseq;
+        memcpy(&lseq, rec + 16, 4);
+        need += 1 + (size_t)(rec[8] ? rec[8] - 1 : 0) + 1 + clen + 1 + 11 + 1 + (size_t)(lseq > 0 ? lseq : 0) + 1;
+    }
+    if (!out) {
+        *out_len = need;
+        return TDT_OK;
+    }
+    if (out_cap < need) {
+        tdt_set_error("tdt_format_clips: buffer of %zu bytes, %zu needed", out_cap, need);
+        return TDT_E_ARG;
+    }
+    char *p = out;
+    for (size_t k = 0; k < m; k++) {
+        const uint32_t r = which[k];
+        const uint8_t *rec = raw + (r ? raw_end[r - 1] : 0u) + 4;
+        const int l_name = rec[8];
+        uint16_t n_cig;
+        int32_t lseq, pos;
+        memcpy(&n_cig, rec + 12, 2);
+        memcpy(&lseq, rec + 16, 4);
+        memcpy(&pos, meta + (size_t)r * 28 + 8, 4);
+        *p++ = '>';
+        const int nl = l_name ? l_name - 1 : 0;
+        memcpy(p, rec + 32, (size_t)nl);
+        p += nl;
+        *p++ = '|';
+        memcpy(p, contig, clen);
+        p += clen;
+        *p++ = '|';
+        p += snprintf(p, 12, "%d", pos + 1);
+        *p++ = '\n';
+        const uint8_t *sq = rec + 32 + l_name + 4 * (size_t)n_cig;
+        for (int i = 0; i < lseq; i++) *p++ = SEQ[(i & 1) ? (sq[i >> 1] & 0xf) : (sq[i >> 1] >> 4)];
+        *p++ = '\n';
+    }
+    *out_len = (size_t)(p - out);
+    return TDT_OK;
+}

@@ -117,6 +117,55 @@ class _ReadProxy:
         return self._rec.get_tag_sa()
 
 
+_META = numpy.dtype([("idx", "<u4"), ("tid", "<i4"), ("pos", "<i4"), ("end", "<i4"), ("mate_tid", "<i4"), ("sa_rel", "<i4"),
+                     ("flag", "<u2"), ("action", "u1"), ("pad", "u1")])
+_FIELD_ORDER = ("tid", "pos", "end", "mapq", "flag", "mate_tid", "mate_pos", "tlen", "l_seq", "cigar_first", "cigar_last", "rec_off", "sa_off", "raw")
+
+
+class SelectedReads:
+    """The reads of one device batch that tiddit_signal.worker acts on (clip / split / discordant), gathered by
+    ``tdt_signal_scan``: field arrays plus their raw records back to back.  Quacks like a decoded batch for RecordView."""
+
+    def __init__(self, ctx, meta, raw_end, raw):
+        self.ctx, self.meta, self.raw_end, self.raw = ctx, meta, raw_end, raw
+        self.tid, self.pos, self.end, self.flag, self.mate_tid, self.action = (meta[k] for k in ("tid", "pos", "end", "flag", "mate_tid", "action"))
+        self.rec_off = numpy.concatenate([[0], raw_end[:-1]]).astype(numpy.uint64) if len(raw_end) else numpy.zeros(0, dtype=numpy.uint64)
+        self.sa_off = numpy.where(meta["sa_rel"] >= 0, self.rec_off.astype(numpy.int64) + meta["sa_rel"], -1)
+
+    def __len__(self):
+        return len(self.meta)
+
+    def record(self, k):
+        from .bamio import RecordView
+        return RecordView(self, k)
+
+    def clip_fasta(self, which, contig):
+        """``>name|contig|pos+1\\nSEQ\\n`` of the selected records `which`, as one string (tdt_format_clips)"""
+        which = numpy.ascontiguousarray(which, dtype=numpy.uint32)
+        lib = self.ctx.lib
+        need = ctypes.c_size_t(0)
+        args = (_native.ptr(self.meta), _native.ptr(self.raw_end), _native.ptr(self.raw), _native.ptr(which), len(which), contig.encode())
+        _native.check(lib.tdt_format_clips(*args, None, 0, ctypes.byref(need)))
+        buf = numpy.empty(need.value, dtype=numpy.uint8)
+        _native.check(lib.tdt_format_clips(*args, _native.ptr(buf), need.value, ctypes.byref(need)))
+        return buf[:need.value].tobytes().decode()
+
+
+def _device_scan(batch, contig_ok, min_q, max_ins, min_anchor_len, min_clip_len, ctx=None):
+    ctx = ctx or _native.default_context()
+    ok = numpy.ascontiguousarray(contig_ok, dtype=numpy.uint8)
+    table = (ctypes.c_void_p * 14)(*[batch.dev[k] or None for k in _FIELD_ORDER])
+    n_sel, raw_bytes = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _native.check(ctx.lib.tdt_signal_scan(ctx.handle, table, len(batch), _native.ptr(ok), len(ok), int(min_q), int(max_ins), int(min_anchor_len),
+                                          int(min_clip_len), ctypes.byref(n_sel), ctypes.byref(raw_bytes)))
+    meta = numpy.empty(n_sel.value, dtype=_META)
+    raw_end = numpy.empty(n_sel.value, dtype=numpy.uint32)
+    raw = numpy.empty(raw_bytes.value, dtype=numpy.uint8)
+    if n_sel.value:
+        _native.check(ctx.lib.tdt_signal_scan_result(ctx.handle, _native.ptr(meta), _native.ptr(raw_end), _native.ptr(raw)))
+    return SelectedReads(ctx, meta, raw_end, raw)
+
+
 def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
     """indices (ascending) of the reads of a decoded batch that are discordant-pair signals"""
     ctx = ctx or _native.default_context()
@@ -155,12 +204,21 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     data = {n: [] for n in names}
     splits = {n: [] for n in names}
     clips = {n: [] for n in names}
+    T = SCAN_SECONDS
+    T.clear()
+    T.update({"ingest (inflate + decode, device)": 0.0, "coverage push": 0.0, "field copies + predicates (host)": 0.0, "clip rows": 0.0,
+              "split rows": 0.0, "discordant select + rows": 0.0})
+    t0 = time.time()
     for b in reader.batches():
-        tid = b.tid
-        flag = b.flag.astype(numpy.int32)
-        placed = tid >= 0
-        ok_contig = numpy.zeros(len(tid), dtype=bool)
-        ok_contig[placed] = big[tid[placed]]
+        t1 = time.time()
+        T["ingest (inflate + decode, device)"] += t1 - t0
+        if not isinstance(b, DeviceBatch):
+            tid = b.tid
+            flag = b.flag.astype(numpy.int32)
+            placed = tid >= 0
+            ok_contig = numpy.zeros(len(tid), dtype=bool)
+            ok_contig[placed] = big[tid[placed]]
+        t2 = time.time()
         # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
         if isinstance(b, DeviceBatch):                      # the decoded arrays are already in HBM
             d = b.dev
@@ -174,6 +232,37 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                 t = int(tid[lo])
                 if t >= 0 and big[t]:
                     hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
+        t3 = time.time()
+        T["coverage push"] += t3 - t2
+        if isinstance(b, DeviceBatch):
+            # the per-read chain of worker (:171-221) on the device; only the selected reads come back (fields + raw records)
+            sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
+            t4 = time.time()
+            T["predicates + gather of the selected reads (device)"] = T.get("predicates + gather of the selected reads (device)", 0.0) + (t4 - t3) + (t2 - t1)
+            stid, act = sel.tid, sel.action
+            clip_k = numpy.flatnonzero(act & 2)
+            if len(clip_k):
+                edges = numpy.flatnonzero(numpy.diff(stid[clip_k])) + 1
+                for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(clip_k)]])):
+                    chrom = names[stid[clip_k[lo]]]
+                    clips[chrom].append([sel.clip_fasta(clip_k[lo:hi], chrom), ""])
+            t5 = time.time()
+            T["clip rows"] += t5 - t4
+            for k in numpy.flatnonzero(act & 4):
+                chrom = names[stid[k]]
+                split = SA_analysis(_ReadProxy(sel, k), min_q, "SA", chrom)
+                if split:
+                    splits[chrom].append(split)
+            t6 = time.time()
+            T["split rows"] += t6 - t5
+            sflag, smate, spos, send = sel.flag, sel.mate_tid, sel.pos, sel.end
+            for k in numpy.flatnonzero(act & 8):
+                chrom, mate = names[stid[k]], names[smate[k]]
+                chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
+                data[chrom].append([chrA, chrB, sel.record(k).query_name, int(spos[k]) + 1, int(send[k]) + 1, bool(sflag[k] & 0x10), chrom])
+            t0 = time.time()
+            T["discordant select + rows"] += t0 - t6
+            continue
         primary = ok_contig & ((flag & 0x404) == 0) & ((flag & 0x900) == 0) & (b.mapq >= min_q)   # :171,:184,:188
         same_chr = b.mate_tid == tid
         abs_isize = numpy.abs(b.tlen.astype(numpy.int64))
@@ -183,21 +272,31 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         has_cigar = b.cigar_first != 0xffffffff
         left = (f_op == 4) & (f_len > min_clip_len) & (l_op == 0) & (l_len > min_anchor_len)
         right = (l_op == 4) & (l_len > min_clip_len) & (f_op == 0) & (f_len > min_anchor_len)
-        for i in numpy.flatnonzero(primary & (abs_isize < max_ins) & same_chr & has_cigar & (left | right)):
+        clip_idx = numpy.flatnonzero(primary & (abs_isize < max_ins) & same_chr & has_cigar & (left | right))
+        split_idx = numpy.flatnonzero(primary & (b.sa_off >= 0))
+        t4 = time.time()
+        T["field copies + predicates (host)"] += (t2 - t1) + (t4 - t3)
+        for i in clip_idx:
             rec = b.record(i)
             chrom = names[tid[i]]
             clips[chrom].append([">{}|{}|{}\n".format(rec.query_name, chrom, int(b.pos[i]) + 1), rec.query_sequence + "\n"])
+        t5 = time.time()
+        T["clip rows"] += t5 - t4
         # split reads (:199-202)
-        for i in numpy.flatnonzero(primary & (b.sa_off >= 0)):
+        for i in split_idx:
             chrom = names[tid[i]]
             split = SA_analysis(_ReadProxy(b, i), min_q, "SA", chrom)
             if split:
                 splits[chrom].append(split)
+        t6 = time.time()
+        T["split rows"] += t6 - t5
         # discordant pairs (:204-221): predicate + order-preserving compaction on the device
         for i in select_discordant(b, big, min_q, max_ins):
             chrom, mate = names[tid[i]], names[b.mate_tid[i]]
             chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
             data[chrom].append([chrA, chrB, b.record(i).query_name, int(b.pos[i]) + 1, int(b.end[i]) + 1, bool(flag[i] & 0x10), chrom])
+        t0 = time.time()
+        T["discordant select + rows"] += t0 - t6
     reader.close()
     chromosomes = [n for n, ok in zip(names, big) if ok]
     coverage = {n: hist.finish(n) for n in chromosomes}
@@ -207,6 +306,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
 
 _SCAN_CACHE = {}
 STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
+SCAN_SECONDS = {}           # ... and of the last scan_signals() pass, by what the host waited for
 
 
 def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bin_size, skip_index, min_anchor_len, min_clip_len):
@@ -235,6 +335,7 @@ def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_con
         bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
     STAGE_SECONDS.clear()
     STAGE_SECONDS["scan (ingest, coverage, predicates, rows)"] = time.time() - t
+    STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
     t1 = time.time()
     all_contigs = [c["SN"] for c in header["SQ"]]
     data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
