@@ -31,6 +31,29 @@ if REPO not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+TRAFFIC_NOTE = "HBM bytes per launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the committed build, gfx950 correction applied); not observed by this run"
+
+
+def profiled_traffic(kernel_prefix):
+    """bytes per launch of the kernel whose name starts with `kernel_prefix`, from the committed rocprofv3 PMC summary"""
+    tp = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        for k, v in json.load(open(tp))["kernels"].items():
+            if k.startswith(kernel_prefix):
+                return float(v["bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def parse():
@@ -138,13 +161,11 @@ def main():
     kern_ms = sum(kern_all) / len(kern_all)                                      # avg cov_accumulate launch (whole genome)
     alg_bytes_launch = 12.0 * total_reads + 8.0 * total_bins                     # 12 B/read + 8 B/bin
     achieved = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tp = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp)).get("cov_accumulate_bytes_per_read") * total_reads
-        except Exception:
-            traffic = None
+    traffic = profiled_traffic("cov_accumulate<true, 0")
+    if traffic is not None and world == 1:
+        traffic *= 1.0     # (the profile was taken on this very workload: 600 M reads per launch)
+    elif traffic is not None:
+        traffic *= total_reads / float(job_reads)
 
     result = {
         "metric": "cov bins/sec, 30x WGS synthetic (signals clustered/sec: see 'dbscan')",
@@ -160,7 +181,8 @@ def main():
                    "arithmetic": "int64 accumulation of the reference's float32 quotients at 2^-S fixed point (exact), float64 bins out"},
         "reads_per_sec": job_reads / (t_cov / args.steps),
         "roofline": {"bound": "hbm", "kernel": "cov_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kern_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": TRAFFIC_NOTE,
+                     "frac_traffic": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": kern_ms,
                      "median_launch_ms": kern_all[len(kern_all) // 2], "min_launch_ms": kern_all[0],
                      "algorithmic_bytes_per_launch": alg_bytes_launch},
     }
@@ -187,6 +209,29 @@ def main():
                                   "sample": "%d of %d contigs (%d reads, %d bins), oracle/tiddit_oracle.c scalar C port of the "
                                             "update_coverage loop, arrays in memory; bins verified bit-identical to the GPU's"
                                             % (k, C, sum(n_reads[:k]), sum(nbins[:k]))}
+        # the same port on ALL host cores (one contig per thread: contigs are independent; ctypes releases the GIL), every contig of
+        # the genome — which also verifies the remaining contigs against the GPU's bins
+        from concurrent.futures import ThreadPoolExecutor
+        host = [[t.cpu().numpy() for t in reads[c]] for c in range(C)]
+        ncores = os.cpu_count() or 1
+        nthreads = max(1, min(ncores, C))
+
+        def one(c):
+            s, e, mq, fl = host[c]
+            return oracle.coverage_stream(s, e, mq, fl.view(np.uint16), L, z, args.min_q)[0]
+
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(nthreads) as pool:
+            wants = list(pool.map(one, range(C)))
+        t_all = time.perf_counter() - t1
+        for c in range(C):
+            if not np.array_equal(outs[c].cpu().numpy(), wants[c]):
+                raise SystemExit("PARITY FAILURE: GPU bins of contig %d differ from the CPU oracle" % c)
+        del host, wants
+        result["cpu_baseline_all_cores"] = {"value": total_bins / t_all, "unit": "bins/s", "reads_per_sec": total_reads / t_all, "cores": nthreads,
+                                            "host_cores": ncores, "cpu_model": cpu_model(), "kind": "port",
+                                            "sample": "all %d contigs (%d reads), one contig per thread on %d threads; every contig's bins verified "
+                                                      "bit-identical to the GPU's" % (C, total_reads, nthreads)}
         result["parity_checked"] = True
     # host-buffer path (tdt_cov_push: pinned double-buffered hipMemcpyAsync + kernel), PCIe/host-memcpy bound;
     # reported for completeness, never the headline value
@@ -241,12 +286,17 @@ def main():
         sv_ms = sum(sv_all) / len(sv_all)
         sv_bytes = 12.0 * total_reads + 8.0 * sum(nb_sv)
         sv_ach = sv_bytes / (sv_ms * 1e-3) / 1e9
+        sv_traffic = profiled_traffic("cov_accumulate<true, 1")
+        if sv_traffic is not None:
+            sv_traffic *= total_reads / float(job_reads)
         svres = {"metric": "cov bins/sec, SV flavour (50-bp bins, q>=5)", "value": C_all * -(-L // zs) / (t_sv / args.steps), "unit": "bins/s",
                  "reads_per_sec": job_reads / (t_sv / args.steps), "ms_per_step": 1e3 * t_sv / args.steps,
                  "config": {"workload": "the same %d-read stream, %d-bp bins (%d bins), q>=%d filter: what `tiddit --sv` accumulates; contigs split over the rank(s)"
                                         % (job_reads, zs, C_all * -(-L // zs), qs_)},
                  "roofline": {"bound": "hbm", "kernel": "cov_accumulate (small-bin flavour)", "achieved": sv_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": sv_ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sv_ms, "median_launch_ms": sv_all[len(sv_all) // 2],
+                              "frac": sv_ach / HBM_PEAK_GBS, "traffic": sv_traffic, "traffic_source": TRAFFIC_NOTE,
+                              "frac_traffic": None if sv_traffic is None else sv_traffic / (sv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "avg_launch_ms": sv_ms, "median_launch_ms": sv_all[len(sv_all) // 2],
                               "min_launch_ms": sv_all[0], "algorithmic_bytes_per_launch": sv_bytes}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             import oracle
@@ -316,11 +366,14 @@ def main():
             t_db = float(tt.item())
         k_ms = sum(a.elapsed_time(b) for a, b in dev_ms) / len(dev_ms)
         db_ach = 16.0 * n / (k_ms * 1e-3) / 1e9
+        t1_, t2_ = profiled_traffic("dbt_tile<true, false>"), profiled_traffic("dbt_finish1")
+        db_traffic = None if t1_ is None or t2_ is None else t1_ + t2_
         dbres = {"metric": "signals clustered/sec", "value": n / (t_db / args.steps), "unit": "signals/s",
                  "ms_per_step": 1e3 * t_db / args.steps,
                  "config": {"workload": "BASELINE configs[2]: gen_points(%d) one chr pair, e=500 l=3, one GPU" % n},
                  "roofline": {"bound": "hbm", "kernel": "tdt_dbscan_device: dbt_tile + dbt_finish1 (2 launches)", "achieved": db_ach, "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": db_ach / HBM_PEAK_GBS, "traffic": None, "avg_pass_ms": k_ms,
+                              "unit": "GB/s", "frac": db_ach / HBM_PEAK_GBS, "traffic": db_traffic, "traffic_source": TRAFFIC_NOTE,
+                              "frac_traffic": None if db_traffic is None else db_traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_pass_ms": k_ms,
                               "algorithmic_bytes_per_pass": 16.0 * n}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             import oracle
@@ -439,11 +492,14 @@ def main():
             t_gc = float(tt.item())
         g_ms = sum(a.elapsed_time(b) for a, b in gev) / len(gev)
         g_ach = (G + G / 50.0) / (g_ms * 1e-3) / 1e9
+        g_traffic = profiled_traffic("gc_small_bins")
+        if g_traffic is not None:
+            g_traffic *= G / float(G_all)
         gres = {"metric": "gc bins/sec", "value": (G / 50.0) * world / (t_gc / args.steps), "unit": "bins/s",
                 "bases_per_sec": G * world / (t_gc / args.steps), "ms_per_step": 1e3 * t_gc / args.steps,
                 "config": {"workload": "GC/N-mask histogram, %d bases split over %d rank(s), 50-bp bins, n_cutoff 0.5" % (G * world, world)},
                 "roofline": {"bound": "hbm", "kernel": "gc_small_bins", "achieved": g_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": g_ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": g_ms,
+                             "frac": g_ach / HBM_PEAK_GBS, "traffic": g_traffic, "traffic_source": TRAFFIC_NOTE, "avg_launch_ms": g_ms,
                              "algorithmic_bytes_per_launch": G + G / 50.0}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             import oracle

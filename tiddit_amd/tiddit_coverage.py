@@ -180,13 +180,24 @@ def update_coverage_batch(ref_start, ref_end, mapq, flag, min_q, bin_size, cover
     (the float64 sum is exact).  Returns ``coverage_data`` like the reference.
     """
     LN = _contig_length(coverage_data, bin_size, end_bin_size)
-    h = CoverageHistogram([("c", LN)], bin_size)
+    key = (LN, int(bin_size))
+    h = _HIST_CACHE.get(key)          # one histogram object per (contig length, bin size): a per-read loop reuses it
+    if h is None:
+        if len(_HIST_CACHE) >= 8:
+            _HIST_CACHE.pop(next(iter(_HIST_CACHE))).close()
+        h = _HIST_CACHE[key] = CoverageHistogram([("c", LN)], bin_size)
     try:
+        h.reset()
         h.push(0, ref_start, ref_end, mapq, flag, min_q)
         coverage_data += h.finish(0)
-    finally:
+    except Exception:
+        _HIST_CACHE.pop(key, None)
         h.close()
+        raise
     return coverage_data
+
+
+_HIST_CACHE = {}
 
 
 def update_coverage(ref_start, ref_end, bin_size, coverage_data, end_bin_size):
