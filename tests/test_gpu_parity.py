@@ -696,3 +696,51 @@ def test_candidate_means_follow_define_variant(ctx):
                     g = got[(chrA, chrB, cid)]
                     same = lambda x, y: (x is None and y is None) or x == y or (x is not None and y is not None and np.isnan(x) and np.isnan(y))
                     assert same(g["avg_a"], avg_a) and same(g["avg_b"], avg_b) and same(g["covM"], covM), (chrA, chrB, cid, g, avg_a, avg_b, covM)
+
+
+@pytest.mark.parametrize("case", ["sparse", "deep", "long_sorted", "contig_end", "tiny_bins", "bin128", "forced_run_merged"])
+def test_coverage_small_bin_flavour_corners(cov, case, monkeypatch):
+    """the difference-pair flavour of cov_accumulate (bins <= 128 bp): streams that re-base the LDS window all the time, many
+    reads per bin, sorted reads far longer than the register path takes, reads piled on the contig's last bins, 2-bp and
+    128-bp bins; and the run-merged flavour forced onto 50-bp bins — all bit-identical to the per-read oracle"""
+    rng = np.random.default_rng(["sparse", "deep", "long_sorted", "contig_end", "tiny_bins", "bin128", "forced_run_merged"].index(case) + 40)
+    z, q = 50, 5
+    if case == "sparse":            # 0.2x: a tile of 1024 reads spans far more than the window
+        LN, n = 40_000_000, 60_000
+        start = np.sort(rng.integers(0, LN - 400, n))
+        span = rng.integers(1, 300, n)
+    elif case == "deep":            # 3000x on a short contig: hundreds of reads per bin
+        LN, n = 200_000, 4_000_000
+        start = np.sort(rng.integers(0, LN - 160, n))
+        span = rng.integers(100, 160, n)
+    elif case == "long_sorted":     # sorted long reads: 5 % beyond 256 bins, some beyond the whole window
+        LN, n = 30_000_000, 300_000
+        start = np.sort(rng.integers(0, LN - 1, n))
+        span = np.where(rng.random(n) < 0.05, rng.integers(12_000, 400_000, n), rng.integers(50, 12_900, n))
+    elif case == "contig_end":      # everything within the last few hundred bins, contig length not a multiple of the bin
+        LN, n = 1_000_037, 500_000
+        start = np.sort(rng.integers(LN - 20_000, LN - 1, n))
+        span = rng.integers(1, 3000, n)
+    elif case == "tiny_bins":
+        z, LN, n = 2, 300_001, 400_000
+        start = np.sort(rng.integers(0, LN - 1, n))
+        span = rng.integers(1, 700, n)
+    elif case == "bin128":
+        z, LN, n = 128, 9_000_001, 1_500_000
+        start = np.sort(rng.integers(0, LN - 1, n))
+        span = rng.integers(1, 500, n)
+    else:
+        monkeypatch.setenv("TIDDIT_COV_MODE", "0")
+        LN, n = 3_000_000, 600_000
+        start = np.sort(rng.integers(0, LN - 200, n))
+        span = rng.integers(1, 200, n)
+    end = np.minimum(start + span, LN)
+    mapq = rng.integers(0, 61, n).astype(np.uint8)
+    flag = np.where(rng.random(n) < 0.05, 0x400, 0).astype(np.uint16) | np.where(rng.random(n) < 0.02, 0x4, 0).astype(np.uint16)
+    want, kept = oracle.coverage_stream(start, end, mapq, flag, LN, z, q)
+    h = cov.CoverageHistogram([("c", LN)], z)
+    h.push("c", start, end, mapq, flag, q)
+    got = h.finish("c")
+    assert h.kept() == kept
+    h.close()
+    assert np.array_equal(got, want)
