@@ -77,6 +77,14 @@ int tdt_cov_push_device(tdt_cov *cov, int tid, const int32_t *d_start, const int
 int tdt_cov_push_device_multi(tdt_cov *cov, int n_items, const int *tids, const int32_t *const *d_start,
                               const int32_t *const *d_end, const uint8_t *const *d_mapq, const uint16_t *const *d_flag,
                               const size_t *n, int min_q);
+/* The same with PACKED records — 8 bytes per read instead of 11: low word = reference_start (int32), high word =
+ * span:24 | min(mapq,63):6 | unmapped(0x4):1 | duplicate(0x400):1, span = reference_end - reference_start (0xffffff: the true end
+ * is read from d_end[i], which may otherwise be NULL).  This is the layout a producer that already sits on the device (the ingest
+ * kernel) hands over; tdt_cov_pack_device converts the four arrays.  min_q > 63 is TDT_E_UNSUPPORTED here. */
+int tdt_cov_pack_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq, const uint16_t *d_flag, size_t n,
+                        uint64_t *d_packed);
+int tdt_cov_push_packed_device_multi(tdt_cov *cov, int n_items, const int *tids, const uint64_t *const *d_packed, const int32_t *const *d_end,
+                                     const size_t *n, int min_q);
 /* All contigs at once: d_out holds tdt_cov_total_bins doubles, contig tid starts at tdt_cov_offset(tid)
  * (contigs are padded to 16-byte boundaries). */
 int tdt_cov_total_bins(tdt_cov *cov, int64_t *total);
@@ -270,6 +278,8 @@ int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_t len, size
 int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t len);
 int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len);
 int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n);
+/* device pointer of the batch's PACKED coverage records (see tdt_cov_push_packed_device_multi), valid until the next push */
+int tdt_ingest_packed(tdt_ingest *g, const uint64_t **d_packed);
 int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 

@@ -744,3 +744,39 @@ def test_coverage_small_bin_flavour_corners(cov, case, monkeypatch):
     assert h.kept() == kept
     h.close()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("z,q", [(500, 20), (50, 5), (1, 0), (4096, 30)])
+def test_coverage_packed_records_equal_the_four_arrays(cov, ctx, z, q):
+    """8-byte packed records (start | span:24 mapq:6 unmapped dup): same bins and kept count as the start/end/mapq/flag arrays,
+    including reads >= 16 Mb that escape to the end array, mapq above 63 and every flag combination"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    contigs = [("a", 40_000_000), ("b", 1137), ("c", 2_000_003)]
+    h = cov.CoverageHistogram(contigs, z)
+    hp = cov.CoverageHistogram(contigs, z)
+    items, pitems, keep, want = [], [], [], {}
+    rng = np.random.default_rng(z)
+    for i, (name, LN) in enumerate(contigs):
+        s, e, mq, fl = synth.gen_reads(LN, 20 if LN > 2000 else 200, seed=70 + i)
+        mq = np.where(rng.random(len(mq)) < 0.05, rng.integers(64, 256, len(mq)), mq).astype(np.uint8)      # above the 6-bit field
+        if name == "a":                                                                                    # two reads of >= 16 Mb
+            e[5], e[len(e) // 2] = s[5] + 17_000_000, min(LN, s[len(e) // 2] + 16_777_215)
+        want[name], _ = oracle.coverage_stream(s, e, mq, fl, LN, z, q)
+        ts = [torch.from_numpy(s.astype(np.int32)).to(dev), torch.from_numpy(e.astype(np.int32)).to(dev),
+              torch.from_numpy(mq).to(dev), torch.from_numpy(fl.view(np.int16)).to(dev)]
+        pk = torch.empty(len(s), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        nat_check = __import__("tiddit_amd._native", fromlist=["check"]).check
+        nat_check(ctx.lib.tdt_cov_pack_device(ctx.handle, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), len(s), pk.data_ptr()))
+        keep += ts + [pk]
+        items.append((name, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), len(s)))
+        pitems.append((name, pk.data_ptr(), ts[1].data_ptr(), len(s)))
+    h.push_device_multi(items, q)
+    hp.push_packed_device_multi(pitems, q)
+    for name, _ in contigs:
+        a, b = h.finish(name), hp.finish(name)
+        assert np.array_equal(a, want[name]) and np.array_equal(b, want[name]), name
+    assert h.kept() == hp.kept()
+    h.close()
+    hp.close()

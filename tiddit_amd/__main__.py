@@ -89,10 +89,7 @@ def run_cov(args):
         import numpy
         for b in reader.batches():
             if isinstance(b, DeviceBatch):
-                d = b.dev
-                items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in b.runs if t >= 0]
-                if items:
-                    hist.push_device_multi(items, args.q)
+                hist.push_device_batch(b, args.q)
                 continue
             tid = b.tid
             edges = numpy.flatnonzero(numpy.diff(tid)) + 1
@@ -171,24 +168,29 @@ def run_sv(args, version):
     max_ins_len = 100000
     T = STAGE_SECONDS
     T.clear()
+    from .trace import stage
     t = time.time()
-    library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s)
+    with stage("tiddit: library statistics"):
+        library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s)
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
     T["library statistics"] = time.time() - t
 
     t = time.time()
-    coverage_data = tiddit_signal.main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
-                                       False, args.min_anchor_len, args.min_clip_len)
+    with stage("tiddit: signal extraction + coverage"):
+        coverage_data = tiddit_signal.main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
+                                           False, args.min_anchor_len, args.min_clip_len)
     print("extracted signals in:")
     print(t - time.time())
     T["signal extraction + coverage"] = time.time() - t
     T.update({"  " + k: v for k, v in tiddit_signal.STAGE_SECONDS.items()})
     t = time.time()
-    gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
+    with stage("tiddit: GC bins"):
+        gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
     T["GC bins"] = time.time() - t
     t = time.time()
-    library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,
-                                                        bam_header, gc_dictionary)
+    with stage("tiddit: ploidy"):
+        library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,
+                                                            bam_header, gc_dictionary)
     print("calculated coverage in:")
     print(time.time() - t)
     T["ploidy (masked medians)"] = time.time() - t
@@ -197,8 +199,9 @@ def run_sv(args, version):
     if not args.e:
         args.e = 50
     t = time.time()
-    sv_clusters = tiddit_cluster.main(prefix, contigs, contig_length, samples, library["mp"], args.e, args.l, max_ins_len, args.min_contig,
-                                      args.skip_assembly, args.r)
+    with stage("tiddit: clustering"):
+        sv_clusters = tiddit_cluster.main(prefix, contigs, contig_length, samples, library["mp"], args.e, args.l, max_ins_len, args.min_contig,
+                                          args.skip_assembly, args.r)
     print("generated clusters in")
     print(time.time() - t)
     T["clustering"] = time.time() - t

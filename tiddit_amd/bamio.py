@@ -594,6 +594,9 @@ class DeviceBamReader:
             ne = ctypes.c_size_t(0)
             _native.check(lib.tdt_ingest_edges(self._h, _native.ptr(edges), 1024, ctypes.byref(ne)))
             b = DeviceBatch(self, n.value, ptrs, raw_len.value, None)
+            pk = ctypes.c_void_p()
+            _native.check(lib.tdt_ingest_packed(self._h, ctypes.byref(pk)))
+            b.dev["packed"] = int(pk.value or 0)         # 8-byte coverage records (csrc/tdt_common.h: cov_pack_record)
             if ne.value == ctypes.c_size_t(-1).value:                   # not coordinate sorted: runs from the tid column
                 tid = b.tid
                 lo = np.concatenate([[0], np.flatnonzero(np.diff(tid)) + 1])

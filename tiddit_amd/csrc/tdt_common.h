@@ -57,6 +57,18 @@ static inline int tdt_ceil_log2_u64(uint64_t v) {
     return l;
 }
 
+// ---- packed alignment record of the coverage path (8 B instead of 11), written by the ingest kernel next to the field arrays:
+//   low word  = reference_start (int32)
+//   high word = span:24 | min(mapq,63):6 | unmapped(0x4):1 | duplicate(0x400):1     span = reference_end - reference_start;
+//               span 0xffffff = escape: the true end is read from the `end` array (reads spanning >= 16 Mb)
+#define COV_PK_SPAN 0xffffffu
+__host__ __device__ __forceinline__ unsigned long long cov_pack_record(int start, int end, unsigned mapq, unsigned flag) {
+    const long long span = (long long)end - (long long)start;
+    const unsigned sp = (span < 0 || span >= (long long)COV_PK_SPAN) ? COV_PK_SPAN : (unsigned)span;
+    const unsigned info = sp | ((mapq > 63u ? 63u : mapq) << 24) | ((flag & 0x4u) ? 1u << 30 : 0u) | ((flag & 0x400u) ? 1u << 31 : 0u);
+    return ((unsigned long long)info << 32) | (unsigned)start;
+}
+
 // ---- BGZF block table shared by the host scan (tdt_bgzf.hip), the device inflate (tdt_inflate.hip) and the ingest (tdt_ingest.hip)
 struct BzDesc {
     unsigned long long in_off, out_off;   // payload offset in the compressed buffer, block offset in the output

@@ -43,6 +43,7 @@ struct CovItem {
     const int32_t *end;
     const uint8_t *mapq;
     const uint16_t *flag;
+    const unsigned long long *packed;    // packed 8-byte records instead of the four arrays (`end` then only serves escapes; may be null)
     unsigned long long n;
     unsigned long long *acc;             // this contig's accumulators
     const unsigned long long *lut_end;   // [bin_size+1] fixed-point float32(b)/float32(end_bin_size)
@@ -166,6 +167,39 @@ __device__ __forceinline__ CovTile<RPL> cov_load(const CovItem &P, unsigned long
     return t;
 }
 
+// Packed alignment record (8 B instead of 11): what the ingest kernel can write next to the field arrays.
+//   low word  = reference_start (int32)
+//   high word = span:24 | min(mapq,63):6 | unmapped(0x4):1 | duplicate(0x400):1     span = reference_end - reference_start;
+//               span 0xffffff = escape: the true end is read from the `end` array (reads spanning >= 16 Mb)
+template <int RPL>
+struct CovTileP {
+    unsigned long long w[RPL];
+};
+
+template <int RPL>
+__device__ __forceinline__ CovTileP<RPL> cov_load_packed(const CovItem &P, unsigned long long idx, unsigned long long r1) {
+    CovTileP<RPL> t;
+    if (P.aligned && idx + RPL <= r1) {
+#pragma unroll
+        for (int k = 0; k < RPL / 2; k++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(P.packed + idx + 2 * k);
+            t.w[2 * k] = v.x;
+            t.w[2 * k + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RPL; j++) t.w[j] = idx + j < r1 ? P.packed[idx + j] : (1ull << 62);   // padding lanes look unmapped
+    }
+    return t;
+}
+
+__global__ void cov_pack(const int32_t *__restrict__ start, const int32_t *__restrict__ end, const uint8_t *__restrict__ mapq,
+                         const uint16_t *__restrict__ flag, unsigned long long n, unsigned long long *__restrict__ out) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = cov_pack_record(start[i], end[i], mapq[i], flag[i]);
+}
+
 // MODE 0 (many reads per bin, e.g. --cov at 500 bp): contributions to bins K, K+1, K+2 are folded into three
 //   registers per lane and merged across the wave by a prefix scan over runs of equal K.
 // MODE 1 (few reads per bin, e.g. --sv at 50 bp, where a 150-bp read covers 3-5 bins and neighbouring lanes hardly
@@ -190,7 +224,7 @@ __device__ __forceinline__ CovTile<RPL> cov_load(const CovItem &P, unsigned long
 #ifndef COV_MIN_WAVES1
 #define COV_MIN_WAVES1 4                           // ... MODE 1
 #endif
-template <bool LDS_LUT, int MODE, bool Z1, int RPL>
+template <bool LDS_LUT, int MODE, bool Z1, int RPL, bool PACKED>
 __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_WAVES) void cov_accumulate(CovParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
     // everything lives in the dynamic region (a static __shared__ in front of it would shift its
@@ -226,7 +260,11 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
     auto div = [&](int x) { return Z1 ? x : (int)(__umulhi((unsigned)x, P.magic) >> P.shift); };
 
     // first tile's loads go out before the LDS set-up
-    CovTile<RPL> cur = cov_load<RPL>(I, r0 + (unsigned long long)tid * RPL, r1);
+    auto load_tile = [&](unsigned long long idx) {
+        if constexpr (PACKED) return cov_load_packed<RPL>(I, idx, r1);
+        else return cov_load<RPL>(I, idx, r1);
+    };
+    auto cur = load_tile(r0 + (unsigned long long)tid * RPL);
 
     for (int i = tid; i < WIN + 2; i += COV_THREADS) win[i] = 0;
     if (LDS_LUT) {
@@ -248,7 +286,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
     }
     // window base: the bin of the chunk's first read; every thread derives it from the same (scalar) load
     auto bin_of_read = [&](unsigned long long idx) {
-        int s = I.start[idx];
+        int s = PACKED ? (int)(unsigned)I.packed[idx] : I.start[idx];
         s = s < 0 ? 0 : s;
         const int b = div(s);
         return b < I.nbins ? b : I.nbins - 1;
@@ -332,8 +370,8 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
 
     for (unsigned long long t0 = r0; t0 < r1; t0 += TILE) {
         // software prefetch: the next tile's loads are in flight while this one is reduced
-        CovTile<RPL> nxt = cur;
-        if (t0 + TILE < r1) nxt = cov_load<RPL>(I, t0 + TILE + (unsigned long long)tid * RPL, r1);
+        auto nxt = cur;
+        if (t0 + TILE < r1) nxt = load_tile(t0 + TILE + (unsigned long long)tid * RPL);
 
         // window re-base (block-uniform): when this tile's last read starts near the window's end the window is spilled
         // and moved to the previous tile's last read, so sparse streams / small bins stay on the LDS path
@@ -351,12 +389,32 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
 
         int sv[RPL], ev[RPL];
         unsigned mq[RPL], fl[RPL];
+        constexpr unsigned FMASK = PACKED ? 0x3u : 0x404u;       // unmapped / duplicate bits of fl[]
+        if constexpr (PACKED) {
+            bool esc = false;
 #pragma unroll
-        for (int j = 0; j < RPL; j++) {
-            sv[j] = cur.s[j];
-            ev[j] = cur.e[j];
-            mq[j] = (cur.mq[j / 4] >> (8 * (j & 3))) & 0xffu;
-            fl[j] = (cur.fl[j / 2] >> (16 * (j & 1))) & 0xffffu;
+            for (int j = 0; j < RPL; j++) {
+                const unsigned info = (unsigned)(cur.w[j] >> 32);
+                sv[j] = (int)(unsigned)cur.w[j];
+                ev[j] = sv[j] + (int)(info & COV_PK_SPAN);
+                mq[j] = (info >> 24) & 63u;
+                fl[j] = info >> 30;
+                esc = esc || (info & COV_PK_SPAN) == COV_PK_SPAN;
+            }
+            if (esc) {                                            // reads of >= 16 Mb: the end array has the truth
+                const unsigned long long idx = t0 + (unsigned long long)tid * RPL;
+#pragma unroll
+                for (int j = 0; j < RPL; j++)
+                    if (((unsigned)(cur.w[j] >> 32) & COV_PK_SPAN) == COV_PK_SPAN) ev[j] = (I.end && idx + j < r1) ? I.end[idx + j] : sv[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPL; j++) {
+                sv[j] = cur.s[j];
+                ev[j] = cur.e[j];
+                mq[j] = (cur.mq[j / 4] >> (8 * (j & 3))) & 0xffu;
+                fl[j] = (cur.fl[j / 2] >> (16 * (j & 1))) & 0xffffu;
+            }
         }
 
         // lane key K: first bin of the lane's first read (one division).  Any K is correct; sorted
@@ -378,7 +436,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 const int s = sv[j], e = ev[j];
-                bool keep = !(fl[j] & 0x404u) && (int)mq[j] >= P.min_q;   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+                bool keep = !(fl[j] & FMASK) && (int)mq[j] >= P.min_q;   // __main__.py:231-235 / tiddit_signal.pyx:171-181
                 const bool invalid = keep && (s < 0 || e <= s);
                 const unsigned rs = (unsigned)s - Kz;        // offsets from the start of bin K
                 const unsigned re = (unsigned)(e - 1) - Kz;
@@ -443,7 +501,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
                 const unsigned rs = (unsigned)sv[j] - Kz;    // offsets from the start of bin K: first base, one past the last base
                 const unsigned re1 = (unsigned)ev[j] - Kz;
                 const unsigned len = re1 - rs;               // e - s (wraps to a huge value when e <= s)
-                const bool cand = ((fl[j] & 0x404u) == 0) & ((int)mq[j] >= P.min_q);   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+                const bool cand = ((fl[j] & FMASK) == 0) & ((int)mq[j] >= P.min_q);   // __main__.py:231-235 / tiddit_signal.pyx:171-181
                 // window path: first bin K or K+1, at most xmax bases past the start of bin K (so the 24-bit multiply below
                 // is an exact division and the last bin is at most K + COV_DQMAX)
                 const bool fast = cand & safe & (rs < 2u * z) & (len - 1u < P.xmax) & (re1 <= P.xmax);
@@ -713,6 +771,7 @@ static CovItem cov_item(tdt_cov *c, int tid, const int32_t *d_start, const int32
     it.end = d_end;
     it.mapq = d_mapq;
     it.flag = d_flag;
+    it.packed = nullptr;
     it.n = n;
     it.acc = c->d_acc + c->off[tid];
     it.lut_end = c->d_lut_end + (size_t)tid * ((size_t)c->bin_size + 1);
@@ -721,6 +780,13 @@ static CovItem cov_item(tdt_cov *c, int tid, const int32_t *d_start, const int32
                  ((uintptr_t)d_flag & (2 * COV_RPL - 1)) == 0;
     it.first_block = 0;
     it.pad_ = 0;
+    return it;
+}
+
+static CovItem cov_item_packed(tdt_cov *c, int tid, const unsigned long long *d_packed, const int32_t *d_end, size_t n) {
+    CovItem it = cov_item(c, tid, nullptr, d_end, nullptr, nullptr, n);
+    it.packed = d_packed;
+    it.aligned = ((uintptr_t)d_packed & 15) == 0;
     return it;
 }
 
@@ -746,14 +812,23 @@ static int cov_launch_items(tdt_cov *c, const CovItem &single, const CovItem *d_
     const size_t lds = 96 + ((size_t)(small ? COV_WIN1 : COV_WIN) + 2) * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0) +
                        (small ? (3 * ((size_t)c->bin_size + 1) + 1) * 8 : 0);
     // small bins: few reads share a bin, a read covers several -> difference-pair kernel
-    if (small)
-        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    const bool packed = single.packed != nullptr;
+    if (small && packed)
+        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (small)
+        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (lds_lut && c->shift >= 0 && packed)
+        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (lds_lut && c->shift >= 0)
-        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (lds_lut && packed)
+        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (lds_lut)
-        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (packed)
+        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else
-        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     TDT_CHECK_LAUNCH();
     return TDT_OK;
 }
@@ -795,6 +870,58 @@ extern "C" int tdt_cov_push_device_multi(tdt_cov *c, int n_items, const int *tid
     int rc = tdt_scratch(c->ctx, 7, items.size() * sizeof(CovItem), &d_items);
     if (rc) return rc;
     // pageable source: the runtime stages it before returning, so `items` may go out of scope
+    TDT_HIP(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(CovItem), hipMemcpyHostToDevice, c->ctx->stream));
+    return cov_launch_items(c, items[0], (const CovItem *)d_items, (int)items.size(), (unsigned)blocks, min_q);
+}
+
+extern "C" int tdt_cov_pack_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq, const uint16_t *d_flag,
+                                   size_t n, uint64_t *d_packed) {
+    if (!ctx || (n && (!d_start || !d_end || !d_mapq || !d_flag || !d_packed))) {
+        tdt_set_error("tdt_cov_pack_device: bad argument");
+        return TDT_E_ARG;
+    }
+    if (!n) return TDT_OK;
+    TDT_HIP(hipSetDevice(ctx->device));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(cov_pack, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_start, d_end, d_mapq, d_flag, (unsigned long long)n,
+                       (unsigned long long *)d_packed);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_push_packed_device_multi(tdt_cov *c, int n_items, const int *tids, const uint64_t *const *d_packed,
+                                                const int32_t *const *d_end, const size_t *n, int min_q) {
+    if (!c || n_items < 0 || (n_items && (!tids || !d_packed || !n))) {
+        tdt_set_error("tdt_cov_push_packed_device_multi: bad argument");
+        return TDT_E_ARG;
+    }
+    if (min_q > 63) {
+        tdt_set_error("tdt_cov_push_packed_device_multi: packed records keep min(mapq, 63); min_q %d needs the unpacked entry point", min_q);
+        return TDT_E_UNSUPPORTED;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    std::vector<CovItem> items;
+    unsigned long long blocks = 0;
+    for (int i = 0; i < n_items; i++) {
+        if (tids[i] < 0 || tids[i] >= c->n_contigs || (n[i] && !d_packed[i])) {
+            tdt_set_error("tdt_cov_push_packed_device_multi: bad item %d", i);
+            return TDT_E_ARG;
+        }
+        if (n[i] == 0 || c->nbins[tids[i]] == 0) continue;
+        CovItem it = cov_item_packed(c, tids[i], (const unsigned long long *)d_packed[i], d_end ? d_end[i] : nullptr, n[i]);
+        it.first_block = (unsigned)blocks;
+        blocks += (n[i] + COV_READS_PER_BLOCK - 1) / COV_READS_PER_BLOCK;
+        items.push_back(it);
+    }
+    if (items.empty()) return TDT_OK;
+    if (blocks >= 0x7fffffffull) {
+        tdt_set_error("tdt_cov_push_packed_device_multi: too many reads for one launch");
+        return TDT_E_ARG;
+    }
+    void *d_items = nullptr;
+    int rc = tdt_scratch(c->ctx, 7, items.size() * sizeof(CovItem), &d_items);
+    if (rc) return rc;
     TDT_HIP(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(CovItem), hipMemcpyHostToDevice, c->ctx->stream));
     return cov_launch_items(c, items[0], (const CovItem *)d_items, (int)items.size(), (unsigned)blocks, min_q);
 }

@@ -133,6 +133,7 @@ struct IngestOut {
     uint32_t *cigar_first, *cigar_last;
     uint64_t *rec_off;
     int64_t *sa_off;
+    unsigned long long *packed;      // cov_pack_record of (pos, end, mapq, flag): what the coverage kernels read
 };
 
 __device__ __forceinline__ long long aux_value_size(unsigned char t, const unsigned char *p, const unsigned char *end) {
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(64) void bam_decode_fields(const unsigned char *__r
         O.end[i] = (int)(pos + rlen);
         O.mapq[i] = r[9];
         O.flag[i] = (uint16_t)fl;
+        O.packed[i] = cov_pack_record(pos, (int)(pos + rlen), r[9], fl);
         O.mate_tid[i] = (int)ld_u32(r + 20);
         O.mate_pos[i] = (int)ld_u32(r + 24);
         O.tlen[i] = (int)ld_u32(r + 28);
@@ -528,12 +530,13 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     if (n) {
         const size_t N = n;
         const size_t a4 = (N * 4 + 255) & ~(size_t)255, a2 = (N * 2 + 255) & ~(size_t)255, a1 = (N + 255) & ~(size_t)255, a8 = (N * 8 + 255) & ~(size_t)255;
-        rc = ing_grow(g, g->soa, 9 * a4 + a2 + a1 + 2 * a8 + 4096);
+        rc = ing_grow(g, g->soa, 9 * a4 + a2 + a1 + 3 * a8 + 4096);
         if (rc) return rc;
         char *p = (char *)g->soa.p;
         IngestOut &O = g->O;
         O.rec_off = (uint64_t *)p; p += a8;
         O.sa_off = (int64_t *)p; p += a8;
+        O.packed = (unsigned long long *)p; p += a8;
         O.tid = (int32_t *)p; p += a4;
         O.pos = (int32_t *)p; p += a4;
         O.end = (int32_t *)p; p += a4;
@@ -590,6 +593,16 @@ extern "C" int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_
                          O.sa_off, g->out.p};
     for (int i = 0; i < 14; i++) out14[i] = g->n_records || i == 13 ? p[i] : nullptr;
     if (raw_len) *raw_len = g->out_len;
+    return TDT_OK;
+}
+
+// the packed coverage records of the current batch (tdt_cov_push_packed_device_multi reads them; `end` serves its escapes)
+extern "C" int tdt_ingest_packed(tdt_ingest *g, const uint64_t **d_packed) {
+    if (!g || !d_packed) {
+        tdt_set_error("tdt_ingest_packed: bad argument");
+        return TDT_E_ARG;
+    }
+    *d_packed = g->n_records ? (const uint64_t *)g->O.packed : nullptr;
     return TDT_OK;
 }
 

@@ -132,10 +132,7 @@ def coverage_sharded(bam_file_name, bin_size, min_q, group=None, ctx=None, chunk
     hist = tiddit_coverage.CoverageHistogram(header, bin_size, ctx=ctx)
     n = 0
     for b in reader.batches():
-        d = b.dev
-        items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in b.runs if t >= 0]
-        if items:
-            hist.push_device_multi(items, min_q)
+        hist.push_device_batch(b, min_q)
         n += len(b)
     empty = reader.first_off is None
     first_off, next_off = reader.first_off, reader.next_off

@@ -126,6 +126,28 @@ class CoverageHistogram:
         _native.check(self.lib.tdt_cov_push_device_multi(self.handle, k, _native.ptr(tids), _native.ptr(ptrs[0]), _native.ptr(ptrs[1]),
                                                          _native.ptr(ptrs[2]), _native.ptr(ptrs[3]), _native.ptr(ns), int(min_q)))
 
+    def push_packed_device_multi(self, items, min_q):
+        """items: list of (contig, d_packed, d_end or 0, n): 8-byte packed records (tdt_cov_pack_device / the ingest kernel) — ONE launch."""
+        k = len(items)
+        tids = numpy.array([self._tid(it[0]) for it in items], dtype=numpy.int32)
+        pk = numpy.array([it[1] for it in items], dtype=numpy.uint64)
+        en = numpy.array([it[2] or 0 for it in items], dtype=numpy.uint64)
+        ns = numpy.array([it[3] for it in items], dtype=numpy.uint64)
+        _native.check(self.lib.tdt_cov_push_packed_device_multi(self.handle, k, _native.ptr(tids), _native.ptr(pk), _native.ptr(en), _native.ptr(ns),
+                                                                int(min_q)))
+
+    def push_device_batch(self, batch, min_q, want=None):
+        """every per-contig run of a DeviceBatch (bamio.DeviceBamReader) in ONE launch, through the 8-byte packed records the
+        ingest kernel wrote when min_q fits their 6-bit mapq field; want[tid] false skips a contig"""
+        d = batch.dev
+        runs = [(t, lo, hi) for t, lo, hi in batch.runs if t >= 0 and (want is None or want[t])]
+        if not runs:
+            return
+        if d.get("packed") and int(min_q) <= 63:
+            self.push_packed_device_multi([(t, d["packed"] + 8 * lo, d["end"] + 4 * lo, hi - lo) for t, lo, hi in runs], min_q)
+        else:
+            self.push_device_multi([(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in runs], min_q)
+
     def total_bins(self):
         t = ctypes.c_int64()
         _native.check(self.lib.tdt_cov_total_bins(self.handle, ctypes.byref(t)))

@@ -221,11 +221,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         t2 = time.time()
         # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
         if isinstance(b, DeviceBatch):                      # the decoded arrays are already in HBM
-            d = b.dev
-            items = [(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo)
-                     for t, lo, hi in b.runs if t >= 0 and big[t]]
-            if items:
-                hist.push_device_multi(items, min_q)
+            hist.push_device_batch(b, min_q, big)
         else:
             edges = numpy.flatnonzero(numpy.diff(tid)) + 1
             for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
