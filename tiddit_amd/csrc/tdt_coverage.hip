@@ -272,6 +272,14 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
             const unsigned long long v = P.lut_main[i];
             lutS[i] = v;
             lutS[i + z + 1] = I.lut_end[i];
+            if (MODE == 0 && !Z1) {
+                // pairA[i] = (v, 0), pairB[i] = (0, v) as 16-byte entries (see the tabled loop below)
+                unsigned long long *pr = lutS + 2 * (z + 1);
+                pr[2 * i] = v;
+                pr[2 * i + 1] = 0;
+                pr[2 * (z + 1) + 2 * i] = 0;
+                pr[2 * (z + 1) + 2 * i + 1] = v;
+            }
             if (MODE == 1) {
                 // tabA[i] = (v, 0), tabB[i] = (0, v): one 8-byte read yields the first-bin partial already routed to
                 // bin K (first word) or K+1 (second word); tabL[i] = v - 2^48: the last bin's partial with its -1;
@@ -429,7 +437,71 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
         continue;
 #endif
         unsigned slowmask = 0;
-        if (MODE == 0) {
+        constexpr bool TABLED = MODE == 0 && LDS_LUT && !Z1;      // MODE 0 with the pair tables in LDS (2 <= bin_size < 1024)
+        if (TABLED) {
+            // A read whose first bin is K or K+1 and whose last bin is at most one further is folded into the three registers a0,a1,a2
+            // (bins K, K+1, K+2).  Its two quotients come from 16-byte table entries that already carry the routing: pairA[i] = (v, 0),
+            // pairB[i] = (0, v); the first-bin entry adds (to K, to K+1), the last-bin entry one bin further (to K+1, to K+2); entry 0 is
+            // (0, 0), so a read that does not take this path selects it and adds nothing — no predicate outlives its read (the
+            // compare-and-select form of this loop kept eight reads' masks alive and spilled them with v_writelane).  Lanes whose bins
+            // K..K+2 leave the window or touch the contig's last bin (other denominator, :66-69) send all their reads down the literal path.
+            const ulonglong2 *pair = reinterpret_cast<const ulonglong2 *>(lutS + 2 * (z + 1));
+            const unsigned ko = (unsigned)(K - base);
+            const bool safe = ko < (unsigned)(WIN - 3) && K + 3 <= last_bin;
+            const unsigned kw = safe ? ko : 0u;
+            const unsigned z3 = 3u * z;
+#pragma unroll
+            for (int j = 0; j < RPL; j++) {
+                const unsigned rs = (unsigned)sv[j] - Kz;    // offsets from the start of bin K: first base, one past the last base
+                const unsigned re1 = (unsigned)ev[j] - Kz;
+                const unsigned len = re1 - rs;               // e - s (wraps to a huge value when e <= s)
+                const bool cand = ((fl[j] & FMASK) == 0) & ((int)mq[j] >= P.min_q);   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+                const bool r1_ = rs >= z;                    // first bin = K + 1
+                const unsigned dq = (__umul24(re1, P.m15) - P.m15) >> P.k15;     // (e - 1 - K z) / z, exact for e - 1 - K z < 2^15
+                const unsigned r = r1_ ? 1u : 0u;
+                const bool fast = cand & safe & (rs < 2u * z) & (len - 1u < z3) & (re1 <= z3) & (dq - r <= 1u);
+                nkept += fast ? 1u : 0u;
+                slowmask |= (cand & !fast) ? (1u << j) : 0u;
+                const bool multi = fast & (dq != r);
+                const unsigned bf = min(len, (r1_ ? 2u * z : z) - rs);          // bases in the first bin (:55 / :61)
+                const unsigned sect = r1_ ? z + 1u : 0u;
+                const ulonglong2 X = pair[(fast ? bf : 0u) + sect];
+                const unsigned bl1 = re1 - __umul24(dq, z);                      // bases in the last bin + 1 (:63 counts one short)
+                const ulonglong2 Y = pair[(multi ? bl1 - 1u : 0u) + sect];
+                a0 += X.x;
+                a1 += X.y + Y.x;
+                a2 += Y.y;
+            }
+            if (slowmask) {
+#pragma unroll
+                for (int j = 0; j < RPL; j++)
+                    if (slowmask & (1u << j)) {
+                        const int s_ = sv[j], e_ = ev[j];
+                        if (s_ < 0 || e_ <= s_ || div(e_ - 1) > last_bin) bad = true;
+                        else { nkept++; slow_read(s_, e_); }
+                    }
+            }
+            // wavefront merge: inclusive prefix sums of the three registers; a run [a..b] of equal K sums to P[b] - P[a-1], so run-tail
+            // lanes add +P[b] and run-head lanes add -P[a-1] (two's complement).  Only lanes on the window path carry sums, and a run
+            // shares K, hence `safe`.
+            wave_scan3_u64(a0, a1, a2);
+            const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
+            const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
+            const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(a0), q1 = dpp_u64<DPP_WAVE_SHR1>(a1), q2 = dpp_u64<DPP_WAVE_SHR1>(a2);
+#ifndef COV_EXP_NOATOMIC
+            if (safe && Knext != K) {  // run tail (lane 63 always: it reads ~K)
+                if (a0) atomicAdd(&win[kw], a0);
+                if (a1) atomicAdd(&win[kw + 1], a1);
+                if (a2) atomicAdd(&win[kw + 2], a2);
+            }
+            if (safe && Kprev != K && lane != 0) {  // run head
+                if (q0) atomicAdd(&win[kw], 0ull - q0);
+                if (q1) atomicAdd(&win[kw + 1], 0ull - q1);
+                if (q2) atomicAdd(&win[kw + 2], 0ull - q2);
+            }
+#endif
+        } else if (MODE == 0) {
+            // (bin_size 1, or >= 1024 with the tables in global memory) compare-and-select form of the same folding:
             // A read whose first bin is K or K+1 and whose last bin is at most one further is folded into the three
             // registers a0,a1,a2 (bins K, K+1, K+2) without branches; anything else (reads spanning more bins,
             // unsorted input) is flagged and replayed literally below.
@@ -629,12 +701,13 @@ extern "C" int tdt_cov_create(tdt_ctx *ctx, const int64_t *contig_len, int n_con
         const bool can = bin_size >= 2 && c->S <= 31;
         c->small_bins = can;
         if (env && env[0] == '0') c->small_bins = false;
-        if (can) {
+        if (bin_size >= 2 && bin_size + 1 <= COV_LUT_LDS_MAX) {
+            // floor(x / bin_size) == (x * m15) >> k15 for 0 <= x < 2^15 with a 24-bit multiply (the product stays below 2^31)
             c->k15 = 15 + L;
             c->m15 = (unsigned)(((1ull << c->k15) + (unsigned)bin_size - 1) / (unsigned)bin_size);
             const unsigned lim = (unsigned)COV_DQMAX * (unsigned)bin_size;
             c->xmax = lim < 32768u ? lim : 32768u;
-            for (unsigned x = 0; x < c->xmax; x++)
+            for (unsigned x = 0; x < 32768u; x++)
                 if (((x * c->m15) >> c->k15) != x / (unsigned)bin_size) {
                     tdt_set_error("internal: 24-bit division self-check failed for d=%d x=%u", bin_size, x);
                     delete c;
@@ -810,7 +883,7 @@ static int cov_launch_items(tdt_cov *c, const CovItem &single, const CovItem *d_
     P.k15 = c->k15;
     const bool lds_lut = c->bin_size + 1 <= COV_LUT_LDS_MAX;
     const size_t lds = 96 + ((size_t)(small ? COV_WIN1 : COV_WIN) + 2) * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0) +
-                       (small ? (3 * ((size_t)c->bin_size + 1) + 1) * 8 : 0);
+                       (small ? (3 * ((size_t)c->bin_size + 1) + 1) * 8 : 0) + ((!small && lds_lut && c->shift >= 0) ? 4 * ((size_t)c->bin_size + 1) * 8 : 0);
     // small bins: few reads share a bin, a read covers several -> difference-pair kernel
     const bool packed = single.packed != nullptr;
     if (small && packed)
