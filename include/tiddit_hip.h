@@ -296,6 +296,14 @@ int tdt_bam_decode(const uint8_t *buf, size_t len, size_t max_records, size_t *c
                    int32_t *mate_pos, int32_t *tlen, int32_t *l_seq, uint32_t *cigar_first, uint32_t *cigar_last,
                    uint64_t *rec_off, int64_t *sa_off);
 
+/* ---- library statistics (host) ------------------------------------------------------------------------ *
+ * The sampling loop of tiddit_stats.statistics (tiddit_stats.py:17-47) over decoded field arrays: state[0] n_sampled, [1] sum of read
+ * lengths, [2] read lengths counted, [3] innie, [4] outtie, [5] done (n_sampled > n_reads) carry over from batch to batch (zero them
+ * first); the template lengths of the pairs that pass every test are appended to out_tlen (room for n), *n_out = how many. */
+int tdt_stats_scan(const int32_t *tid, const int32_t *pos, const int32_t *mate_tid, const int32_t *mate_pos, const int32_t *tlen,
+                   const int32_t *l_seq, const uint16_t *flag, const uint8_t *mapq, size_t n, int64_t n_reads, int min_mapq,
+                   int64_t max_ins_len, int64_t *state, int32_t *out_tlen, size_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,7 @@ SYMBOLS = {
     "tdt_ingest_edges": (_i, [_P, _P, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "tdt_copy_to_host": (_i, [_P, _P, _P, _sz]),
+    "tdt_stats_scan": (_i, [_P] * 8 + [_sz, _i64, _i, _i64, _P, _P, ctypes.POINTER(_sz)]),
     "tdt_bam_decode": (_i, [_P, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)] + [_P] * 13),
 }
 

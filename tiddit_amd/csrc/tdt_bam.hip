@@ -147,3 +147,40 @@ extern "C" int tdt_bam_decode(const uint8_t *buf, size_t len, size_t max_records
     *n_records = n;
     return TDT_OK;
 }
+
+// ---- library statistics: the sampling loop of tiddit_stats.statistics (tiddit_stats.py:17-47) over decoded field arrays (host).
+// state[0] n_sampled, [1] sum of read lengths, [2] read lengths counted, [3] innie, [4] outtie, [5] done (n_sampled > n_reads).
+// Insert sizes of the pairs that pass every test are appended to out_tlen (room for n), *n_out = how many.
+extern "C" int tdt_stats_scan(const int32_t *tid, const int32_t *pos, const int32_t *mate_tid, const int32_t *mate_pos, const int32_t *tlen,
+                              const int32_t *l_seq, const uint16_t *flag, const uint8_t *mapq, size_t n, int64_t n_reads, int min_mapq,
+                              int64_t max_ins_len, int64_t *state, int32_t *out_tlen, size_t *n_out) {
+    if (!state || !n_out || (n && (!tid || !pos || !mate_tid || !mate_pos || !tlen || !l_seq || !flag || !mapq || !out_tlen))) {
+        tdt_set_error("tdt_stats_scan: bad argument");
+        return TDT_E_ARG;
+    }
+    size_t k = 0;
+    int64_t sampled = state[0], sum_len = state[1], n_len = state[2], innie = state[3], outtie = state[4];
+    bool done = state[5] != 0;
+    for (size_t i = 0; i < n && !done; i++) {
+        if (tid[i] < 0) continue;                                   // samfile.fetch() skips the unplaced tail (:17)
+        sum_len += l_seq[i];                                        // read_length.append(read.query_length) (:19)
+        n_len++;
+        sampled++;
+        if (sampled > n_reads) {                                    // :22-23
+            done = true;
+            break;
+        }
+        const unsigned f = flag[i];
+        if (f & 0x8u) continue;                                     // mate_is_unmapped (:25)
+        if (((f & 0x10u) != 0) == ((f & 0x20u) != 0)) continue;      // is_reverse == mate_is_reverse (:28)
+        if (mate_tid[i] != tid[i] || (int64_t)tlen[i] > max_ins_len) continue;   // (:31)
+        if (mate_pos[i] < pos[i]) continue;                         // (:34)
+        if ((f & 0xd00u) || (int)mapq[i] < min_mapq) continue;      // supplementary / secondary / duplicate / mapq (:37)
+        out_tlen[k++] = tlen[i];                                    // (:40)
+        if ((f & 0x10u) && !(f & 0x20u)) outtie++;                  // (:42-45)
+        else innie++;
+    }
+    state[0] = sampled; state[1] = sum_len; state[2] = n_len; state[3] = innie; state[4] = outtie; state[5] = done ? 1 : 0;
+    *n_out = k;
+    return TDT_OK;
+}

@@ -3,8 +3,11 @@ first ``n_reads`` placed alignments — mean read length, insert-size mean / std
 the pair-orientation vote.  Same sampling rules, evaluated on the decoded arrays instead of per read."""
 import time
 
+import ctypes
+
 import numpy
 
+from . import _native
 from .bamio import open_bam
 
 
@@ -12,33 +15,26 @@ def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     library = {}
     t = time.time()
     reader = open_bam(bam_file_name)
-    read_length, insert_size = [], []
-    is_innie = is_outtie = 0
-    n_sampled = 0
+    lib = _native.load()
+    state = numpy.zeros(6, dtype=numpy.int64)
+    chunks = []
     for b in reader.batches():
-        placed = numpy.flatnonzero(b.tid >= 0)            # samfile.fetch() skips the unplaced tail (:17)
-        room = n_reads + 1 - n_sampled                    # the read that trips `n_sampled > n_reads` still adds its length (:19-23)
-        take = placed[:room]
-        read_length.append(b.l_seq[take])
-        n_sampled += len(take)
-        use = take[:max(0, min(len(take), n_reads - (n_sampled - len(take))))]
-        flag = b.flag[use].astype(numpy.int32)
-        tlen = b.tlen[use]
-        ok = (flag & 0x8) == 0                                           # mate mapped (:25)
-        ok &= ((flag & 0x10) != 0) != ((flag & 0x20) != 0)               # opposite strands (:28)
-        ok &= (b.mate_tid[use] == b.tid[use]) & (tlen <= max_ins_len)    # same contig, not too far (:31)
-        ok &= b.mate_pos[use] >= b.pos[use]                              # leftmost read of the pair (:34)
-        ok &= ((flag & 0xd00) == 0) & (b.mapq[use] >= min_mapq)          # primary, not duplicate (:37)
-        insert_size.append(tlen[ok])
-        rev = (flag[ok] & 0x10) != 0
-        is_outtie += int(rev.sum())                                      # reverse read first: outtie (:42-45)
-        is_innie += int((~rev).sum())
-        if n_sampled > n_reads:
+        n = len(b)
+        cols = [numpy.ascontiguousarray(getattr(b, k)) for k in ("tid", "pos", "mate_tid", "mate_pos", "tlen", "l_seq", "flag", "mapq")]
+        out = numpy.empty(n, dtype=numpy.int32)
+        k = ctypes.c_size_t(0)
+        # the sampling loop of the reference (:17-47), read by read, in C (csrc/tdt_bam.hip: tdt_stats_scan)
+        _native.check(lib.tdt_stats_scan(*[_native.ptr(c) for c in cols], n, int(n_reads), int(min_mapq), int(max_ins_len), _native.ptr(state),
+                                         _native.ptr(out), ctypes.byref(k)))
+        chunks.append(out[:k.value].copy())
+        if state[5]:
             break
     reader.close()
-    read_length = numpy.concatenate(read_length) if read_length else numpy.zeros(0)
-    insert_size = numpy.concatenate(insert_size) if insert_size else numpy.zeros(0)
-    library["avg_read_length"] = numpy.average(read_length)
+    insert_size = numpy.concatenate(chunks) if chunks else numpy.zeros(0, dtype=numpy.int32)
+    is_innie, is_outtie = int(state[3]), int(state[4])
+    # numpy.average of the read lengths: an exact integer sum over an exact count
+    avg_read_length = (float(state[1]) / float(state[2])) if state[2] else float(numpy.average(numpy.zeros(0)))
+    library["avg_read_length"] = avg_read_length
     if len(insert_size):
         library["avg_insert_size"] = numpy.average(insert_size)
         library["std_insert_size"] = numpy.std(insert_size)
