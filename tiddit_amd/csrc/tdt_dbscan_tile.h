@@ -6,7 +6,7 @@
 // number of extra sub-runs before the point (DBSCAN.py:112-122).  Everything else is local to an x-cluster, and x-clusters
 // are contiguous index ranges.  So ONE launch does all the local work with the tile in LDS:
 //
-//   dbt_tile    a workgroup stages DT_NW words (2048 points) of x and y, OWNS the x-clusters that start in all but its last two words
+//   dbt_tile    a workgroup stages DT_NW words (1536 points) of x and y, OWNS the x-clusters that start in all but its last two words
 //               (a cluster may run on into the two halo words: it has at most DB_SMALL = 128 members) and computes for them
 //               the window masks p (DBSCAN.py:41-51), runs / labelled masks (:52-62), the stable y order of every cluster
 //               (:76-81), the y window masks (:90-99), sub-run starts and sub-run numbers (:101-110).  Every point gets its
@@ -24,7 +24,7 @@
 #define DT_THREADS 256
 #define DT_WAVES (DT_THREADS / 64)
 #ifndef DT_NW
-#define DT_NW 32                            // staged words per tile
+#define DT_NW 24                            // staged words per tile
 #endif
 #define DT_OW (DT_NW - 2)                   // owned words: clusters starting here are this tile's
 #define DT_S (DT_NW * 64)                   // 4096 staged positions
@@ -105,13 +105,15 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
                 }
             }
         }
-        uint4 w[DT_S / 4 / DT_THREADS];
+        constexpr int NCY = (DT_S / 4 + DT_THREADS - 1) / DT_THREADS;
+        uint4 w[NCY];
         if (!XONLY) {
 #pragma unroll
-            for (int k = 0; k < DT_S / 4 / DT_THREADS; k++) {
+            for (int k = 0; k < NCY; k++) {
                 const int c = tid + k * DT_THREADS;
                 const int g = t0 + 4 * c;
                 w[k] = make_uint4(0, 0, 0, 0);
+                if (c >= DT_S / 4) continue;
                 if (g + 4 <= n) w[k] = *reinterpret_cast<const uint4 *>(P.y + g);
                 else {
                     w[k].x = g < n ? P.y[g] : 0u;
@@ -128,7 +130,8 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         }
         if (!XONLY) {
 #pragma unroll
-            for (int k = 0; k < DT_S / 4 / DT_THREADS; k++) *reinterpret_cast<uint4 *>(yv + 4 * (tid + k * DT_THREADS)) = w[k];
+            for (int k = 0; k < NCY; k++)
+                if (tid + k * DT_THREADS < DT_S / 4) *reinterpret_cast<uint4 *>(yv + 4 * (tid + k * DT_THREADS)) = w[k];
         }
     }
     // bucket boundaries (first points of buckets, and n) inside [t0-64, t0+S+128) as a bit stream: BM word k covers
