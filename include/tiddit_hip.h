@@ -121,6 +121,15 @@ int tdt_gc_bins_fasta_device(tdt_ctx *ctx, const uint8_t *d_raw, int64_t nbytes,
  *   mode 0: main (x then y);  mode 1: x pass only.  *last_id receives the final cluster_id. */
 int tdt_dbscan(tdt_ctx *ctx, const int64_t *data, size_t n, size_t stride, double eps, int m, int mode,
                double *labels, int64_t *last_id);
+/* DBSCAN.y_coordinate_clustering(data, eps, m, cluster_id, clusters) (DBSCAN.py:66-123) on caller-supplied x labels: `labels` holds
+ * them on entry (float64: -1 or the cluster numbers 0, 1, 2, ... — every number one contiguous range, ascending along the array, as
+ * x_coordinate_clustering returns them for any eps / m) and the relabelled result on return; sub-run 1 of a cluster keeps its label,
+ * extra sub-runs get cluster_id + 1, cluster_id + 2, ...; *last_id = the returned cluster_id.  TDT_E_UNSUPPORTED for label arrays of
+ * another shape, for clusters above 128 members and for m > 64 (use tdt_dbscan mode 0 on the data instead). */
+int tdt_dbscan_y(tdt_ctx *ctx, const int64_t *data, size_t n, size_t stride, double eps, int m, int64_t cluster_id, double *labels,
+                 int64_t *last_id);
+int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const uint32_t *d_y, size_t n, uint64_t eps, int m, int64_t cluster_id,
+                        double *d_labels, int64_t *d_last_id, int *too_large);
 /* Device-resident batch: nb independent buckets ((chrA,chrB) pairs), bucket b owning points
  * [bucket_off[b], bucket_off[b+1]) of d_x/d_y (uint32 coordinates, each bucket in DBSCAN.main input
  * order).  bucket_off is a HOST array of nb+1 offsets.  Labels (float64, ids restart per bucket)

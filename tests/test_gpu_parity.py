@@ -780,3 +780,30 @@ def test_coverage_packed_records_equal_the_four_arrays(cov, ctx, z, q):
     assert h.kept() == hp.kept()
     h.close()
     hp.close()
+
+
+def test_y_pass_on_caller_supplied_labels(db):
+    """DBSCAN.y_coordinate_clustering takes any label array of the x pass's shape — here the x labels of ANOTHER eps / m, labels with
+    some clusters dropped and the rest renumbered by hand, and an arbitrary starting cluster_id — not only the ones this module produced"""
+    rng = np.random.default_rng(21)
+    for n, span, eps_x, m_x, eps, m, start_id in ((40_000, 30_000_000, 800, 3, 300, 3, None), (25_000, 9_000_000, 500, 4, 500, 2, 777),
+                                                  (3000, 400_000, 400, 3, 150, 4, 5), (64, 4000, 300, 2, 300, 3, None)):
+        x = np.sort(rng.integers(0, span, n))
+        y = np.where(rng.random(n) < 0.6, x + rng.integers(0, 6 * eps, n), rng.integers(0, span, n))
+        data = np.stack([x, y, np.arange(n)], 1).astype(np.int64)
+        xl, xid = oracle.x_coordinate_clustering(data, eps_x, m_x)
+        if start_id is not None and xid >= 3:                       # drop every third cluster, renumber the rest 0, 1, 2, ...
+            ids = xl.astype(np.int64)
+            kept = (ids >= 0) & (ids % 3 != 2)
+            new_id = np.cumsum(np.arange(xid + 1) % 3 != 2) - 1
+            xl = np.where(kept, new_id[np.maximum(ids, 0)], -1).astype(np.float64)
+            xid = int(xl.max())
+        cid = xid if start_id is None else start_id
+        want, wid = oracle.y_coordinate_clustering(data, eps, m, cid, xl.copy())
+        mine = xl.copy()
+        got, gid = db.y_coordinate_clustering(data, eps, m, cid, mine)
+        assert got is mine and gid == wid and np.array_equal(got, want), (n, eps_x, m_x, eps, m)
+    # a shape this path does not take: the same label on two separate ranges
+    bad = np.array([0.0, 0.0, -1.0, 0.0, 1.0, 1.0])
+    with pytest.raises(NotImplementedError):
+        db.y_coordinate_clustering(np.stack([np.arange(6) * 10, np.arange(6), np.arange(6)], 1).astype(np.int64), 50, 2, 1, bad)

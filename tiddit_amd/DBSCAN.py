@@ -44,15 +44,27 @@ def x_coordinate_clustering(data, epsilon, m):
 
 
 def y_coordinate_clustering(data, epsilon, m, cluster_id, clusters):
-    """Second pass over the labels produced by ``x_coordinate_clustering`` for the same
-    (data, epsilon, m); ``clusters`` is updated in place and returned, like the reference."""
-    xl, xid = _run(data, epsilon, m, 1)
-    if xid != cluster_id or not numpy.array_equal(xl, clusters):
-        raise NotImplementedError("y_coordinate_clustering expects the labels/cluster_id returned by "
-                                  "x_coordinate_clustering(data, epsilon, m)")
-    yl, yid = _run(data, epsilon, m, 0)
-    clusters[:] = yl
-    return clusters, yid
+    """Second pass (:66-123) over x labels: ``clusters`` (float64, -1 or cluster numbers) is relabelled in place and returned
+    with the final ``cluster_id``, like the reference.  Any label array of the shape ``x_coordinate_clustering`` produces is
+    taken as it is (contiguous clusters numbered 0, 1, 2, ... along the array — e.g. labels from another eps / m); it does not
+    have to come from this module.  Clusters above 128 members take the ``main`` route, which needs the labels to be the x pass
+    of the same ``(data, epsilon, m)``."""
+    ctx = _native.default_context()
+    data = _as_data(data)
+    n, stride = data.shape
+    lab = numpy.ascontiguousarray(clusters, dtype=numpy.float64).copy()
+    last = ctypes.c_int64(int(cluster_id))
+    rc = ctx.lib.tdt_dbscan_y(ctx.handle, _native.ptr(data), n, stride, float(epsilon), int(m), int(cluster_id), _native.ptr(lab), ctypes.byref(last))
+    if rc == -6:                                  # TDT_E_UNSUPPORTED: large clusters / m > 64 / another label shape
+        xl, xid = _run(data, epsilon, m, 1)
+        if xid != cluster_id or not numpy.array_equal(xl, clusters):
+            raise NotImplementedError("y_coordinate_clustering: " + ctx.lib.tdt_last_error().decode())
+        yl, yid = _run(data, epsilon, m, 0)
+        clusters[:] = yl
+        return clusters, yid
+    _native.check(rc)
+    clusters[:] = lab
+    return clusters, int(last.value)
 
 
 def main(data, epsilon, m):

@@ -534,7 +534,7 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         if (nb == 1) {
             ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
             hipLaunchKernelGGL(dbt_finish1, dim3(ntt), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
-                               (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, t_flags, hw, seq);
+                               (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, 0ll, 0, t_flags, hw, seq);
         } else {
             hipLaunchKernelGGL(dbt_scan, dim3(1), dim3(1024), 0, st, t_aggR, t_aggE, ntt, (const int *)d_boff, nb, n, (const unsigned *)t_brun,
                                (const unsigned *)t_bext, t_runbase, t_extbase, (long long *)d_last_id, mode, t_flags, hw, seq);
@@ -749,6 +749,163 @@ extern "C" int tdt_dbscan(tdt_ctx *ctx, const int64_t *data, size_t n, size_t st
     long long lid = -1;
     TDT_HIP(hipMemcpy(labels, dl, n * 8, hipMemcpyDeviceToHost));
     TDT_HIP(hipMemcpy(&lid, dlid, 8, hipMemcpyDeviceToHost));
+    if (last_id) *last_id = lid;
+    return TDT_OK;
+}
+
+// ---- y pass on caller-supplied x labels (DBSCAN.y_coordinate_clustering, DBSCAN.py:66-123) -------------------------------------
+// d_xlab: int32 labels, -1 = unlabelled, every label value one contiguous index range, values ascending along the array (what
+// x_coordinate_clustering returns, for any eps / m).  Sub-run 1 of a cluster keeps its label, extra sub-runs get cluster_id + 1,
+// cluster_id + 2, ... in cluster order; *d_last_id = the final cluster_id.  *too_large != 0: a cluster has more than DB_SMALL
+// members (or m > 64) — the labels were NOT produced; the caller takes another route.
+extern "C" int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const uint32_t *d_y, size_t n_, uint64_t eps, int m, int64_t cluster_id,
+                                   double *d_labels, int64_t *d_last_id, int *too_large) {
+    if (!ctx || !too_large || m < 2 || (n_ && (!d_xlab || !d_y || !d_labels))) {
+        tdt_set_error("tdt_dbscan_y_device: bad argument");
+        return TDT_E_ARG;
+    }
+    *too_large = 0;
+    if (n_ >= 0x7fff0000ull || m > DBF_M_MAX) {
+        *too_large = 1;
+        return TDT_OK;
+    }
+    if (n_ == 0) return TDT_OK;
+    TDT_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int n = (int)n_;
+    const int ntt = (n + DT_T - 1) / DT_T;
+    const size_t sz_flags = 256, sz_agg = db_align((size_t)ntt * 4), sz_grp = db_align((size_t)2 * DT_GRPMAX * 4);
+    void *ts = nullptr, *tb = nullptr;
+    int rc = tdt_scratch(ctx, 20, sz_flags + 2 * sz_grp, &ts);
+    if (rc) return rc;
+    rc = tdt_scratch(ctx, 21, 2 * sz_agg + 1024, &tb);
+    if (rc) return rc;
+    unsigned *t_flags = (unsigned *)ts;
+    unsigned *t_grp0 = (unsigned *)((char *)ts + sz_flags), *t_grp1 = (unsigned *)((char *)ts + sz_flags + sz_grp);
+    unsigned *t_aggR = (unsigned *)tb, *t_aggE = (unsigned *)((char *)tb + sz_agg);
+    if (ctx->tile_flags_zeroed != ts) {
+        TDT_HIP(hipMemsetAsync(t_flags, 0, sz_flags, st));
+        TDT_HIP(hipMemsetAsync(t_grp0, 0, 2 * sz_grp, st));
+        ctx->tile_flags_zeroed = ts;
+    }
+    DtParams TP;
+    TP.x = (const unsigned *)d_xlab;
+    TP.y = d_y;
+    TP.n = n;
+    TP.boff = nullptr;
+    TP.nb = 1;
+    TP.eps32 = eps > 0xffffffffull ? 0xffffffffu : (unsigned)eps;
+    TP.wide = eps > 0xffffffffull;
+    TP.m = m;
+    TP.lab = (unsigned long long *)d_labels;
+    TP.aggR = t_aggR;
+    TP.aggE = t_aggE;
+    TP.brun = TP.bext = nullptr;
+    TP.flags = t_flags;
+    const bool odd = (ctx->tile_calls++ & 1u) != 0;
+    TP.grp = odd ? t_grp1 : t_grp0;
+    void *hp = nullptr;
+    rc = tdt_pinned(ctx, 2, 64, &hp);
+    if (rc) return rc;
+    volatile unsigned *hw = (volatile unsigned *)hp;
+    static std::atomic<unsigned> y_seq{0x40000000u};
+    const unsigned seq = ++y_seq | 0x40000000u;
+    hw[1] = 0;
+    hipLaunchKernelGGL((dbt_tile<true, false, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
+    ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
+    hipLaunchKernelGGL(dbt_finish1, dim3(ntt), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR, (const unsigned *)t_aggE,
+                       ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, (long long)cluster_id, 1,
+                       t_flags, hw, seq);
+    TDT_CHECK_LAUNCH();
+    bool seen = false;
+    for (long spin = 0; spin < 4000000; spin++) {
+        if (hw[1] == seq) {
+            seen = true;
+            break;
+        }
+        __builtin_ia32_pause();
+    }
+    if (!seen) TDT_HIP(hipStreamSynchronize(st));
+    if (hw[0]) *too_large = 1;
+    return TDT_OK;
+}
+
+extern "C" int tdt_dbscan_y(tdt_ctx *ctx, const int64_t *data, size_t n, size_t stride, double eps, int m, int64_t cluster_id, double *labels,
+                            int64_t *last_id) {
+    if (!ctx || stride < 2 || (n && (!data || !labels))) {
+        tdt_set_error("tdt_dbscan_y: bad argument");
+        return TDT_E_ARG;
+    }
+    if (m < 2) {
+        tdt_set_error("tdt_dbscan_y: m must be >= 2");
+        return TDT_E_ARG;
+    }
+    if (last_id) *last_id = cluster_id;
+    if (n == 0) return TDT_OK;
+    if (n >= 0x7fff0000ull) {
+        tdt_set_error("tdt_dbscan_y: n too large");
+        return TDT_E_UNSUPPORTED;
+    }
+    TDT_HIP(hipSetDevice(ctx->device));
+    // the labels this path takes: integers >= -1, every value one contiguous range, 0, 1, 2, ... along the array (the reference visits
+    // `set(clusters)` — ascending for such values — and selects members by value; other label arrays are not reproduced here)
+    long long next = 0, cur = -2;
+    for (size_t i = 0; i < n; i++) {
+        const double v = labels[i];
+        const long long l = (long long)v;
+        if ((double)l != v || l < -1 || l > 0x7ffffff0ll) {
+            tdt_set_error("tdt_dbscan_y: label %g at %zu is not an integer in [-1, 2^31)", v, i);
+            return TDT_E_UNSUPPORTED;
+        }
+        if (l == cur) continue;
+        if (l >= 0) {
+            if (l != next) {
+                tdt_set_error("tdt_dbscan_y: labels must number contiguous clusters 0, 1, 2, ... along the array (label %lld at %zu, expected %lld)", l, i, next);
+                return TDT_E_UNSUPPORTED;
+            }
+            next++;
+        }
+        cur = l;
+    }
+    int64_t ymin = data[1], ymax = data[1];
+    for (size_t i = 0; i < n; i++) {
+        ymin = std::min(ymin, data[i * stride + 1]);
+        ymax = std::max(ymax, data[i * stride + 1]);
+    }
+    if ((unsigned __int128)((__int128)ymax - ymin) > 0xfffffffeull) {
+        tdt_set_error("tdt_dbscan_y: coordinate span >= 2^32 is outside the device path's domain");
+        return TDT_E_UNSUPPORTED;
+    }
+    void *h = nullptr, *d = nullptr;
+    int rc = tdt_pinned(ctx, 1, n * 8 + 64, &h);
+    if (rc) return rc;
+    rc = tdt_scratch(ctx, 5, n * 16 + 256, &d);
+    if (rc) return rc;
+    uint32_t *hy = (uint32_t *)h;
+    int32_t *hl = (int32_t *)(hy + n);
+    for (size_t i = 0; i < n; i++) {
+        hy[i] = (uint32_t)(data[i * stride + 1] - ymin);
+        hl[i] = (int32_t)labels[i];
+    }
+    uint32_t *dy = (uint32_t *)d;
+    int32_t *dl = (int32_t *)(dy + n);
+    double *dlab = (double *)((char *)d + ((n * 8 + 255) & ~(size_t)255));
+    hipStream_t st = ctx->stream;
+    TDT_HIP(hipMemcpyAsync(dy, hy, n * 8, hipMemcpyHostToDevice, st));
+    void *dlast = nullptr;
+    rc = tdt_scratch(ctx, 6, 64, &dlast);
+    if (rc) return rc;
+    int large = 0;
+    rc = tdt_dbscan_y_device(ctx, dl, dy, n, db_eps_u64(eps), m, cluster_id, dlab, (int64_t *)dlast, &large);
+    if (rc) return rc;
+    if (large) {
+        tdt_set_error("tdt_dbscan_y: an x-cluster has more than %d members (or m > %d): not on the caller-supplied-labels path", DB_SMALL, DBF_M_MAX);
+        return TDT_E_UNSUPPORTED;
+    }
+    TDT_HIP(hipStreamSynchronize(st));
+    long long lid = cluster_id;
+    TDT_HIP(hipMemcpy(labels, dlab, n * 8, hipMemcpyDeviceToHost));
+    TDT_HIP(hipMemcpy(&lid, dlast, 8, hipMemcpyDeviceToHost));
     if (last_id) *last_id = lid;
     return TDT_OK;
 }

@@ -33,6 +33,7 @@
 #define DT_XS (DT_S + 64 + DBF_M_MAX + 8)   // x staged for [t0-64, t0+S+m+...)
 #define DT_CODE_PREV (1ull << 62)           // the position belongs to the NEXT tile's range: its owner is tile(position) - 1
 #define DT_CODE_EXTRA (1ull << 61)          // index counts extra sub-run starts (else: x-run index)
+#define DT_CODE_LITERAL (1ull << 60)        // the low word IS the id (caller-supplied x labels)
 #define DT_MINUS1 0xbff0000000000000ull     // bits of -1.0
 #define DT_GRP 64                           // tiles per group of the two-level count sums (one-bucket path)
 #define DT_GRPMAX 20000                     // groups: 2^31 points / (DT_GRP * smallest tile)
@@ -71,7 +72,10 @@ __device__ __forceinline__ ull dt_bits_after(ull w0, ull w1, ull w2, int bit, in
     return cnt >= 64 ? v : v & ((1ull << cnt) - 1ull);
 }
 
-template <bool ONE_BUCKET, bool XONLY>
+// LABELS: the x pass is not computed — P.x holds caller-supplied x labels (int32, -1 = unlabelled; every label one contiguous range),
+// DBSCAN.y_coordinate_clustering's `clusters` argument (DBSCAN.py:66-74); sub-run 1 keeps the label, extra sub-runs are numbered
+// from the caller's cluster_id by dbt_finish1.
+template <bool ONE_BUCKET, bool XONLY, bool LABELS = false>
 __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     __shared__ __attribute__((aligned(16))) unsigned xs[DT_XS];        // x, later the y values in sorted order
     __shared__ __attribute__((aligned(16))) unsigned yv[DT_S];
@@ -94,14 +98,15 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         for (int k = 0; k < NCX; k++) {
             const int c = tid + k * DT_THREADS;
             const int g = sh0 + 4 * c;
-            v[k] = make_uint4(0, 0, 0, 0);
+            constexpr unsigned FILL = LABELS ? 0xffffffffu : 0u;      // outside the array: x 0 / label -1
+            v[k] = make_uint4(FILL, FILL, FILL, FILL);
             if (c < DT_XS / 4) {
                 if (g >= 0 && g + 4 <= n) v[k] = *reinterpret_cast<const uint4 *>(P.x + g);
                 else {
-                    v[k].x = (g >= 0 && g < n) ? P.x[g] : 0u;
-                    v[k].y = (g + 1 >= 0 && g + 1 < n) ? P.x[g + 1] : 0u;
-                    v[k].z = (g + 2 >= 0 && g + 2 < n) ? P.x[g + 2] : 0u;
-                    v[k].w = (g + 3 >= 0 && g + 3 < n) ? P.x[g + 3] : 0u;
+                    v[k].x = (g >= 0 && g < n) ? P.x[g] : FILL;
+                    v[k].y = (g + 1 >= 0 && g + 1 < n) ? P.x[g + 1] : FILL;
+                    v[k].z = (g + 2 >= 0 && g + 2 < n) ? P.x[g + 2] : FILL;
+                    v[k].w = (g + 3 >= 0 && g + 3 < n) ? P.x[g + 3] : FILL;
                 }
             }
         }
@@ -193,15 +198,30 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         }
         return __ballot(p);
     };
+    if (LABELS) {
+        // caller-supplied labels: "labelled" and "a cluster starts here" straight from them
 #pragma unroll 4
-    for (int s = 0; s < DT_WPW; s++) {
-        const int W = wave * DT_WPW + s;
-        const ull w = p_word(W);
-        if (lane == 0) PM[1 + W] = w;
-    }
-    if (wave == 0) {
-        const ull w = p_word(-1);
-        if (lane == 0) PM[0] = w;
+        for (int s = 0; s < DT_WPW; s++) {
+            const int W = wave * DT_WPW + s;
+            const int o = 64 * W + lane + 64;
+            const int l = (int)xs[o], lp = (int)xs[o - 1];
+            const ull fw = __ballot(l >= 0), sw = __ballot(l >= 0 && l != lp);
+            if (lane == 0) {
+                FM[W] = fw;
+                ST[W] = sw;
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int s = 0; s < DT_WPW; s++) {
+            const int W = wave * DT_WPW + s;
+            const ull w = p_word(W);
+            if (lane == 0) PM[1 + W] = w;
+        }
+        if (wave == 0) {
+            const ull w = p_word(-1);
+            if (lane == 0) PM[0] = w;
+        }
     }
     __syncthreads();
 
@@ -209,11 +229,11 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     if (wave == 0) {
         const int W = lane;
         const bool act = W < DT_NW;
-        const ull cur = act ? PM[1 + W] : 0ull, prev = act ? PM[W] : 0ull;
+        const ull cur = (act && !LABELS) ? PM[1 + W] : 0ull, prev = (act && !LABELS) ? PM[W] : 0ull;
         const int g0 = t0 + 64 * W;
         const ull valid = g0 >= n ? 0ull : (n - g0 >= 64 ? ~0ull : dbf_lt(n - g0));
-        const ull st = cur & ~((cur << 1) | (prev >> 63));                 // a run starts: p and not p before (:52-57)
-        const ull f = dbf_smear(cur, prev, m) & valid;                     // label != -1: some p in [i-m+1, i]  (:58-62)
+        const ull st = LABELS ? (act ? ST[W] : 0ull) : cur & ~((cur << 1) | (prev >> 63));     // a run starts: p and not p before (:52-57)
+        const ull f = LABELS ? (act ? FM[W] : 0ull) : dbf_smear(cur, prev, m) & valid;         // label != -1: some p in [i-m+1, i]  (:58-62)
         // f / st of the next word's first position (the last word's cluster is closed by force: a cluster reaching the end of
         // the staged range has more than DB_SMALL members, since it started in the owned words)
         ull fnx = __shfl_down(f, 1), snx = __shfl_down(st, 1);
@@ -244,10 +264,12 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     // ---- lane = point: cluster ids and extents.  cid = index (1-based) of the point's cluster among the runs started in the
     // staged range; 1..n_owned are this tile's.  Packed per point for the later steps: cid << 1 | labelled.
     unsigned info[DT_WPW];
+    unsigned labv[LABELS ? DT_WPW : 1];
 #pragma unroll
     for (int s = 0; s < DT_WPW; s++) {
         const int W = wave * DT_WPW + s;
         const int q = 64 * W + lane;
+        if (LABELS) labv[s] = xs[q + 64];
         const ull st = dbf_uni(ST[W]), f = dbf_uni(FM[W]), tl = dbf_uni(TL[W]);
         const unsigned cid = runBase[W] + dbf_cnt_le(st, lane);
         const bool lab = (f >> lane) & 1ull;
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
             ull code = DT_MINUS1;
             if ((FY[W] >> lane) & 1ull) {
                 const ull prevf = dq >= DT_T ? DT_CODE_PREV : 0ull;
-                if (sub[s] == 1) code = prevf | (ull)((info[s] >> 1) - 1u);                       // sub-run 1 keeps the x id
+                if (sub[s] == 1) code = LABELS ? (DT_CODE_LITERAL | (ull)labv[s]) : (prevf | (ull)((info[s] >> 1) - 1u));   // sub-run 1 keeps the x id
                 else code = prevf | DT_CODE_EXTRA | (ull)(extBase[W] + dbf_cnt_le(EB[W], lane));  // k-th extra start of the bucket
             }
             P.lab[g] = code;
@@ -555,6 +577,7 @@ __global__ __launch_bounds__(256) void dbt_finish(unsigned long long *__restrict
 __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restrict__ lab, int n, const unsigned *__restrict__ aggR,
                                                    const unsigned *__restrict__ aggE, int nt, const unsigned *__restrict__ grp,
                                                    unsigned *__restrict__ grp_next, int ng_clear, long long *__restrict__ last_id,
+                                                   long long id_base, int use_id_base,
                                                    unsigned *__restrict__ flags, volatile unsigned *host, unsigned seq) {
     __shared__ unsigned red[4][6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -593,7 +616,7 @@ __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restric
 #pragma unroll
     for (int k = 0; k < 6; k++) v[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
     const unsigned preR[2] = {v[0], v[0] + v[1]}, preE[2] = {v[3], v[3] + v[4]};     // [0]: the previous tile's, [1]: this tile's
-    const long long R1 = (long long)v[2] - 1;
+    const long long R1 = use_id_base ? id_base : (long long)v[2] - 1;     // ids of the extra sub-runs continue from here (:112-122)
     if (tile == 0 && tid == 0 && last_id) last_id[0] = R1 + (long long)v[5];
     const int i0 = tile * DT_T;
     const bool al = (((size_t)lab) & 15) == 0;
@@ -616,7 +639,8 @@ __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restric
             if (w[k] >> 63) continue;                                  // -1.0 stays
             const int sel = 1 - (int)((w[k] >> 62) & 1ull);
             const unsigned c = (unsigned)w[k];
-            const double id = (w[k] & DT_CODE_EXTRA) ? (double)(R1 + (long long)(preE[sel] + c)) : (double)(preR[sel] + c);
+            const double id = (w[k] & DT_CODE_LITERAL) ? (double)(int)c
+                              : (w[k] & DT_CODE_EXTRA) ? (double)(R1 + (long long)(preE[sel] + c)) : (double)(preR[sel] + c);
             w[k] = (ull)__double_as_longlong(id);
             any = true;
         }
