@@ -1032,3 +1032,15 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     return TDT_OK;
 }
 
+
+#ifdef DT_PROF
+// variant builds only: per-phase cycles of dbt_tile summed over the workgroups of the last launch
+extern "C" int tdt_debug_dt_prof(unsigned long long *out16) {
+    static unsigned h[DT_PROF_TILES * 16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dt_prof), sizeof(h)) != hipSuccess) return -1;
+    for (int k = 0; k < 16; k++) out16[k] = 0;
+    for (int t = 0; t < DT_PROF_TILES; t++)
+        for (int k = 0; k < 16; k++) out16[k] += h[t * 16 + k];
+    return 0;
+}
+#endif

@@ -38,6 +38,15 @@
 #define DT_GRP 64                           // tiles per group of the two-level count sums (one-bucket path)
 #define DT_GRPMAX 20000                     // groups: 2^31 points / (DT_GRP * smallest tile)
 
+#ifdef DT_PROF
+// variant builds only (tools/dt_prof.sh): shader-clock cycles per phase of dbt_tile as seen by thread 0, per workgroup
+#define DT_PROF_TILES 8192
+__device__ unsigned dt_prof[DT_PROF_TILES * 16];
+#define DT_MARK(k) do { if (ONE_BUCKET && !LABELS && tid == 0 && blockIdx.x < DT_PROF_TILES) { const unsigned long long t_ = clock64(); dt_prof[blockIdx.x * 16 + k] = (unsigned)(t_ - t_last); t_last = t_; } } while (0)
+#else
+#define DT_MARK(k) do { } while (0)
+#endif
+
 struct DtParams {
     const unsigned *x, *y;
     int n;
@@ -72,15 +81,35 @@ __device__ __forceinline__ ull dt_bits_after(ull w0, ull w1, ull w2, int bit, in
     return cnt >= 64 ? v : v & ((1ull << cnt) - 1ull);
 }
 
+// lanes where a - b - cin borrows, i.e. a < b + cin (cin: one bit per lane); no flags register is touched
+__device__ __forceinline__ ull dt_borrow(unsigned a, unsigned b, ull cin) {
+    unsigned diff;
+    ull bout;
+    asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(diff), "=s"(bout) : "v"(a), "v"(b), "s"(cin));
+    return bout;
+}
+// r + (the lane's bit of mask)
+__device__ __forceinline__ unsigned dt_add_bit(unsigned r, ull mask) {
+    unsigned out;
+    ull cout;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(out), "=s"(cout) : "v"(r), "s"(mask));
+    return out;
+}
+
 // LABELS: the x pass is not computed — P.x holds caller-supplied x labels (int32, -1 = unlabelled; every label one contiguous range),
 // DBSCAN.y_coordinate_clustering's `clusters` argument (DBSCAN.py:66-74); sub-run 1 keeps the label, extra sub-runs are numbered
 // from the caller's cluster_id by dbt_finish1.
 template <bool ONE_BUCKET, bool XONLY, bool LABELS = false>
 __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     __shared__ __attribute__((aligned(16))) unsigned xs[DT_XS];        // x, later the y values in sorted order
-    __shared__ __attribute__((aligned(16))) unsigned yv[DT_S];
-    __shared__ unsigned short ordl[DT_S], segA[DT_S], segE[DT_S];
-    __shared__ ull PM[DT_NW + 2], ST[DT_NW], FM[DT_NW], TL[DT_NW], PY[DT_NW + 1], SY[DT_NW], FY[DT_NW], EB[DT_NW], BM[DT_NW + 3];
+    __shared__ __attribute__((aligned(16))) unsigned yv[DT_S + 8];      // + 8: the rank loop's masked reads past the last cluster
+    // run starts lie at least two positions apart (a start needs a non-p position in front of it), so the staged range holds at
+    // most DT_S / 2 x-clusters; caller-supplied labels may start one at every position
+    constexpr int NSEG = LABELS ? DT_S : DT_S / 2 + 2;
+    __shared__ unsigned short ordl[DT_S], segA[NSEG], segE[NSEG];
+    __shared__ ull PM[DT_NW + 2], ST[DT_NW], FM[DT_NW], TL[DT_NW], SY[DT_NW], FY[DT_NW], BM[DT_NW + 3];
+    ull *PY = PM;                        // the x window masks are dead once the run masks exist; so are the cluster tails (8 workgroups
+    ull *EB = TL;                        // of 20 KB fit a CU's LDS, not 6 of 23 KB)
     __shared__ unsigned runBase[DT_NW + 1], extBase[DT_NW + 1];
     __shared__ unsigned s_owned, s_b0, s_b1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,6 +118,9 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     const int t0 = tile * DT_T;          // the host takes this path only for n < 2^31 - 2^16: int arithmetic cannot overflow
     const int sh0 = t0 - 64;
     unsigned *ysrt = xs;
+#ifdef DT_PROF
+    unsigned long long t_last = clock64();
+#endif
 
     // ---- stage x [t0-64, ...) and y [t0, t0+S) with 16-byte loads, zero outside the array
     {
@@ -165,6 +197,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         }
     }
     __syncthreads();
+    DT_MARK(0);
 
     // ---- x pass: p words -1 .. NW-1   (PM[1 + W]; PM[0] = the word before the tile)
     auto p_word = [&](int W) -> ull {
@@ -224,6 +257,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         }
     }
     __syncthreads();
+    DT_MARK(1);
 
     // ---- lane = word: run starts, labelled mask, cluster tails; counts of starts before every word
     if (wave == 0) {
@@ -259,6 +293,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         }
     }
     __syncthreads();
+    DT_MARK(2);
     const unsigned n_owned = s_owned;
 
     // ---- lane = point: cluster ids and extents.  cid = index (1-based) of the point's cluster among the runs started in the
@@ -301,6 +336,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         return;
     }
     __syncthreads();
+    DT_MARK(3);
 
 #ifdef DT_ABL_STOP_AFTER_X
     if (segA[tid] == 0x1234u) P.lab[tid] = 1;
@@ -320,6 +356,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         }
     }
     __syncthreads();           // every x read is done: xs becomes ysrt
+    DT_MARK(4);
 #pragma unroll
     for (int s = 0; s < DT_WPW; s++) {
         const int W = wave * DT_WPW + s;
@@ -332,16 +369,19 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
             rank = q - a;
             if (false)
 #endif
-            // 8 members per trip: clamped, independent LDS loads (a cluster of the usual size is done in one trip; the wave runs
-            // as long as its largest cluster)
+            // 8 members per trip, branch-free: one address, eight loads at constant offsets (reads past the cluster's end stay inside
+            // the workgroup's LDS and are masked).  Per member four vector instructions: two compares of the trip's distances with a
+            // constant (masks in SGPRs), one subtract-with-borrow whose borrow-out IS the sort predicate, one add-with-carry
+            // (the wave runs as long as its largest cluster; a cluster of the usual size is done in one trip)
             for (int j0 = a; j0 < e; j0 += 8) {
+                const int dq = q - j0, de = e - j0;                 // member k sorts before q on a tie iff k < dq; it exists iff k < de
                 unsigned v[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = yv[min(j0 + k, e - 1)];
+                for (int k = 0; k < 8; k++) v[k] = yv[j0 + k];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const int j = j0 + k;
-                    rank += (j < e) && ((v[k] < yq) || (v[k] == yq && j < q));
+                    const ull tie = __ballot(k < dq), there = __ballot(k < de);
+                    rank = (int)dt_add_bit((unsigned)rank, dt_borrow(v[k], yq, tie) & there);      // v < yq + tie
                 }
             }
             ysrt[a + rank] = yq;
@@ -350,6 +390,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     }
     if (large) atomicOr(P.flags, 1u);
     __syncthreads();
+    DT_MARK(5);
 
 #ifdef DT_ABL_STOP_AFTER_RANK
     if (ysrt[tid] == 0x12345u) P.lab[tid] = 1;
@@ -370,6 +411,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     }
     if (tid == 0) PY[0] = 0;
     __syncthreads();
+    DT_MARK(6);
     if (wave == 0) {   // lane = word: sub-run starts (a cluster head always starts one), labelled mask, starts before every word
         const int W = lane;
         ull sy = 0;
@@ -388,6 +430,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         if (W < DT_NW) extBase[W] = incl - c;      // (the array holds the extra-start counts later)
     }
     __syncthreads();
+    DT_MARK(7);
     // sub-run number of a member = sub-run starts in [a, q] = starts up to q minus starts before the cluster's head, which the
     // head publishes; a start that is not the first of its cluster is an EXTRA (:112-122)
     unsigned short *cHead = segA;                  // the cluster extents live in registers by now
@@ -401,6 +444,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         if (ext[s] && (int)(ext[s] & 0xffff) == q) cHead[(info[s] >> 1) - 1] = (unsigned short)(sub[s] - (unsigned)((sy >> lane) & 1ull));
     }
     __syncthreads();
+    DT_MARK(8);
 #pragma unroll
     for (int s = 0; s < DT_WPW; s++) {
         const int W = wave * DT_WPW + s;
@@ -413,6 +457,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         if (lane == 0) EB[W] = w;
     }
     __syncthreads();
+    DT_MARK(9);
     if (wave == 0) {
         const unsigned c = lane < DT_NW ? (unsigned)dbf_popc(EB[lane]) : 0u;
         unsigned incl = c;
@@ -427,6 +472,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
         }
     }
     __syncthreads();
+    DT_MARK(10);
 
     // ---- results: -1.0 or a code, written at the member's ORIGINAL position (labels come back in input order)
 #pragma unroll
@@ -447,6 +493,7 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
             P.lab[t0 + q] = DT_MINUS1;                          // not in any x-cluster
         }
     }
+    DT_MARK(11);
     if (!ONE_BUCKET) {
         for (unsigned b = s_b0 + tid; b < s_b1; b += DT_THREADS) {
             const int off = P.boff[b] - t0;
