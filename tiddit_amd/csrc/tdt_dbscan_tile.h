@@ -20,6 +20,7 @@
 //
 // All predicates are ballot masks (lane = point), the word-level algebra runs with lane = word, as in tdt_dbscan_fused.h.
 #pragma once
+#include <type_traits>
 
 #define DT_THREADS 256
 #define DT_WAVES (DT_THREADS / 64)
@@ -100,16 +101,17 @@ __device__ __forceinline__ unsigned dt_add_bit(unsigned r, ull mask) {
 // DBSCAN.y_coordinate_clustering's `clusters` argument (DBSCAN.py:66-74); sub-run 1 keeps the label, extra sub-runs are numbered
 // from the caller's cluster_id by dbt_finish1.
 template <bool ONE_BUCKET, bool XONLY, bool LABELS = false>
-__global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
+__global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void dbt_tile(DtParams P) {
     __shared__ __attribute__((aligned(16))) unsigned xs[DT_XS];        // x, later the y values in sorted order
     __shared__ __attribute__((aligned(16))) unsigned yv[DT_S + 8];      // + 8: the rank loop's masked reads past the last cluster
     // run starts lie at least two positions apart (a start needs a non-p position in front of it), so the staged range holds at
     // most DT_S / 2 x-clusters; caller-supplied labels may start one at every position
     constexpr int NSEG = LABELS ? DT_S : DT_S / 2 + 2;
     __shared__ unsigned short ordl[DT_S], segA[NSEG], segE[NSEG];
-    __shared__ ull PM[DT_NW + 2], ST[DT_NW], FM[DT_NW], TL[DT_NW], SY[DT_NW], FY[DT_NW], BM[DT_NW + 3];
+    __shared__ ull PM[DT_NW + 2], ST[DT_NW], FM[DT_NW], TL[DT_NW], FY[DT_NW], BM[DT_NW + 3];
     ull *PY = PM;                        // the x window masks are dead once the run masks exist; so are the cluster tails (8 workgroups
     ull *EB = TL;                        // of 20 KB fit a CU's LDS, not 6 of 23 KB)
+    ull *SY = BM;                        // the bucket-boundary stream is read by the x pass only
     __shared__ unsigned runBase[DT_NW + 1], extBase[DT_NW + 1];
     __shared__ unsigned s_owned, s_b0, s_b1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -200,36 +202,43 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
     DT_MARK(0);
 
     // ---- x pass: p words -1 .. NW-1   (PM[1 + W]; PM[0] = the word before the tile)
-    auto p_word = [&](int W) -> ull {
+    auto p_word = [&](int W, auto m3) -> ull {                // m3: m == 3, the caller's usual l (tiddit_cluster.pyx: min_pts = 3)
         const int i = t0 + 64 * W + lane;                     // global index
         const int o = 64 * W + lane + 64;                     // xs index
         const unsigned xi = xs[o];
-        bool p;
+        // Only the window's LAST member can be missing where p can hold: i <= n-m admits i = n-m, whose window data[i+1:i+m+1] is
+        // one short (:39,43); a bucket boundary at i+m does the same.  The first m-1 members are compared unconditionally (outside
+        // the array the staging wrote zeros, and p is false there anyway).
+        bool p, last;
         if (ONE_BUCKET) {
-            const int cnt = min(i + m, n - 1) - i;                // window members (data[i+1:i+m+1] truncated at the end, :43)
-            unsigned maxd = 0;
-            if (m <= 4) {
-                const unsigned v1 = xs[o + 1], v2 = xs[o + 2], v3 = xs[o + 3], v4 = xs[o + 4];
-                maxd = db_absdiff(v1, xi);
-                maxd = cnt >= 2 ? max(maxd, db_absdiff(v2, xi)) : maxd;
-                maxd = cnt >= 3 ? max(maxd, db_absdiff(v3, xi)) : maxd;
-                maxd = cnt >= 4 ? max(maxd, db_absdiff(v4, xi)) : maxd;
-            } else {
-                for (int q = 1; q <= m; q++) maxd = q <= cnt ? max(maxd, db_absdiff(xs[o + q], xi)) : maxd;
-            }
-            p = i >= 0 && i + m <= n && (P.wide || maxd < P.eps32);              // i <= n-m (:39)
+            last = i + m < n;
+            p = i >= 0 && i + m <= n;
         } else {
             // boundaries at positions i+1 .. i+m: one among the first m-1 ends the bucket inside the window (no p); one at
             // i+m exactly truncates the window by one member
             const int k = (64 * W + lane + 64) >> 6, bit = (64 * W + lane + 64) & 63;
             const ull nb_bits = dt_bits_after(BM[k], BM[k + 1], 0, bit, m);
-            const bool cut = (nb_bits & ((1ull << (m - 1)) - 1ull)) != 0;
-            const int cnt = m - (int)((nb_bits >> (m - 1)) & 1ull);
-            unsigned maxd = 0;
-            for (int q = 1; q <= m; q++) maxd = q <= cnt ? max(maxd, db_absdiff(xs[o + q], xi)) : maxd;
-            p = i >= 0 && i < n && !cut && (P.wide || maxd < P.eps32);
+            last = !((nb_bits >> (m - 1)) & 1ull);
+            p = i >= 0 && i < n && (nb_bits & ((1ull << (m - 1)) - 1ull)) == 0;
         }
-        return __ballot(p);
+        // max |x_j - x_i| over the window from the window's largest and smallest value (the input need not be sorted: :41-45 takes abs)
+        unsigned hi = xi, lo = xi;
+        if (decltype(m3)::value) {
+            const unsigned v1 = xs[o + 1], v2 = xs[o + 2], r3 = xs[o + 3], v3 = last ? r3 : xi;      // (loads stay unconditional)
+            hi = max(max(v1, v2), max(v3, xi));
+            lo = min(min(v1, v2), min(v3, xi));
+        } else {
+            for (int q = 1; q < m; q++) {
+                const unsigned v = xs[o + q];
+                hi = max(hi, v);
+                lo = min(lo, v);
+            }
+            const unsigned rl = xs[o + m], v = last ? rl : xi;
+            hi = max(hi, v);
+            lo = min(lo, v);
+        }
+        const unsigned maxd = max(hi - xi, xi - lo);
+        return __ballot(p & (P.wide != 0 | maxd < P.eps32));       // (no short circuit: the words of a wave interleave)
     };
     if (LABELS) {
         // caller-supplied labels: "labelled" and "a cluster starts here" straight from them
@@ -245,16 +254,21 @@ __global__ __launch_bounds__(DT_THREADS) void dbt_tile(DtParams P) {
             }
         }
     } else {
-#pragma unroll 4
-        for (int s = 0; s < DT_WPW; s++) {
-            const int W = wave * DT_WPW + s;
-            const ull w = p_word(W);
-            if (lane == 0) PM[1 + W] = w;
-        }
-        if (wave == 0) {
-            const ull w = p_word(-1);
-            if (lane == 0) PM[0] = w;
-        }
+        auto x_pass = [&](auto m3) {
+            ull w[DT_WPW];
+#pragma unroll
+            for (int s = 0; s < DT_WPW; s++) w[s] = p_word(wave * DT_WPW + s, m3);
+            if (lane == 0) {
+#pragma unroll
+                for (int s = 0; s < DT_WPW; s++) PM[1 + wave * DT_WPW + s] = w[s];
+            }
+            if (wave == 0) {
+                const ull w1 = p_word(-1, m3);
+                if (lane == 0) PM[0] = w1;
+            }
+        };
+        if (m == 3) x_pass(std::true_type{});
+        else x_pass(std::false_type{});
     }
     __syncthreads();
     DT_MARK(1);
