@@ -807,3 +807,46 @@ def test_y_pass_on_caller_supplied_labels(db):
     bad = np.array([0.0, 0.0, -1.0, 0.0, 1.0, 1.0])
     with pytest.raises(NotImplementedError):
         db.y_coordinate_clustering(np.stack([np.arange(6) * 10, np.arange(6), np.arange(6)], 1).astype(np.int64), 50, 2, 1, bad)
+
+
+def test_coverage_config2_whole_genome_every_contig(cov, ctx):
+    """BASELINE configs[1] at its full size — 24 contigs x 125 Mb, 30x, 600 M reads in ONE launch — both as `--cov` runs it
+    (500-bp bins, q >= 20) and as `--sv` does (50-bp bins, q >= 5; tiddit_signal.pyx:181,235), from the packed records and from the
+    four arrays: every bin of every contig and the kept count equal the scalar oracle's"""
+    torch = pytest.importorskip("torch")
+    from tiddit_amd import _native
+    dev = torch.device("cuda:0")
+    C, L = 24, 125_000_000
+    if torch.cuda.get_device_properties(0).total_memory < 40 * 2**30:
+        pytest.skip("needs the stream of a 3-Gb genome in device memory")
+    reads = [synth.gen_reads_device(L, 30, dev, seed=synth.SEED + c) for c in range(C)]
+    torch.cuda.synchronize()
+    n = [int(r[0].numel()) for r in reads]
+    assert sum(n) == 600_000_000
+    packed = []
+    for c in range(C):
+        pk = torch.empty(n[c], dtype=torch.int64, device=dev)
+        _native.check(ctx.lib.tdt_cov_pack_device(ctx.handle, reads[c][0].data_ptr(), reads[c][1].data_ptr(), reads[c][2].data_ptr(),
+                                                  reads[c][3].data_ptr(), n[c], pk.data_ptr()))
+        packed.append(pk)
+    ctx.sync()
+    host = [tuple(t.cpu().numpy() for t in r) for r in reads]
+    contigs = [("s%02d" % (c + 1), L) for c in range(C)]
+    for z, q in ((500, 20), (50, 5)):
+        want, kept = [], 0
+        for c in range(C):
+            s, e, mq, fl = host[c]
+            w, k = oracle.coverage_stream(s, e, mq, fl.view(np.uint16), L, z, q)
+            want.append(w)
+            kept += k
+        for layout in ("packed", "four arrays"):
+            h = cov.CoverageHistogram(contigs, z)
+            if layout == "packed":
+                h.push_packed_device_multi([(c, packed[c].data_ptr(), reads[c][1].data_ptr(), n[c]) for c in range(C)], q)
+            else:
+                h.push_device_multi([(c, reads[c][0].data_ptr(), reads[c][1].data_ptr(), reads[c][2].data_ptr(), reads[c][3].data_ptr(), n[c])
+                                     for c in range(C)], q)
+            for c in range(C):
+                assert np.array_equal(h.finish(contigs[c][0]), want[c]), (z, layout, c)
+            assert h.kept() == kept, (z, layout)
+            h.close()
