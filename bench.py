@@ -39,7 +39,7 @@ def profiled_traffic(kernel_prefix):
     tp = os.path.join(REPO, "profiles", "traffic.json")
     try:
         for k, v in json.load(open(tp))["kernels"].items():
-            if k.startswith(kernel_prefix):
+            if k.startswith(kernel_prefix) or k.startswith(kernel_prefix.rstrip(">")):      # (later template parameters may follow)
                 return float(v["bytes_per_launch"])
     except Exception:
         pass
@@ -390,7 +390,7 @@ def main():
             t_db = float(tt.item())
         k_ms = sum(a.elapsed_time(b) for a, b in dev_ms) / len(dev_ms)
         db_ach = 16.0 * n / (k_ms * 1e-3) / 1e9
-        t1_, t2_ = profiled_traffic("dbt_tile<true, false>"), profiled_traffic("dbt_finish1")
+        t1_, t2_ = profiled_traffic("dbt_tile<true, false, false>"), profiled_traffic("dbt_finish1")
         db_traffic = None if t1_ is None or t2_ is None else t1_ + t2_
         dbres = {"metric": "signals clustered/sec", "value": n / (t_db / args.steps), "unit": "signals/s",
                  "ms_per_step": 1e3 * t_db / args.steps,
