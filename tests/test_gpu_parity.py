@@ -850,3 +850,102 @@ def test_coverage_config2_whole_genome_every_contig(cov, ctx):
                 assert np.array_equal(h.finish(contigs[c][0]), want[c]), (z, layout, c)
             assert h.kept() == kept, (z, layout)
             h.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_coverage_random_parameter_sweep(cov, ctx, seed):
+    """Random bin sizes on both sides of every kernel switch (1, the table-driven 2..1023 with their 24-bit division constants, the
+    difference-pair flavour <= 128, >= 1024), contig lengths that are and are not multiples of the bin, short / long / mixed reads,
+    sorted and shuffled streams, several filters — packed records and the four arrays against the scalar oracle"""
+    torch = pytest.importorskip("torch")
+    from tiddit_amd import _native
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        z = int(rng.choice([1, 2, 3, 7, 31, 50, 64, 100, 127, 128, 129, 250, 500, 511, 777, 1000, 1023, 1024, 1500, 5000, int(rng.integers(2, 1400))]))
+        LN = int(rng.integers(1, 3_000_000)) if rng.random() < 0.8 else int(z * rng.integers(1, 2000))
+        n = int(rng.integers(1, 400_000))
+        start = np.sort(rng.integers(0, LN, n))
+        kind = rng.random()
+        if kind < 0.4:
+            span = rng.integers(1, 300, n)                                  # short reads
+        elif kind < 0.7:
+            span = np.where(rng.random(n) < 0.03, rng.integers(1, 100_000, n), rng.integers(1, 400, n))      # long-read tails
+        else:
+            span = rng.integers(1, max(2, 6 * z), n)                        # a few bins each, whatever the bin size
+        end = np.minimum(start + span, LN)
+        if rng.random() < 0.3:
+            p = rng.permutation(n)                                          # unsorted input: any order is legal for the histogram
+            start, end = start[p], end[p]
+        mapq = rng.choice([0, 1, 4, 5, 19, 20, 30, 60, 61, 255], n).astype(np.uint8)
+        flag = (rng.choice([0, 0x4, 0x400, 0x404, 0x10, 0x800], n, p=[.8, .04, .04, .02, .05, .05]) | rng.choice([0, 0x1, 0x2, 0x100], n)).astype(np.uint16)
+        q = int(rng.choice([0, 1, 5, 20, 60, 63]))
+        s32, e32 = start.astype(np.int32), end.astype(np.int32)
+        want, kept = oracle.coverage_stream(s32, e32, mapq, flag, LN, z, q)
+        ts = [torch.from_numpy(s32).to(dev), torch.from_numpy(e32).to(dev), torch.from_numpy(mapq).to(dev),
+              torch.from_numpy(flag.view(np.int16)).to(dev)]
+        pk = torch.empty(n, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        _native.check(ctx.lib.tdt_cov_pack_device(ctx.handle, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), n, pk.data_ptr()))
+        for layout in ("packed", "four arrays"):
+            h = cov.CoverageHistogram([("c", LN)], z)
+            if layout == "packed":
+                h.push_packed_device_multi([("c", pk.data_ptr(), ts[1].data_ptr(), n)], q)
+            else:
+                h.push_device_multi([("c", ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), n)], q)
+            got = h.finish("c")
+            assert h.kept() == kept, (seed, z, LN, n, q, layout)
+            assert np.array_equal(got, want), (seed, z, LN, n, q, layout)
+            h.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dbscan_random_parameter_sweep(ctx, nat, seed):
+    """Random (eps, m) with m on both sides of the m == 3 fast path and up to the tile path's limit, sorted and unsorted x, dense and
+    sparse buckets, 1 .. 60 buckets in one call, both modes (x pass only / both passes): labels and last ids against the oracle"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2000 + seed)
+    for _ in range(5):
+        nb = int(rng.choice([1, 1, 2, 9, 60]))
+        m = int(rng.choice([2, 2, 3, 3, 4, 5, 8, 17, 64]))          # (m = 1: the reference itself raises, max() of an empty window)
+        eps = int(rng.choice([1, 50, 300, 500, 5000]))
+        mode = int(rng.random() < 0.25)
+        srt = rng.random() < 0.7
+        xs, ys, want, lastid = [], [], [], []
+        sizes = rng.choice([0, 1, 2, m, m + 1, 70, 1500, 9000], nb)
+        for s in sizes:
+            s = int(s)
+            span = max(10, int(s * eps * rng.choice([0.05, 0.5, 3.0])))
+            x = rng.integers(0, span, s)
+            if srt:
+                x = np.sort(x)
+            y = np.where(rng.random(s) < 0.6, x + rng.integers(0, 3 * eps + 1, s), rng.integers(0, span, s))
+            xs.append(x)
+            ys.append(y)
+            if s:
+                d = np.stack([x, y], 1).astype(np.int64)
+                xl, xid = oracle.x_coordinate_clustering(d, eps, m)
+                if mode == 1:
+                    want.append(xl)
+                    lastid.append(xid)
+                else:
+                    yl, yid = oracle.y_coordinate_clustering(d, eps, m, xid, xl)
+                    want.append(yl)
+                    lastid.append(yid)
+            else:
+                want.append(np.zeros(0))
+                lastid.append(-1)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        x, y, want = np.concatenate(xs), np.concatenate(ys), np.concatenate(want)
+        tx = torch.from_numpy(x.astype(np.int64).astype(np.uint32).view(np.int32)).to(dev)
+        ty = torch.from_numpy(y.astype(np.int64).astype(np.uint32).view(np.int32)).to(dev)
+        tl = torch.empty(max(1, len(x)), dtype=torch.float64, device=dev)
+        tid = torch.empty(nb, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        nat.check(ctx.lib.tdt_dbscan_device(ctx.handle, tx.data_ptr(), ty.data_ptr(), len(x), nat.ptr(off), nb, eps, m, mode,
+                                            tl.data_ptr(), tid.data_ptr()))
+        ctx.sync()
+        key = (seed, nb, m, eps, mode, bool(srt), sizes.tolist())
+        assert np.array_equal(tl.cpu().numpy()[:len(x)], want), key
+        assert np.array_equal(tid.cpu().numpy(), np.array(lastid)), key
