@@ -450,6 +450,8 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
             const bool safe = ko < (unsigned)(WIN - 3) && K + 3 <= last_bin;
             const unsigned kw = safe ? ko : 0u;
             const unsigned z3 = 3u * z;
+            const char *pairA = reinterpret_cast<const char *>(pair), *pairB = reinterpret_cast<const char *>(pair + (z + 1u));
+            const int nz = -(int)z;
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
                 const unsigned rs = (unsigned)sv[j] - Kz;    // offsets from the start of bin K: first base, one past the last base
@@ -457,17 +459,18 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
                 const unsigned len = re1 - rs;               // e - s (wraps to a huge value when e <= s)
                 const bool cand = ((fl[j] & FMASK) == 0) & ((int)mq[j] >= P.min_q);   // __main__.py:231-235 / tiddit_signal.pyx:171-181
                 const bool r1_ = rs >= z;                    // first bin = K + 1
-                const unsigned dq = (__umul24(re1, P.m15) - P.m15) >> P.k15;     // (e - 1 - K z) / z, exact for e - 1 - K z < 2^15
+                const unsigned rl = re1 - 1u;                                    // offset of the last base
+                const unsigned dq = __umul24(rl, P.m15) >> P.k15;                // (e - 1 - K z) / z, exact for e - 1 - K z < 2^15
                 const unsigned r = r1_ ? 1u : 0u;
                 const bool fast = cand & safe & (rs < 2u * z) & (len - 1u < z3) & (re1 <= z3) & (dq - r <= 1u);
                 nkept += fast ? 1u : 0u;
                 slowmask |= (cand & !fast) ? (1u << j) : 0u;
                 const bool multi = fast & (dq != r);
                 const unsigned bf = min(len, (r1_ ? 2u * z : z) - rs);          // bases in the first bin (:55 / :61)
-                const unsigned sect = r1_ ? z + 1u : 0u;
-                const ulonglong2 X = pair[(fast ? bf : 0u) + sect];
-                const unsigned bl1 = re1 - __umul24(dq, z);                      // bases in the last bin + 1 (:63 counts one short)
-                const ulonglong2 Y = pair[(multi ? bl1 - 1u : 0u) + sect];
+                const char *sect = r1_ ? pairB : pairA;                          // the (0, v) / (v, 0) table: one select of two bases
+                const ulonglong2 X = *reinterpret_cast<const ulonglong2 *>(sect + ((fast ? bf : 0u) << 4));
+                const unsigned bl = (unsigned)(__mul24((int)dq, nz) + (int)rl);  // bases in the last bin, counted one short as :63 does (one v_mad_i32_i24)
+                const ulonglong2 Y = *reinterpret_cast<const ulonglong2 *>(sect + ((multi ? bl : 0u) << 4));
                 a0 += X.x;
                 a1 += X.y + Y.x;
                 a2 += Y.y;
