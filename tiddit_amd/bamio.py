@@ -103,7 +103,7 @@ class RecordView:
 
     def __init__(self, batch, i):
         self.batch, self.i = batch, i
-        self.raw = batch.raw
+        self.raw = getattr(batch, "raw_bytes", None) or batch.raw       # (a bytes copy, where the batch keeps one: cheaper to slice)
         self.off = int(batch.rec_off[i]) + 4
 
     def _u(self, fmt, o):

@@ -14,6 +14,7 @@ from collections import Counter
 
 import numpy
 
+from .hostutil import quiet_gc
 from . import _native
 
 # (orientation of read A, orientation of read B) -> which of (start, end) is the breakpoint side,
@@ -167,7 +168,7 @@ def _breakpoints_from_discordants(cand, is_mp):
     return pickA(A["discordants"]), pickB(B["discordants"])
 
 
-def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
+def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
     import time
     t0 = time.time()
     signals, positions = _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly)
@@ -246,3 +247,10 @@ def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins
                 cand["endA"] = max(A["end"])
     STAGE_SECONDS["regroup + breakpoints"] = time.time() - t0
     return candidates
+
+
+def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
+    """``tiddit_cluster.main`` (tiddit_cluster.pyx:39-336): .tab files -> candidates dictionary.  (The collector is off while the row
+    tables are built: hostutil.quiet_gc.)"""
+    with quiet_gc():
+        return _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads)

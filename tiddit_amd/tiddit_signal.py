@@ -14,14 +14,17 @@ whole arrays — only the ~1 % of reads that are discordant, split or clipped ar
 """
 import itertools
 import os
+import re
+import shutil
 import time
 
 import numpy
 
 import ctypes
 
+from .hostutil import quiet_gc
 from . import _native, tiddit_coverage
-from .bamio import DeviceBatch, open_bam
+from .bamio import DeviceBatch, RecordView, open_bam
 
 _SA_OPS = {"M": 0, "S": 4, "H": 5, "D": 2, "I": 1}   # :23 — any other CIGAR letter raises KeyError, like the reference
 
@@ -53,10 +56,17 @@ def _leading_softclip(cigar):
     return n
 
 
+_CIGAR_OK = re.compile(r"(?:[0-9]+[^0-9])+\Z")          # ASCII digit runs each followed by ONE other character: the well-formed case
+_CIGAR_PAIR = re.compile(r"([0-9]+)([^0-9])")
+
+
 def find_SA_query_range(SA):
     """SA = one entry split on ',': rname,pos,strand,CIGAR,mapQ,NM  (:11-29)"""
-    parts = ["".join(x) for _, x in itertools.groupby(SA[3], key=str.isdigit)]
-    cigar = [(_SA_OPS[parts[i * 2 + 1]], int(parts[i * 2])) for i in range(0, int(len(parts) / 2))]
+    if _CIGAR_OK.match(SA[3]):                          # same pairs as the grouping below, without building the groups
+        cigar = [(_SA_OPS[op], int(n)) for n, op in _CIGAR_PAIR.findall(SA[3])]
+    else:
+        parts = ["".join(x) for _, x in itertools.groupby(SA[3], key=str.isdigit)]
+        cigar = [(_SA_OPS[parts[i * 2 + 1]], int(parts[i * 2])) for i in range(0, int(len(parts) / 2))]
     return _SASegment(int(SA[1]), SA[2] != "+", cigar)
 
 
@@ -128,6 +138,7 @@ class SelectedReads:
 
     def __init__(self, ctx, meta, raw_end, raw):
         self.ctx, self.meta, self.raw_end, self.raw = ctx, meta, raw_end, raw
+        self.raw_bytes = raw.tobytes()                  # the selected records are ~1.5 % of the batch: RecordView slices this copy
         self.tid, self.pos, self.end, self.flag, self.mate_tid, self.action = (meta[k] for k in ("tid", "pos", "end", "flag", "mate_tid", "action"))
         self.rec_off = numpy.concatenate([[0], raw_end[:-1]]).astype(numpy.uint64) if len(raw_end) else numpy.zeros(0, dtype=numpy.uint64)
         self.sa_off = numpy.where(meta["sa_rel"] >= 0, self.rec_off.astype(numpy.int64) + meta["sa_rel"], -1)
@@ -136,7 +147,6 @@ class SelectedReads:
         return len(self.meta)
 
     def record(self, k):
-        from .bamio import RecordView
         return RecordView(self, k)
 
     def clip_fasta(self, which, contig):
@@ -251,11 +261,15 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                     splits[chrom].append(split)
             t6 = time.time()
             T["split rows"] += t6 - t5
-            sflag, smate, spos, send = sel.flag, sel.mate_tid, sel.pos, sel.end
-            for k in numpy.flatnonzero(act & 8):
-                chrom, mate = names[stid[k]], names[smate[k]]
+            which = numpy.flatnonzero(act & 8)
+            rb = sel.raw_bytes
+            cols = zip(stid[which].tolist(), sel.mate_tid[which].tolist(), sel.pos[which].tolist(), sel.end[which].tolist(),
+                       sel.flag[which].tolist(), sel.rec_off[which].tolist())
+            for t_, m_, p_, e_, f_, o_ in cols:
+                chrom, mate = names[t_], names[m_]
                 chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
-                data[chrom].append([chrA, chrB, sel.record(k).query_name, int(spos[k]) + 1, int(send[k]) + 1, bool(sflag[k] & 0x10), chrom])
+                qname = rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode()          # block_size, 32 fixed bytes, then l_read_name bytes (NUL included)
+                data[chrom].append([chrA, chrB, qname, p_ + 1, e_ + 1, bool(f_ & 0x10), chrom])
             t0 = time.time()
             T["discordant select + rows"] += t0 - t6
             continue
@@ -325,7 +339,7 @@ def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bi
     return (chromosome, data[chromosome], splits[chromosome], coverage[chromosome], path)
 
 
-def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
+def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
     t = time.time()
     header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
         bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
@@ -376,9 +390,16 @@ def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_con
             for chrB in splits[chrA]:
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
-    with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "w") as f:             # :328-332
+    with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "wb") as f:            # :328-332 (line by line there; same bytes)
         for path in clip_fasta:
-            for line in open(path):
-                f.write(line)
+            with open(path, "rb") as g:
+                shutil.copyfileobj(g, f, 1 << 22)
     STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
     return coverage_data
+
+
+def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
+    """``tiddit_signal.main`` (tiddit_signal.pyx:230-334): signals of every contig -> discordants_/splits_ .tab, clips_ .fa; returns the
+    50-bp coverage dictionary.  (The collector is off while the row tables are built: hostutil.quiet_gc.)"""
+    with quiet_gc():
+        return _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len)

@@ -7,11 +7,12 @@ import ctypes
 
 import numpy
 
+from .hostutil import quiet_gc
 from . import _native
 from .bamio import open_bam
 
 
-def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
+def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     library = {}
     t = time.time()
     reader = open_bam(bam_file_name)
@@ -57,3 +58,9 @@ def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     print("Calculated statistics in: " + str(t - time.time()))
     print("")
     return library
+
+
+def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
+    """``tiddit_stats.statistics`` (tiddit_stats.py:5-78); the collector is off meanwhile (hostutil.quiet_gc)."""
+    with quiet_gc():
+        return _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads)
