@@ -675,8 +675,9 @@ def main():
         result["next_rows"] = nres
 
     # ---- BASELINE configs[3]: `tiddit --sv --skip_assembly` end to end, from the BAM file to the candidates table (rank 0)
-    if not args.no_sv_e2e and rank == 0:
-        result["sv_e2e"] = sv_e2e(args, ctx, world == 1 and not args.no_cpu_baseline)
+    # (one process, one GPU: at N > 1 the section is left out rather than run beside idle ranks)
+    if not args.no_sv_e2e and world == 1:
+        result["sv_e2e"] = sv_e2e(args, ctx, not args.no_cpu_baseline)
 
     if rank == 0:
         print(json.dumps(result))
