@@ -1,6 +1,7 @@
 """Drop-in for ``tiddit.tiddit_stats.statistics`` (tiddit_stats.py:5-78): library statistics from the
 first ``n_reads`` placed alignments — mean read length, insert-size mean / std / 99.9th percentile and
 the pair-orientation vote.  Same sampling rules, evaluated on the decoded arrays instead of per read."""
+import concurrent.futures
 import time
 
 import ctypes
@@ -19,17 +20,29 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     lib = _native.load()
     state = numpy.zeros(6, dtype=numpy.int64)
     chunks = []
-    for b in reader.batches():
-        n = len(b)
-        cols = [numpy.ascontiguousarray(getattr(b, k)) for k in ("tid", "pos", "mate_tid", "mate_pos", "tlen", "l_seq", "flag", "mapq")]
+
+    def scan(cols, n):
+        # the sampling loop of the reference (:17-47), read by read, in C (csrc/tdt_bam.hip: tdt_stats_scan); `state` carries over
         out = numpy.empty(n, dtype=numpy.int32)
         k = ctypes.c_size_t(0)
-        # the sampling loop of the reference (:17-47), read by read, in C (csrc/tdt_bam.hip: tdt_stats_scan)
         _native.check(lib.tdt_stats_scan(*[_native.ptr(c) for c in cols], n, int(n_reads), int(min_mapq), int(max_ins_len), _native.ptr(state),
                                          _native.ptr(out), ctypes.byref(k)))
         chunks.append(out[:k.value].copy())
-        if state[5]:
-            break
+
+    # one worker runs the loop of batch k (ctypes drops the GIL) while the device inflates and decodes batch k + 1; batches are
+    # scanned in order, and the pass stops one batch after the loop has seen its n_reads-th read
+    pending = None
+    with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+        for b in reader.batches():
+            cols = [numpy.ascontiguousarray(getattr(b, k)) for k in ("tid", "pos", "mate_tid", "mate_pos", "tlen", "l_seq", "flag", "mapq")]
+            if pending is not None:
+                pending.result()
+                if state[5]:
+                    pending = None
+                    break
+            pending = pool.submit(scan, cols, len(b))
+        if pending is not None:
+            pending.result()
     reader.close()
     insert_size = numpy.concatenate(chunks) if chunks else numpy.zeros(0, dtype=numpy.int32)
     is_innie, is_outtie = int(state[3]), int(state[4])
