@@ -352,10 +352,6 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     __syncthreads();
     DT_MARK(3);
 
-#ifdef DT_ABL_STOP_AFTER_X
-    if (segA[tid] == 0x1234u) P.lab[tid] = 1;
-    return;
-#endif
     // ---- stable y order inside every owned cluster (:76-81): rank = members sorting before the point
     unsigned ext[DT_WPW];      // a | e << 16 of the point's cluster (0: not a member of an owned small cluster)
     bool large = false;
@@ -379,10 +375,6 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             const int a = ext[s] & 0xffff, e = ext[s] >> 16;
             const unsigned yq = yv[q];
             int rank = 0;
-#ifdef DT_ABL_NORANK
-            rank = q - a;
-            if (false)
-#endif
             // 8 members per trip, branch-free: one address, eight loads at constant offsets (reads past the cluster's end stay inside
             // the workgroup's LDS and are masked).  Per member four vector instructions: two compares of the trip's distances with a
             // constant (masks in SGPRs), one subtract-with-borrow whose borrow-out IS the sort predicate, one add-with-carry
@@ -406,10 +398,6 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     __syncthreads();
     DT_MARK(5);
 
-#ifdef DT_ABL_STOP_AFTER_RANK
-    if (ysrt[tid] == 0x12345u) P.lab[tid] = 1;
-    return;
-#endif
     // ---- y pass on the sorted values: window test with m-1 following members (:90-99)
 #pragma unroll
     for (int s = 0; s < DT_WPW; s++) {
