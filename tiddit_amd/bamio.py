@@ -461,7 +461,7 @@ class DeviceBamReader:
             import os
             from concurrent.futures import ThreadPoolExecutor
             fd, fsize, fo = self._f.fileno(), x_hi, b_lo           # this reader's byte range of the file
-            pool = ThreadPoolExecutor(int(os.environ.get("TIDDIT_READ_THREADS", "8")))
+            pool = ThreadPoolExecutor(int(os.environ.get("TIDDIT_READ_THREADS", "16")))       # (8 threads: 9.2 GB/s of BGZF from the page cache, 16: 10.5)
             try:
                 k, carry = 0, np.zeros(0, dtype=np.uint8)
                 eof = False

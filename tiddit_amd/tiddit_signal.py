@@ -12,6 +12,7 @@ histogram (bin 50, same read filter, :171-182), and the signal predicates (:184-
 whole arrays — only the ~1 % of reads that are discordant, split or clipped are touched one by one.
 ``threads`` and ``skip_index`` are accepted for signature compatibility and ignored (no index needed).
 """
+import concurrent.futures
 import itertools
 import os
 import re
@@ -218,6 +219,39 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     T.clear()
     T.update({"ingest (inflate + decode, device)": 0.0, "coverage push": 0.0, "field copies + predicates (host)": 0.0, "clip rows": 0.0,
               "split rows": 0.0, "discordant select + rows": 0.0})
+    def rows_of(sel):
+        """clip / split / discordant rows of one batch's selected reads (host copies only: runs on the worker thread while the device
+        ingests the next batch — the main thread waits inside the library without the GIL)"""
+        t4 = time.time()
+        stid, act = sel.tid, sel.action
+        clip_k = numpy.flatnonzero(act & 2)
+        if len(clip_k):
+            edges = numpy.flatnonzero(numpy.diff(stid[clip_k])) + 1
+            for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(clip_k)]])):
+                chrom = names[stid[clip_k[lo]]]
+                clips[chrom].append([sel.clip_fasta(clip_k[lo:hi], chrom), ""])
+        t5 = time.time()
+        T["clip rows"] += t5 - t4
+        for k in numpy.flatnonzero(act & 4):
+            chrom = names[stid[k]]
+            split = SA_analysis(_ReadProxy(sel, k), min_q, "SA", chrom)
+            if split:
+                splits[chrom].append(split)
+        t6 = time.time()
+        T["split rows"] += t6 - t5
+        which = numpy.flatnonzero(act & 8)
+        rb = sel.raw_bytes
+        cols = zip(stid[which].tolist(), sel.mate_tid[which].tolist(), sel.pos[which].tolist(), sel.end[which].tolist(),
+                   sel.flag[which].tolist(), sel.rec_off[which].tolist())
+        for t_, m_, p_, e_, f_, o_ in cols:
+            chrom, mate = names[t_], names[m_]
+            chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
+            qname = rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode()          # block_size, 32 fixed bytes, then l_read_name bytes (NUL included)
+            data[chrom].append([chrA, chrB, qname, p_ + 1, e_ + 1, bool(f_ & 0x10), chrom])
+        T["discordant select + rows"] += time.time() - t6
+
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+    pending = None
     t0 = time.time()
     for b in reader.batches():
         t1 = time.time()
@@ -245,33 +279,10 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
             t4 = time.time()
             T["predicates + gather of the selected reads (device)"] = T.get("predicates + gather of the selected reads (device)", 0.0) + (t4 - t3) + (t2 - t1)
-            stid, act = sel.tid, sel.action
-            clip_k = numpy.flatnonzero(act & 2)
-            if len(clip_k):
-                edges = numpy.flatnonzero(numpy.diff(stid[clip_k])) + 1
-                for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(clip_k)]])):
-                    chrom = names[stid[clip_k[lo]]]
-                    clips[chrom].append([sel.clip_fasta(clip_k[lo:hi], chrom), ""])
-            t5 = time.time()
-            T["clip rows"] += t5 - t4
-            for k in numpy.flatnonzero(act & 4):
-                chrom = names[stid[k]]
-                split = SA_analysis(_ReadProxy(sel, k), min_q, "SA", chrom)
-                if split:
-                    splits[chrom].append(split)
-            t6 = time.time()
-            T["split rows"] += t6 - t5
-            which = numpy.flatnonzero(act & 8)
-            rb = sel.raw_bytes
-            cols = zip(stid[which].tolist(), sel.mate_tid[which].tolist(), sel.pos[which].tolist(), sel.end[which].tolist(),
-                       sel.flag[which].tolist(), sel.rec_off[which].tolist())
-            for t_, m_, p_, e_, f_, o_ in cols:
-                chrom, mate = names[t_], names[m_]
-                chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
-                qname = rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode()          # block_size, 32 fixed bytes, then l_read_name bytes (NUL included)
-                data[chrom].append([chrA, chrB, qname, p_ + 1, e_ + 1, bool(f_ & 0x10), chrom])
+            if pending is not None:
+                pending.result()                                  # rows are built in batch order, one batch behind the device
+            pending = pool.submit(rows_of, sel)
             t0 = time.time()
-            T["discordant select + rows"] += t0 - t6
             continue
         primary = ok_contig & ((flag & 0x404) == 0) & ((flag & 0x900) == 0) & (b.mapq >= min_q)   # :171,:184,:188
         same_chr = b.mate_tid == tid
@@ -307,6 +318,9 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             data[chrom].append([chrA, chrB, b.record(i).query_name, int(b.pos[i]) + 1, int(b.end[i]) + 1, bool(flag[i] & 0x10), chrom])
         t0 = time.time()
         T["discordant select + rows"] += t0 - t6
+    if pending is not None:
+        pending.result()
+    pool.shutdown()
     reader.close()
     chromosomes = [n for n, ok in zip(names, big) if ok]
     coverage = {n: hist.finish(n) for n in chromosomes}
