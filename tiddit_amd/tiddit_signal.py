@@ -253,74 +253,76 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     pending = None
     t0 = time.time()
-    for b in reader.batches():
-        t1 = time.time()
-        T["ingest (inflate + decode, device)"] += t1 - t0
-        if not isinstance(b, DeviceBatch):
-            tid = b.tid
-            flag = b.flag.astype(numpy.int32)
-            placed = tid >= 0
-            ok_contig = numpy.zeros(len(tid), dtype=bool)
-            ok_contig[placed] = big[tid[placed]]
-        t2 = time.time()
-        # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
-        if isinstance(b, DeviceBatch):                      # the decoded arrays are already in HBM
-            hist.push_device_batch(b, min_q, big)
-        else:
-            edges = numpy.flatnonzero(numpy.diff(tid)) + 1
-            for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
-                t = int(tid[lo])
-                if t >= 0 and big[t]:
-                    hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
-        t3 = time.time()
-        T["coverage push"] += t3 - t2
-        if isinstance(b, DeviceBatch):
-            # the per-read chain of worker (:171-221) on the device; only the selected reads come back (fields + raw records)
-            sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
+    try:
+        for b in reader.batches():
+            t1 = time.time()
+            T["ingest (inflate + decode, device)"] += t1 - t0
+            if not isinstance(b, DeviceBatch):
+                tid = b.tid
+                flag = b.flag.astype(numpy.int32)
+                placed = tid >= 0
+                ok_contig = numpy.zeros(len(tid), dtype=bool)
+                ok_contig[placed] = big[tid[placed]]
+            t2 = time.time()
+            # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
+            if isinstance(b, DeviceBatch):                      # the decoded arrays are already in HBM
+                hist.push_device_batch(b, min_q, big)
+            else:
+                edges = numpy.flatnonzero(numpy.diff(tid)) + 1
+                for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
+                    t = int(tid[lo])
+                    if t >= 0 and big[t]:
+                        hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
+            t3 = time.time()
+            T["coverage push"] += t3 - t2
+            if isinstance(b, DeviceBatch):
+                # the per-read chain of worker (:171-221) on the device; only the selected reads come back (fields + raw records)
+                sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
+                t4 = time.time()
+                T["predicates + gather of the selected reads (device)"] = T.get("predicates + gather of the selected reads (device)", 0.0) + (t4 - t3) + (t2 - t1)
+                if pending is not None:
+                    pending.result()                                  # rows are built in batch order, one batch behind the device
+                pending = pool.submit(rows_of, sel)
+                t0 = time.time()
+                continue
+            primary = ok_contig & ((flag & 0x404) == 0) & ((flag & 0x900) == 0) & (b.mapq >= min_q)   # :171,:184,:188
+            same_chr = b.mate_tid == tid
+            abs_isize = numpy.abs(b.tlen.astype(numpy.int64))
+            # clipped reads for local assembly (:190-197)
+            f_op, f_len = b.cigar_first & 0xf, b.cigar_first >> 4
+            l_op, l_len = b.cigar_last & 0xf, b.cigar_last >> 4
+            has_cigar = b.cigar_first != 0xffffffff
+            left = (f_op == 4) & (f_len > min_clip_len) & (l_op == 0) & (l_len > min_anchor_len)
+            right = (l_op == 4) & (l_len > min_clip_len) & (f_op == 0) & (f_len > min_anchor_len)
+            clip_idx = numpy.flatnonzero(primary & (abs_isize < max_ins) & same_chr & has_cigar & (left | right))
+            split_idx = numpy.flatnonzero(primary & (b.sa_off >= 0))
             t4 = time.time()
-            T["predicates + gather of the selected reads (device)"] = T.get("predicates + gather of the selected reads (device)", 0.0) + (t4 - t3) + (t2 - t1)
-            if pending is not None:
-                pending.result()                                  # rows are built in batch order, one batch behind the device
-            pending = pool.submit(rows_of, sel)
+            T["field copies + predicates (host)"] += (t2 - t1) + (t4 - t3)
+            for i in clip_idx:
+                rec = b.record(i)
+                chrom = names[tid[i]]
+                clips[chrom].append([">{}|{}|{}\n".format(rec.query_name, chrom, int(b.pos[i]) + 1), rec.query_sequence + "\n"])
+            t5 = time.time()
+            T["clip rows"] += t5 - t4
+            # split reads (:199-202)
+            for i in split_idx:
+                chrom = names[tid[i]]
+                split = SA_analysis(_ReadProxy(b, i), min_q, "SA", chrom)
+                if split:
+                    splits[chrom].append(split)
+            t6 = time.time()
+            T["split rows"] += t6 - t5
+            # discordant pairs (:204-221): predicate + order-preserving compaction on the device
+            for i in select_discordant(b, big, min_q, max_ins):
+                chrom, mate = names[tid[i]], names[b.mate_tid[i]]
+                chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
+                data[chrom].append([chrA, chrB, b.record(i).query_name, int(b.pos[i]) + 1, int(b.end[i]) + 1, bool(flag[i] & 0x10), chrom])
             t0 = time.time()
-            continue
-        primary = ok_contig & ((flag & 0x404) == 0) & ((flag & 0x900) == 0) & (b.mapq >= min_q)   # :171,:184,:188
-        same_chr = b.mate_tid == tid
-        abs_isize = numpy.abs(b.tlen.astype(numpy.int64))
-        # clipped reads for local assembly (:190-197)
-        f_op, f_len = b.cigar_first & 0xf, b.cigar_first >> 4
-        l_op, l_len = b.cigar_last & 0xf, b.cigar_last >> 4
-        has_cigar = b.cigar_first != 0xffffffff
-        left = (f_op == 4) & (f_len > min_clip_len) & (l_op == 0) & (l_len > min_anchor_len)
-        right = (l_op == 4) & (l_len > min_clip_len) & (f_op == 0) & (f_len > min_anchor_len)
-        clip_idx = numpy.flatnonzero(primary & (abs_isize < max_ins) & same_chr & has_cigar & (left | right))
-        split_idx = numpy.flatnonzero(primary & (b.sa_off >= 0))
-        t4 = time.time()
-        T["field copies + predicates (host)"] += (t2 - t1) + (t4 - t3)
-        for i in clip_idx:
-            rec = b.record(i)
-            chrom = names[tid[i]]
-            clips[chrom].append([">{}|{}|{}\n".format(rec.query_name, chrom, int(b.pos[i]) + 1), rec.query_sequence + "\n"])
-        t5 = time.time()
-        T["clip rows"] += t5 - t4
-        # split reads (:199-202)
-        for i in split_idx:
-            chrom = names[tid[i]]
-            split = SA_analysis(_ReadProxy(b, i), min_q, "SA", chrom)
-            if split:
-                splits[chrom].append(split)
-        t6 = time.time()
-        T["split rows"] += t6 - t5
-        # discordant pairs (:204-221): predicate + order-preserving compaction on the device
-        for i in select_discordant(b, big, min_q, max_ins):
-            chrom, mate = names[tid[i]], names[b.mate_tid[i]]
-            chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
-            data[chrom].append([chrA, chrB, b.record(i).query_name, int(b.pos[i]) + 1, int(b.end[i]) + 1, bool(flag[i] & 0x10), chrom])
-        t0 = time.time()
-        T["discordant select + rows"] += t0 - t6
-    if pending is not None:
-        pending.result()
-    pool.shutdown()
+            T["discordant select + rows"] += t0 - t6
+        if pending is not None:
+            pending.result()
+    finally:
+        pool.shutdown(wait=True)                              # (also on an error: no row thread outlives the scan)
     reader.close()
     chromosomes = [n for n, ok in zip(names, big) if ok]
     coverage = {n: hist.finish(n) for n in chromosomes}
