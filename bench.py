@@ -456,7 +456,7 @@ def main():
             sres = {"metric": "tdt_sort_dbscan from host int64 columns (what tiddit_cluster.main calls), signals/sec",
                     "one_bucket": {"signals": n, "ms": 1e3 * t_one, "value": n / t_one},
                     "many_buckets": {"signals": nm, "buckets": int(len(sizes)), "largest_bucket": int(sizes.max()), "ms": 1e3 * t_many, "value": nm / t_many},
-                    "unit": "signals/s", "note": "includes the H2D copy of 16 B/signal, the device radix sort by (bucket, posA), both clustering passes and the D2H copy of 12 B/signal"}
+                    "unit": "signals/s", "note": "includes the host passes over the two int64 columns (16 B/signal read), the H2D copy of their 32-bit offsets (8 B/signal), the device radix sort by (bucket, posA), both clustering passes and the D2H copy of order + int32 labels (8 B/signal)"}
             if world == 1 and not args.no_cpu_baseline:
                 import oracle
                 o1 = np.argsort(pa, kind="stable")

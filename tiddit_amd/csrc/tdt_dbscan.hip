@@ -930,6 +930,12 @@ __global__ __launch_bounds__(DB_THREADS) void sd_unpack(const unsigned long long
     perm[i] = src;
 }
 
+// labels on the wire: -1 or an id below 2^31, so 4 bytes each cross PCIe and the host widens them again (exact)
+__global__ __launch_bounds__(DB_THREADS) void sd_labels_i32(const double *__restrict__ lab, int n, int *__restrict__ out) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i < n) out[i] = (int)lab[i];
+}
+
 extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
                                double eps, int m, uint32_t *perm_out, double *labels_out) {
     if (!ctx || nb < 1 || !bucket_off || (n && (!posA || !posB || !perm_out || !labels_out))) {
@@ -1019,14 +1025,18 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     TDT_CHECK_LAUNCH();
     rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, nullptr);
     if (rc) return rc;
-    // results come back through the pinned block (its input columns are consumed by now), then go to the caller's arrays on the host threads
-    double *hlab = (double *)h;
-    uint32_t *hperm = (uint32_t *)((char *)h + n * 8);
-    TDT_HIP(hipMemcpyAsync(hlab, dlab, n * 8, hipMemcpyDeviceToHost, st));
+    // results come back through the pinned block (its input columns are consumed by now), labels as int32 (dv0 is free again), then go
+    // to the caller's arrays on the host threads
+    int *dlab32 = (int *)dv0;
+    hipLaunchKernelGGL(sd_labels_i32, dim3(blocks), dim3(DB_THREADS), 0, st, (const double *)dlab, (int)n, dlab32);
+    TDT_CHECK_LAUNCH();
+    int *hlab = (int *)h;
+    uint32_t *hperm = (uint32_t *)((char *)h + n * 4);
+    TDT_HIP(hipMemcpyAsync(hlab, dlab32, n * 4, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipMemcpyAsync(hperm, dperm, n * 4, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipStreamSynchronize(st));
     par([&](int, size_t i0, size_t i1) {
-        memcpy(labels_out + i0, hlab + i0, (i1 - i0) * 8);
+        for (size_t i = i0; i < i1; i++) labels_out[i] = (double)hlab[i];
         memcpy(perm_out + i0, hperm + i0, (i1 - i0) * 4);
     });
     return TDT_OK;
