@@ -457,7 +457,11 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
                 const unsigned rs = (unsigned)sv[j] - Kz;    // offsets from the start of bin K: first base, one past the last base
                 const unsigned re1 = (unsigned)ev[j] - Kz;
                 const unsigned len = re1 - rs;               // e - s (wraps to a huge value when e <= s)
-                const bool cand = ((fl[j] & FMASK) == 0) & ((int)mq[j] >= P.min_q);   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+                // __main__.py:231-235 / tiddit_signal.pyx:171-181.  Packed records keep duplicate | unmapped | mapq in the top byte of
+                // the high word, so "no flag and mapq >= min_q" is ONE range test of that word: [min_q << 24, 64 << 24)
+                bool cand;
+                if constexpr (PACKED) cand = (unsigned)(cur.w[j] >> 32) - ((unsigned)P.min_q << 24) < ((64u - (unsigned)P.min_q) << 24);
+                else cand = ((fl[j] & FMASK) == 0) & ((int)mq[j] >= P.min_q);
                 const bool r1_ = rs >= z;                    // first bin = K + 1
                 const unsigned rl = re1 - 1u;                                    // offset of the last base
                 const unsigned dq = __umul24(rl, P.m15) >> P.k15;                // (e - 1 - K z) / z, exact for e - 1 - K z < 2^15
@@ -576,7 +580,11 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
                 const unsigned rs = (unsigned)sv[j] - Kz;    // offsets from the start of bin K: first base, one past the last base
                 const unsigned re1 = (unsigned)ev[j] - Kz;
                 const unsigned len = re1 - rs;               // e - s (wraps to a huge value when e <= s)
-                const bool cand = ((fl[j] & FMASK) == 0) & ((int)mq[j] >= P.min_q);   // __main__.py:231-235 / tiddit_signal.pyx:171-181
+                // __main__.py:231-235 / tiddit_signal.pyx:171-181.  Packed records keep duplicate | unmapped | mapq in the top byte of
+                // the high word, so "no flag and mapq >= min_q" is ONE range test of that word: [min_q << 24, 64 << 24)
+                bool cand;
+                if constexpr (PACKED) cand = (unsigned)(cur.w[j] >> 32) - ((unsigned)P.min_q << 24) < ((64u - (unsigned)P.min_q) << 24);
+                else cand = ((fl[j] & FMASK) == 0) & ((int)mq[j] >= P.min_q);
                 // window path: first bin K or K+1, at most xmax bases past the start of bin K (so the 24-bit multiply below
                 // is an exact division and the last bin is at most K + COV_DQMAX)
                 const bool fast = cand & safe & (rs < 2u * z) & (len - 1u < P.xmax) & (re1 <= P.xmax);
@@ -976,6 +984,7 @@ extern "C" int tdt_cov_push_packed_device_multi(tdt_cov *c, int n_items, const i
         tdt_set_error("tdt_cov_push_packed_device_multi: packed records keep min(mapq, 63); min_q %d needs the unpacked entry point", min_q);
         return TDT_E_UNSUPPORTED;
     }
+    if (min_q < 0) min_q = 0;                 // every mapq passes either way; the kernel's range test wants a field value
     TDT_HIP(hipSetDevice(c->ctx->device));
     std::vector<CovItem> items;
     unsigned long long blocks = 0;
