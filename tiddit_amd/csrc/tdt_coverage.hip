@@ -221,11 +221,14 @@ __global__ void cov_pack(const int32_t *__restrict__ start, const int32_t *__res
 #ifndef COV_MIN_WAVES
 #define COV_MIN_WAVES 4                            // waves per SIMD the register allocation must allow (MODE 0)
 #endif
+#ifndef COV_MIN_WAVES4
+#define COV_MIN_WAVES4 3                           // ... MODE 0 fed from four arrays: at 4 it spills 14 registers to scratch
+#endif
 #ifndef COV_MIN_WAVES1
 #define COV_MIN_WAVES1 4                           // ... MODE 1
 #endif
 template <bool LDS_LUT, int MODE, bool Z1, int RPL, bool PACKED>
-__global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_WAVES) void cov_accumulate(CovParams P) {
+__global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (PACKED ? COV_MIN_WAVES : COV_MIN_WAVES4)) void cov_accumulate(CovParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
     // everything lives in the dynamic region (a static __shared__ in front of it would shift its
     // base off 16-byte alignment): [0..11] scratch (4 scan words, then the bin of every tile's last read), [12..) window
@@ -398,6 +401,19 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
         int sv[RPL], ev[RPL];
         unsigned mq[RPL], fl[RPL];
         constexpr unsigned FMASK = PACKED ? 0x3u : 0x404u;       // unmapped / duplicate bits of fl[]
+        // The small-bin flavour never folds a read of the escape span (16 Mb) into registers: it reaches the literal path, which looks its
+        // true end up there (ESC_LATE: 2 % of that launch).  The other flavours patch the ends up front — the same change costs the
+        // 500-bp flavour, which has no register to spare, 21 spilled registers and a quarter of its speed.
+        constexpr bool ESC_LATE = PACKED && MODE == 1 && LDS_LUT && !Z1;
+        auto true_end = [&](int j) -> int {
+            if constexpr (ESC_LATE) {
+                if (((unsigned)(cur.w[j] >> 32) & COV_PK_SPAN) == COV_PK_SPAN) {
+                    const unsigned long long idx = t0 + (unsigned long long)tid * RPL + j;
+                    return (I.end && idx < r1) ? I.end[idx] : sv[j];
+                }
+            }
+            return ev[j];
+        };
         if constexpr (PACKED) {
             bool esc = false;
 #pragma unroll
@@ -407,7 +423,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
                 ev[j] = sv[j] + (int)(info & COV_PK_SPAN);
                 mq[j] = (info >> 24) & 63u;
                 fl[j] = info >> 30;
-                esc = esc || (info & COV_PK_SPAN) == COV_PK_SPAN;
+                if (!ESC_LATE) esc = esc || (info & COV_PK_SPAN) == COV_PK_SPAN;
             }
             if (esc) {                                            // reads of >= 16 Mb: the end array has the truth
                 const unsigned long long idx = t0 + (unsigned long long)tid * RPL;
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
 #pragma unroll
                 for (int j = 0; j < RPL; j++)
                     if (slowmask & (1u << j)) {
-                        const int s_ = sv[j], e_ = ev[j];
+                        const int s_ = sv[j], e_ = true_end(j);
                         if (s_ < 0 || e_ <= s_ || div(e_ - 1) > last_bin) bad = true;
                         else { nkept++; slow_read(s_, e_); }
                     }
@@ -616,7 +632,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : COV_MIN_W
 #pragma unroll
                 for (int j = 0; j < RPL; j++)
                     if (slowmask & (1u << j)) {
-                        const int s = sv[j], e = ev[j];
+                        const int s = sv[j], e = true_end(j);
                         if (s < 0 || e <= s || div(e - 1) > last_bin) bad = true;
                         else { nkept++; slow_read(s, e); }
                     }
