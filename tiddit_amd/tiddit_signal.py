@@ -16,7 +16,6 @@ import concurrent.futures
 import itertools
 import os
 import re
-import shutil
 import time
 
 import numpy
@@ -368,22 +367,25 @@ def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_co
     splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
     os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
     clip_fasta = []
-    for chrom in chromosomes:                                            # results in contig order (:262-284)
-        print("Collecting signals on contig: {}".format(chrom))
-        for signal in res_data[chrom]:
-            if signal[0] not in data:
-                continue
-            data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
-        for signal in res_splits[chrom]:
-            if signal[0] not in splits:
-                continue
-            splits[signal[0]][signal[1]].setdefault(signal[2], [])
-            splits[signal[0]][signal[1]][signal[2]] += signal[3:]
-        path = "{}_tiddit/clips/{}.fa".format(prefix, chrom)
-        with open(path, "w") as f:
-            for clip in res_clips[chrom]:
-                f.write("".join(clip))
-        clip_fasta.append(path)
+    with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "w") as all_clips:      # (written last in the reference; same bytes)
+        for chrom in chromosomes:                                            # results in contig order (:262-284)
+            print("Collecting signals on contig: {}".format(chrom))
+            for signal in res_data[chrom]:
+                if signal[0] not in data:
+                    continue
+                data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
+            for signal in res_splits[chrom]:
+                if signal[0] not in splits:
+                    continue
+                splits[signal[0]][signal[1]].setdefault(signal[2], [])
+                splits[signal[0]][signal[1]][signal[2]] += signal[3:]
+            path = "{}_tiddit/clips/{}.fa".format(prefix, chrom)
+            with open(path, "w") as f:
+                for clip in res_clips[chrom]:
+                    text = "".join(clip)
+                    f.write(text)
+                    all_clips.write(text)                # clips_{sample}.fa is the per-contig files one after the other (:328-332)
+            clip_fasta.append(path)
     print("total", time.time() - t)
     print("Writing signals to file")
 
@@ -406,10 +408,6 @@ def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_co
             for chrB in splits[chrA]:
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
-    with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "wb") as f:            # :328-332 (line by line there; same bytes)
-        for path in clip_fasta:
-            with open(path, "rb") as g:
-                shutil.copyfileobj(g, f, 1 << 22)
     STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
     return coverage_data
 
