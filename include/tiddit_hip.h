@@ -141,6 +141,11 @@ int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32_t *d_y, si
  * perm_out[i] = index (within the whole input) of the point at sorted position i. */
 int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
                     double eps, int m, uint32_t *perm_out, double *labels_out);
+/* The same call, also reporting per bucket the number of x-runs (x_coordinate_clustering's cluster_id + 1, DBSCAN.py:33-64) in
+ * runs_out[nb] and DBSCAN.main's final cluster_id in last_out[nb] (either may be NULL): what a caller that cut ONE oversized
+ * bucket into pieces at gaps >= eps needs to re-base the pieces' ids (DBSCAN.py:112-122 numbers extra sub-runs after ALL x-runs). */
+int tdt_sort_dbscan_ex(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
+                       double eps, int m, uint32_t *perm_out, double *labels_out, int64_t *runs_out, int64_t *last_out);
 
 /* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) ------------------------------------- *
  * The clustering path shards by (chrA,chrB) bucket (tiddit_cluster.pyx:140-154 keeps no cross-bucket state): every rank
@@ -160,6 +165,17 @@ int tdt_comm_destroy(tdt_comm *comm);
 int tdt_allgatherv(tdt_comm *comm, const void *d_send, size_t send_count, void *d_recv, const size_t *counts, const size_t *displs,
                    int elem_bytes);
 int tdt_allreduce_sum_f64(tdt_comm *comm, double *d_buf, size_t n);
+/* The broadcasts tdt_allgatherv issues, as a pure host function (no RCCL, no GPU): ops[k] = root rank, destination byte range in
+ * d_recv, and whether this rank reads its send buffer (it is the root).  Empty contributions issue nothing; overlapping ranges and
+ * ranges beyond recv_capacity_bytes (0 = not checked) are refused.  ops must hold `world` entries. */
+typedef struct tdt_gather_op {
+    int root;
+    int from_send;
+    size_t offset_bytes;
+    size_t nbytes;
+} tdt_gather_op;
+int tdt_allgatherv_plan(int rank, int world, const size_t *counts, const size_t *displs, int elem_bytes, size_t recv_capacity_bytes,
+                        tdt_gather_op *ops, int *n_ops);
 
 /* ---- discordant-pair candidate selection ------------------------------------------------------ *
  * Replaces the per-read predicate chain of tiddit_signal.worker (tiddit_signal.pyx:171-211): a read is a

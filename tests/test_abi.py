@@ -59,3 +59,58 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+class _GatherOp(ctypes.Structure):
+    _fields_ = [("root", ctypes.c_int), ("from_send", ctypes.c_int), ("offset_bytes", ctypes.c_size_t), ("nbytes", ctypes.c_size_t)]
+
+
+def _plan(lib, rank, world, counts, displs, elem, cap=0):
+    import numpy as np
+    c = np.ascontiguousarray(counts, dtype=np.uint64)
+    d = np.ascontiguousarray(displs, dtype=np.uint64)
+    ops = (_GatherOp * world)()
+    n = ctypes.c_int(0)
+    rc = lib.tdt_allgatherv_plan(rank, world, c.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p), elem, cap,
+                                 ctypes.cast(ops, ctypes.c_void_p), ctypes.byref(n))
+    return rc, [(o.root, o.from_send, o.offset_bytes, o.nbytes) for o in ops[:n.value]]
+
+
+def test_allgatherv_layout_for_2_to_8_ranks(native):
+    """tdt_allgatherv's count / displacement arithmetic without RCCL: the broadcast list of every rank, replayed on host buffers,
+    leaves the concatenation of all contributions on every rank — for N = 2..8, empty contributions and gaps included"""
+    import numpy as np
+    lib = native.load()
+    rng = np.random.default_rng(4)
+    for world in range(2, 9):
+        for elem in (1, 4, 8):
+            for trial in range(6):
+                counts = rng.integers(0, 50, world)
+                counts[rng.integers(0, world)] = 0                         # at least one rank with nothing to send
+                if trial == 0:
+                    counts[:] = 0
+                gap = rng.integers(0, 3, world)                            # displacements need not be dense
+                displs = np.concatenate([[0], np.cumsum(counts + gap)[:-1]])
+                total = int((displs + counts).max()) * elem
+                send = [rng.integers(0, 256, int(counts[r]) * elem, dtype=np.uint8) for r in range(world)]
+                recv = [np.full(total, 0xEE, dtype=np.uint8) for _ in range(world)]
+                plans = []
+                for r in range(world):
+                    rc, ops = _plan(lib, r, world, counts, displs, elem, total)
+                    assert rc == 0
+                    plans.append(ops)
+                    assert [o[0] for o in ops] == [q for q in range(world) if counts[q]]          # one broadcast per non-empty rank, rank order
+                    assert [o[1] for o in ops] == [int(q == r) for q in range(world) if counts[q]]  # only the root reads its send buffer
+                assert all([(o[0], o[2], o[3]) for o in p] == [(o[0], o[2], o[3]) for o in plans[0]] for p in plans)   # same group on all ranks
+                for root, _, off, nb in plans[0]:                          # replay: ncclBroadcast(root) delivers the root's bytes everywhere
+                    for r in range(world):
+                        recv[r][off:off + nb] = send[root]
+                for r in range(world):
+                    for q in range(world):
+                        o = int(displs[q]) * elem
+                        assert np.array_equal(recv[r][o:o + int(counts[q]) * elem], send[q])
+    # refused: overlapping ranges, ranges beyond the receive buffer, bad rank
+    assert _plan(lib, 0, 2, [4, 4], [0, 2], 4)[0] != 0
+    assert _plan(lib, 0, 2, [4, 4], [0, 4], 4, cap=31)[0] != 0
+    assert _plan(lib, 0, 2, [4, 4], [0, 4], 4, cap=32)[0] == 0
+    assert _plan(lib, 2, 2, [4, 4], [0, 4], 4)[0] != 0

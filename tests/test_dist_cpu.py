@@ -232,3 +232,123 @@ def test_bench_shared_clustering_step_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one oversized bucket cut at posA gaps >= eps: planner, halo point and id re-basing against the oracle on
+# the UNCUT bucket
+
+def _oracle_cluster_buckets(buckets, epsilon, m, ctx=None, counts=False):
+    """tiddit_cluster.cluster_buckets with the C oracle standing in for tdt_sort_dbscan_ex (same contract)"""
+    import oracle
+    labs, runs, last = [], [], []
+    for b in buckets:
+        b = np.asarray(b, dtype=np.int64).reshape(-1, 2) if len(b) else np.zeros((0, 2), np.int64)
+        o = np.argsort(b[:, 0], kind="stable")
+        d = np.ascontiguousarray(b[o])
+        lab = np.empty(len(b))
+        if len(b):
+            xl, xid = oracle.x_coordinate_clustering(d, epsilon, m)
+            yl, yid = oracle.y_coordinate_clustering(d, epsilon, m, xid, xl.copy())
+            lab[o] = yl
+        else:
+            xid = yid = -1
+        labs.append(lab)
+        runs.append(xid + 1)
+        last.append(yid)
+    return (labs, np.array(runs, np.int64), np.array(last, np.int64)) if counts else labs
+
+
+def _clumpy_bucket(rng, n, span, eps):
+    """signals in clumps (clusters with several y sub-runs) over sparse noise: gaps >= eps exist between clumps"""
+    centres = rng.integers(0, span, max(2, n // 40))
+    x = np.concatenate([rng.choice(centres, n - n // 5) + rng.integers(0, eps * 2, n - n // 5), rng.integers(0, span, n // 5)])
+    y = x + rng.choice([300, 5000, 90000], len(x)) + rng.integers(0, eps, len(x))
+    p = rng.permutation(len(x))
+    return np.stack([x[p], y[p]], 1).astype(np.int64)
+
+
+def test_plan_bucket_cuts_are_legal_gaps():
+    from tiddit_amd.dist import plan_bucket_cuts
+    rng = np.random.default_rng(3)
+    for eps in (1, 7.5, 120, 500):
+        b = _clumpy_bucket(rng, 4000, 3_000_000, int(eps) + 1)
+        ts, w = plan_bucket_cuts(b[:, 0], eps, 6)
+        assert ts == sorted(set(ts)) and len(ts) >= 2 and w >= eps
+        for t in ts:
+            assert not ((b[:, 0] >= t) & (b[:, 0] < t + w)).any()           # nothing inside the gap ...
+            assert (b[:, 0] < t).any() and (b[:, 0] >= t + w).any()         # ... and signals on both sides
+    assert plan_bucket_cuts(np.arange(100), 5, 4) == ([], 0)                # no gap anywhere: not cut
+    assert plan_bucket_cuts(np.array([1, 2, 3]), 1, 4) == ([], 0)
+    assert plan_bucket_cuts(np.arange(0, 100000, 1000), 0, 4) == ([], 0)   # eps 0: nothing clusters, nothing to plan
+
+
+def test_cut_pieces_rebased_equal_uncut_bucket(monkeypatch):
+    """pieces (with their halo point) clustered independently + rebase_pieces == DBSCAN.main on the whole bucket, incl. the
+    short-last-window quirk (DBSCAN.py:41-43) that a cut without the halo gets wrong"""
+    import oracle
+    from tiddit_amd import tiddit_cluster as tc
+    monkeypatch.setattr(tc, "cluster_buckets", _oracle_cluster_buckets)
+    rng = np.random.default_rng(11)
+    halo_mattered = 0
+    for trial in range(40):
+        eps, m = int(rng.choice([40, 150, 500])), int(rng.choice([2, 3, 4, 6]))
+        buckets = [_clumpy_bucket(rng, int(rng.integers(300, 2500)), 400_000, eps), _clumpy_bucket(rng, 60, 400_000, eps)]
+        pieces = tc.plan_pieces(buckets, eps, 4, balance=0.5, min_cut=100)
+        assert sum(1 for p in pieces if p[0] == 0) >= 3 and [p for p in pieces if p[0] == 1][0][2] is None
+        labs, runs, last = tc.cluster_pieces_local(buckets, pieces, list(range(len(pieces))), eps, m)
+        got = tc.assemble_pieces(buckets, pieces, labs, runs, last)
+        want = _oracle_cluster_buckets(buckets, eps, m)
+        for b in range(2):
+            assert np.array_equal(got[b], want[b]), (trial, b, eps, m)
+        # the same cut WITHOUT the halo point: pieces end one window early -> at least sometimes different labels
+        bare = [(b, k, mem, None) for b, k, mem, _ in pieces]
+        l2, r2, s2 = tc.cluster_pieces_local(buckets, bare, list(range(len(bare))), eps, m)
+        halo_mattered += not np.array_equal(tc.assemble_pieces(buckets, bare, l2, r2, s2)[0], want[0])
+    assert halo_mattered > 0
+
+
+def _cut_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from tiddit_amd import tiddit_cluster as tc
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def spy(buckets, epsilon, m, ctx=None, counts=False):
+            calls.append(sum(len(b) for b in buckets))
+            return _oracle_cluster_buckets(buckets, epsilon, m, ctx, counts)
+        tc.cluster_buckets = spy
+        rng = np.random.default_rng(21)                      # the same two-bucket job on every rank
+        buckets = [_clumpy_bucket(rng, 6000, 2_000_000, 300), _clumpy_bucket(rng, 5000, 2_000_000, 300), np.zeros((0, 2), np.int64)]
+        got = tc.cluster_buckets_sharded(buckets, 300, 3, min_cut=1000)
+        want = _oracle_cluster_buckets(buckets, 300, 3)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+        total = sum(len(b) for b in buckets)
+        assert len(calls) == 1 and abs(calls[0] - total / world) < 0.15 * total      # two big buckets, balanced over the ranks by the cut
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oversized_bucket_cut_gloo_world2_and_3():
+    import torch.multiprocessing as mp
+    for world in (2, 3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cut_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=240) for _ in procs]
+        for p in procs:
+            p.join(60)
+        assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -95,3 +95,62 @@ def test_live_oracle_on_the_same_file(run, tmp_path):
     names = [n_ for n_, _ in contigs]
     args = (names, dict(contigs), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"], max_ins, P["min_contig"], True, P["min_reads"])
     assert cluster_oracle.canonical(tiddit_cluster.main(out, *args)) == cluster_oracle.canonical(cluster_oracle.main(out, *args))
+
+
+# ---- BASELINE configs[4]: the same run as N processes (one per GPU in production; here they share the box's one GPU and
+# exchange over gloo, like tests/test_gpu_ingest.py::test_coverage_sharded_multi_process)
+
+def _sv_rank(rank, world, port, q, argv, min_cut):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      TIDDIT_HIP_DEVICE="0", TIDDIT_DIST_BACKEND="gloo", TIDDIT_INGEST_CHUNK=str(48 << 20), TIDDIT_CLUSTER_MIN_CUT=str(min_cut))
+    try:
+        import torch.distributed as dist
+        from tiddit_amd import __main__ as cli, tiddit_cluster
+        seen = []
+        real = tiddit_cluster.cluster_buckets
+
+        def spy(buckets, *a, **k):
+            seen.append(sum(len(b) for b in buckets))
+            return real(buckets, *a, **k)
+        tiddit_cluster.cluster_buckets = spy
+        cli.main(argv)
+        q.put((rank, seen))
+        dist.destroy_process_group()
+    except BaseException:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sv_on_n_ranks_is_byte_identical(run, tmp_path, world):
+    """`tiddit --sv --skip_assembly` as 2 / 3 ranks on ONE file: byte-range shards of the BAM with checked seams, one exact all-reduce
+    of the 50-bp bins, rows gathered in file order, buckets (the large ones cut at posA gaps >= eps) clustered where the packing puts
+    them — discordants/splits .tab, every clip FASTA, .ploidies.tab and .candidates.tab equal the single-process run byte for byte"""
+    import socket
+    import torch.multiprocessing as mp
+    fx, bam, fa, contigs, out = run
+    P = fx["params"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    nout = str(tmp_path / "ranks")
+    argv = ["--sv", "--bam", bam, "--ref", fa, "-o", nout, "--skip_assembly", "-s", str(P["n_reads_stats"])]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sv_rank, args=(r, world, port, q, argv, 40)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(120)
+    assert all(isinstance(v, list) for v in res.values()), res
+    for rel in ["_tiddit/discordants_WGS.tab", "_tiddit/splits_WGS.tab", "_tiddit/clips_WGS.fa", ".ploidies.tab", ".candidates.tab"] + \
+               ["_tiddit/clips/%s.fa" % n for n, ln in contigs if ln >= P["min_contig"]]:
+        assert open(nout + rel, "rb").read() == open(out + rel, "rb").read(), rel
+    assert h(open(nout + "_tiddit/discordants_WGS.tab").read()) == fx["discordants_sha256"]
+    # every rank clustered a share of the signals (one device call each), none of them all of it
+    shares = [sum(v) for v in res.values()]
+    assert all(len(v) == 1 for v in res.values()) and max(shares) < sum(shares)

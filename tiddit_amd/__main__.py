@@ -157,13 +157,33 @@ def run_sv(args, version):
     contig_number = {c: i for i, c in enumerate(contigs)}
     contig_length = {c["SN"]: c["LN"] for c in bam_header["SQ"]}
     prefix = args.o
-    try:
-        os.mkdir("{}_tiddit".format(prefix))
-        os.mkdir("{}_tiddit/clips".format(prefix))
-    except Exception:
-        if not args.force_overwrite:
-            print("Eror output folder exists")
-            quit()
+    # one process per GPU on ONE file (BASELINE configs[4]; `torchrun --nproc-per-node N -m tiddit_amd --sv ...`): rank 0 owns the
+    # output files and the host-only stages, the signal scan and the clustering are shared (tiddit_signal.main_sharded,
+    # tiddit_cluster.main_sharded)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from . import dist as tdist
+        backend = os.environ.get("TIDDIT_DIST_BACKEND", "nccl")          # gloo: ranks sharing one GPU (tests)
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if not dist.is_initialized():
+            dist.init_process_group(backend)
+        rank = dist.get_rank()
+    if rank == 0:
+        try:
+            os.mkdir("{}_tiddit".format(prefix))
+            os.mkdir("{}_tiddit/clips".format(prefix))
+        except Exception:
+            if not args.force_overwrite:
+                print("Eror output folder exists")
+                if world > 1:
+                    dist.destroy_process_group()
+                    os._exit(1)                                          # (the other ranks sit in the broadcast below: take the job down)
+                quit()
     min_mapq = args.q
     max_ins_len = 100000
     T = STAGE_SECONDS
@@ -171,45 +191,55 @@ def run_sv(args, version):
     from .trace import stage
     t = time.time()
     with stage("tiddit: library statistics"):
-        library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s)
+        if rank == 0:                                                    # the sample is a prefix of the file: one rank's job
+            library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s)
+        if world > 1:
+            library = tdist.broadcast_object(library if rank == 0 else None, 0)
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
     T["library statistics"] = time.time() - t
 
     t = time.time()
     with stage("tiddit: signal extraction + coverage"):
-        coverage_data = tiddit_signal.main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
-                                           False, args.min_anchor_len, args.min_clip_len)
-    print("extracted signals in:")
-    print(t - time.time())
+        signal_main = tiddit_signal.main_sharded if world > 1 else tiddit_signal.main
+        coverage_data = signal_main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
+                                    False, args.min_anchor_len, args.min_clip_len)
+    if rank == 0:
+        print("extracted signals in:")
+        print(t - time.time())
     T["signal extraction + coverage"] = time.time() - t
     T.update({"  " + k: v for k, v in tiddit_signal.STAGE_SECONDS.items()})
-    t = time.time()
-    with stage("tiddit: GC bins"):
-        gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
-    T["GC bins"] = time.time() - t
-    t = time.time()
-    with stage("tiddit: ploidy"):
-        library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,
-                                                            bam_header, gc_dictionary)
-    print("calculated coverage in:")
-    print(time.time() - t)
-    T["ploidy (masked medians)"] = time.time() - t
+    if rank == 0:
+        t = time.time()
+        with stage("tiddit: GC bins"):
+            gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
+        T["GC bins"] = time.time() - t
+        t = time.time()
+        with stage("tiddit: ploidy"):
+            library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,
+                                                                bam_header, gc_dictionary)
+        print("calculated coverage in:")
+        print(time.time() - t)
+        T["ploidy (masked medians)"] = time.time() - t
     if not args.e:
         args.e = int(library["avg_insert_size"] / 2.0)
     if not args.e:
         args.e = 50
     t = time.time()
     with stage("tiddit: clustering"):
-        sv_clusters = tiddit_cluster.main(prefix, contigs, contig_length, samples, library["mp"], args.e, args.l, max_ins_len, args.min_contig,
-                                          args.skip_assembly, args.r)
-    print("generated clusters in")
-    print(time.time() - t)
+        cluster_main = tiddit_cluster.main_sharded if world > 1 else tiddit_cluster.main
+        sv_clusters = cluster_main(prefix, contigs, contig_length, samples, library["mp"], args.e, args.l, max_ins_len, args.min_contig,
+                                   args.skip_assembly, args.r)
     T["clustering"] = time.time() - t
     T.update({"  " + k: v for k, v in tiddit_cluster.STAGE_SECONDS.items()})
-    t = time.time()
-    write_candidates(prefix + ".candidates.tab", contigs, sv_clusters)
-    T["candidates table"] = time.time() - t
-    print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
+    if rank == 0:
+        print("generated clusters in")
+        print(T["clustering"])
+        t = time.time()
+        write_candidates(prefix + ".candidates.tab", contigs, sv_clusters)
+        T["candidates table"] = time.time() - t
+        print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
+    if world > 1:
+        dist.barrier()                                                   # every output file exists when any rank returns
 
 
 def main(argv=None):

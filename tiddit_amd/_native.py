@@ -60,11 +60,13 @@ SYMBOLS = {
     "tdt_dbscan_y_device": (_i, [_P, _P, _P, _sz, ctypes.c_uint64, _i, _i64, _P, _P, ctypes.POINTER(_i)]),
     "tdt_dbscan_device": (_i, [_P, _P, _P, _sz, _P, _i, ctypes.c_uint64, _i, _i, _P, _P]),
     "tdt_sort_dbscan": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P]),
+    "tdt_sort_dbscan_ex": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P, _P, _P]),
     "tdt_comm_unique_id": (_i, [_P]),
     "tdt_comm_init": (_i, [_P, _P, _i, _i, _PP]),
     "tdt_comm_destroy": (_i, [_P]),
     "tdt_allgatherv": (_i, [_P, _P, _sz, _P, _P, _P, _i]),
     "tdt_allreduce_sum_f64": (_i, [_P, _P, _sz]),
+    "tdt_allgatherv_plan": (_i, [_i, _i, _P, _P, _i, _sz, _P, ctypes.POINTER(_i)]),
     "tdt_signal_select": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, ctypes.POINTER(_sz)]),
     "tdt_signal_select_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _i, _i, _i64, _P, _P]),
     "tdt_signal_scan": (_i, [_P, _P, _sz, _P, _i, _i, _i64, _i, _i, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),

@@ -5,6 +5,7 @@
 // RCCL is bound at run time (dlopen): a process that already carries an RCCL (PyTorch-ROCm ships its own librccl.so) keeps
 // using that one — two RCCL instances in one process do not share their state — and a plain C/C++ caller gets ROCm's.
 #include "tdt_common.h"
+#include <vector>
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -121,23 +122,63 @@ extern "C" int tdt_comm_destroy(tdt_comm *c) {
     return TDT_OK;
 }
 
+// The layout of one variable-count all-gather, as a pure function of (rank, world, counts, displs): the list of broadcasts the group
+// call issues — root, destination byte range in d_recv, and whether this rank's source is its send buffer (it is the root) or the
+// destination itself.  Separate from the RCCL calls so that the count / displacement arithmetic is testable on the host for any
+// world size (tests/test_abi.py); tdt_allgatherv executes exactly this list.
+extern "C" int tdt_allgatherv_plan(int rank, int world, const size_t *counts, const size_t *displs, int elem_bytes, size_t recv_capacity_bytes,
+                                   tdt_gather_op *ops, int *n_ops) {
+    if (world < 1 || rank < 0 || rank >= world || !counts || !displs || elem_bytes <= 0 || !ops || !n_ops) {
+        tdt_set_error("tdt_allgatherv_plan: bad argument");
+        return TDT_E_ARG;
+    }
+    int k = 0;
+    for (int r = 0; r < world; r++) {
+        if (!counts[r]) continue;                                   // an empty contribution is no broadcast at all (on every rank alike)
+        if (counts[r] > SIZE_MAX / (size_t)elem_bytes || displs[r] > SIZE_MAX / (size_t)elem_bytes) {
+            tdt_set_error("tdt_allgatherv_plan: rank %d's range overflows size_t", r);
+            return TDT_E_ARG;
+        }
+        const size_t off = displs[r] * (size_t)elem_bytes, nb = counts[r] * (size_t)elem_bytes;
+        if (recv_capacity_bytes && (off > recv_capacity_bytes || nb > recv_capacity_bytes - off)) {
+            tdt_set_error("tdt_allgatherv_plan: rank %d's range [%zu, %zu) leaves the receive buffer of %zu bytes", r, off, off + nb, recv_capacity_bytes);
+            return TDT_E_ARG;
+        }
+        for (int q = 0; q < k; q++)                                 // two ranks' ranges must not overlap
+            if (off < ops[q].offset_bytes + ops[q].nbytes && ops[q].offset_bytes < off + nb) {
+                tdt_set_error("tdt_allgatherv_plan: the ranges of ranks %d and %d overlap", ops[q].root, r);
+                return TDT_E_ARG;
+            }
+        ops[k].root = r;
+        ops[k].offset_bytes = off;
+        ops[k].nbytes = nb;
+        ops[k].from_send = r == rank;
+        k++;
+    }
+    *n_ops = k;
+    return TDT_OK;
+}
+
 extern "C" int tdt_allgatherv(tdt_comm *c, const void *d_send, size_t send_count, void *d_recv, const size_t *counts, const size_t *displs,
                               int elem_bytes) {
     if (!c || !d_recv || !counts || !displs || elem_bytes <= 0 || (send_count && !d_send) || counts[c->rank] != send_count) {
         tdt_set_error("tdt_allgatherv: bad argument (counts[rank] must equal send_count)");
         return TDT_E_ARG;
     }
+    std::vector<tdt_gather_op> ops((size_t)c->world);
+    int n_ops = 0;
+    int rc = tdt_allgatherv_plan(c->rank, c->world, counts, displs, elem_bytes, 0, ops.data(), &n_ops);
+    if (rc) return rc;
     TDT_HIP(hipSetDevice(c->ctx->device));
     hipStream_t st = c->ctx->stream;
     TDT_NCCL(g_rccl.GroupStart());
-    for (int r = 0; r < c->world; r++) {
-        if (!counts[r]) continue;
-        char *dst = (char *)d_recv + displs[r] * (size_t)elem_bytes;
-        const void *src = r == c->rank ? d_send : (const void *)dst;
-        ncclResult_t e = g_rccl.Broadcast(src, dst, counts[r] * (size_t)elem_bytes, ncclUint8, r, c->comm, st);
+    for (int k = 0; k < n_ops; k++) {
+        char *dst = (char *)d_recv + ops[k].offset_bytes;
+        const void *src = ops[k].from_send ? d_send : (const void *)dst;
+        ncclResult_t e = g_rccl.Broadcast(src, dst, ops[k].nbytes, ncclUint8, ops[k].root, c->comm, st);
         if (e != ncclSuccess) {
             (void)g_rccl.GroupEnd();
-            tdt_set_error("ncclBroadcast (root %d) failed: %s", r, g_rccl.GetErrorString(e));
+            tdt_set_error("ncclBroadcast (root %d) failed: %s", ops[k].root, g_rccl.GetErrorString(e));
             return TDT_E_HIP;
         }
     }

@@ -911,6 +911,8 @@ extern "C" int tdt_dbscan_y(tdt_ctx *ctx, const int64_t *data, size_t n, size_t 
 }
 
 // -------------------------------------------------------------------- sort + cluster in one call
+extern "C" int tdt_sort_dbscan_ex(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
+                                  double eps, int m, uint32_t *perm_out, double *labels_out, int64_t *runs_out, int64_t *last_out);
 __global__ __launch_bounds__(DB_THREADS) void sd_make_keys(const unsigned *__restrict__ x, int n, const int *__restrict__ boff, int nb,
                                                            unsigned long long *__restrict__ key, unsigned *__restrict__ val) {
     const int i = blockIdx.x * DB_THREADS + threadIdx.x;
@@ -938,6 +940,13 @@ __global__ __launch_bounds__(DB_THREADS) void sd_labels_i32(const double *__rest
 
 extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
                                double eps, int m, uint32_t *perm_out, double *labels_out) {
+    return tdt_sort_dbscan_ex(ctx, posA, posB, n, bucket_off, nb, eps, m, perm_out, labels_out, nullptr, nullptr);
+}
+
+// the same call, also reporting per bucket the number of x-runs (DBSCAN.py:33-64: the x pass's cluster_id + 1) and the final
+// cluster_id of DBSCAN.main — what a caller that cut one bucket into pieces needs to re-base the pieces' ids (dist.py)
+extern "C" int tdt_sort_dbscan_ex(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
+                                  double eps, int m, uint32_t *perm_out, double *labels_out, int64_t *runs_out, int64_t *last_out) {
     if (!ctx || nb < 1 || !bucket_off || (n && (!posA || !posB || !perm_out || !labels_out))) {
         tdt_set_error("tdt_sort_dbscan: bad argument");
         return TDT_E_ARG;
@@ -950,7 +959,13 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
         tdt_set_error("tdt_sort_dbscan: bad bucket offsets / n");
         return TDT_E_ARG;
     }
-    if (n == 0) return TDT_OK;
+    if (n == 0) {
+        for (int b = 0; b < nb; b++) {
+            if (runs_out) runs_out[b] = 0;
+            if (last_out) last_out[b] = -1;
+        }
+        return TDT_OK;
+    }
     TDT_HIP(hipSetDevice(ctx->device));
     // column ranges and the 32-bit offsets: host passes over n elements, spread over the host threads
     const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)tdt_host_thread_count(), n / (1u << 16) + 1));
@@ -1023,8 +1038,28 @@ extern "C" int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t 
     hipLaunchKernelGGL(sd_unpack, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned long long *)ks, (const unsigned *)vs,
                        (const unsigned *)dy, (int)n, dxs, dys, dperm);
     TDT_CHECK_LAUNCH();
-    rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, nullptr);
+    long long *dcnt = nullptr;
+    if (runs_out || last_out) {
+        void *dc = nullptr;
+        rc = tdt_scratch(ctx, 6, (size_t)nb * 16 + 64, &dc);
+        if (rc) return rc;
+        dcnt = (long long *)dc;
+        if (runs_out) {                      // the x pass alone: its cluster_id is the number of x-runs - 1
+            rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 1, dlab, (int64_t *)dcnt);
+            if (rc) return rc;
+        }
+    }
+    rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, dcnt ? (int64_t *)(dcnt + nb) : nullptr);
     if (rc) return rc;
+    if (dcnt) {
+        std::vector<long long> hc((size_t)nb * 2);
+        TDT_HIP(hipMemcpyAsync(hc.data(), dcnt, (size_t)nb * 16, hipMemcpyDeviceToHost, st));
+        TDT_HIP(hipStreamSynchronize(st));
+        for (int b = 0; b < nb; b++) {
+            if (runs_out) runs_out[b] = hc[b] + 1;
+            if (last_out) last_out[b] = hc[nb + b];
+        }
+    }
     // results come back through the pinned block (its input columns are consumed by now), labels as int32 (dv0 is free again), then go
     // to the caller's arrays on the host threads
     int *dlab32 = (int *)dv0;

@@ -28,8 +28,8 @@
 #define DT_NW 24                            // staged words per tile
 #endif
 #define DT_OW (DT_NW - 2)                   // owned words: clusters starting here are this tile's
-#define DT_S (DT_NW * 64)                   // 4096 staged positions
-#define DT_T (DT_OW * 64)                   // 3968 owned positions
+#define DT_S (DT_NW * 64)                   // 1536 staged positions (DT_NW 24)
+#define DT_T (DT_OW * 64)                   // 1408 owned positions
 #define DT_WPW (DT_NW / DT_WAVES)           // words per wave
 #define DT_XS (DT_S + 64 + DBF_M_MAX + 8)   // x staged for [t0-64, t0+S+m+...)
 #define DT_CODE_PREV (1ull << 62)           // the position belongs to the NEXT tile's range: its owner is tile(position) - 1

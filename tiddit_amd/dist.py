@@ -154,3 +154,104 @@ def coverage_sharded(bam_file_name, bin_size, min_q, group=None, ctx=None, chunk
         out[c["SN"]] = host[o:o + hist.nbins(i)[0]].copy()
     hist.close()
     return header, out, n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# `tiddit --sv` on N ranks (BASELINE configs[4]): small host objects (library statistics, signal rows) travel as byte tensors
+# through the process group, so the same code runs over RCCL (device tensors) and gloo (host tensors).
+
+def _wire_device(group=None):
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def broadcast_object(obj, src=0, group=None):
+    """pickle -> uint8 tensor -> broadcast (length first).  -> the object on every rank."""
+    import pickle
+    import numpy
+    import torch
+    import torch.distributed as dist
+    dev = _wire_device(group)
+    me = dist.get_rank(group)
+    blob = pickle.dumps(obj, protocol=4) if me == src else b""
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src, group=group)
+    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    if me == src and len(blob):
+        buf.copy_(torch.from_numpy(numpy.frombuffer(blob, dtype=numpy.uint8).copy()))
+    if buf.numel():
+        dist.broadcast(buf, src, group=group)
+    return obj if me == src else pickle.loads(buf.cpu().numpy().tobytes())
+
+
+def gather_bytes(blob, dst=0, group=None):
+    """variable-length byte strings of every rank -> list in RANK ORDER on `dst` (None elsewhere): lengths by one all-gather,
+    payloads point to point (no padding to the largest rank)."""
+    import numpy
+    import torch
+    import torch.distributed as dist
+    dev = _wire_device(group)
+    me, world = dist.get_rank(group), dist.get_world_size(group)
+    cnt = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, cnt, group=group)
+    counts = counts.cpu().tolist()
+    if me != dst:
+        if len(blob):
+            dist.send(torch.from_numpy(numpy.frombuffer(blob, dtype=numpy.uint8).copy()).to(dev), dst, group=group)
+        return None
+    out = []
+    for r in range(world):
+        if r == me:
+            out.append(bytes(blob))
+            continue
+        buf = torch.empty(counts[r], dtype=torch.uint8, device=dev)
+        if counts[r]:
+            dist.recv(buf, r, group=group)
+        out.append(buf.cpu().numpy().tobytes())
+    return out
+
+
+# One oversized (chrA,chrB) bucket cut into pieces that cluster independently (SURVEY §8(e)).  A cut is legal between two
+# posA-neighbours a < b with b - a >= eps: every sliding window that spans the gap fails `max(distances) < epsilon`
+# (DBSCAN.py:50), so no x-run — hence no cluster — crosses it.  ONE detail makes a naive cut wrong: the reference's last
+# window of an array is one point short (`data[i+1:i+m+1]` at i = n-m, DBSCAN.py:41-43), so the END of an array is treated more
+# leniently than the same position in the middle of one.  Every piece but the last therefore carries one HALO point — a
+# coordinate >= eps beyond its last signal, standing in for the first signal of the next piece — which makes its final
+# windows exactly the windows of the uncut array; the halo itself can never be labelled (it is >= m+1 positions behind the last
+# passing window start) and is dropped.  Ids are then re-based by exclusive scans of the pieces' x-run and extra-sub-run
+# counts (DBSCAN.py:112-122: extra sub-runs are numbered after ALL x-runs of the array).
+
+def plan_bucket_cuts(posA, eps, parts, max_cells=1 << 24):
+    """-> (thresholds, halo_width): ascending cut values t (piece k holds t[k-1] <= posA < t[k]) such that no signal lies in
+    [t, t + halo_width) and halo_width >= ceil(eps); [] when the bucket cannot (or need not) be cut.  Host planner, O(n):
+    an occupancy histogram over cells of >= ceil(eps) bp — an empty cell is a legal gap — and the empty cell nearest each
+    1/parts quantile.  Deterministic: every rank computes the same plan."""
+    import math
+    import numpy
+    posA = numpy.asarray(posA, dtype=numpy.int64)
+    n = len(posA)
+    if not (eps > 0) or parts < 2 or n < 2 * parts:
+        return [], 0
+    E = int(math.ceil(eps))
+    lo, hi = int(posA.min()), int(posA.max())
+    W = max(E, -(-(hi - lo + 1) // max_cells))
+    cells = (posA - lo) // W
+    cnt = numpy.bincount(cells, minlength=(hi - lo) // W + 1)
+    empty = numpy.flatnonzero(cnt == 0)
+    if len(empty) == 0:
+        return [], 0
+    before = numpy.cumsum(cnt)[empty]                    # signals below the empty cell (non-decreasing along `empty`)
+    chosen = set()
+    for k in range(1, parts):
+        target = n * k / parts
+        j = int(numpy.searchsorted(before, target))
+        best = min((c for c in (j - 1, j) if 0 <= c < len(empty)), key=lambda c: (abs(before[c] - target), c))
+        if 0 < before[best] < n:
+            chosen.add(int(before[best]))                # one cut per distinct split of the signals
+    ts = []
+    for b in sorted(chosen):
+        c = empty[int(numpy.searchsorted(before, b))]    # the first empty cell with that many signals below it
+        ts.append(lo + int(c) * W)
+    return ts, W

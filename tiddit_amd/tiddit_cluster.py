@@ -101,17 +101,21 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
     return signals, positions
 
 
-def cluster_buckets(buckets, epsilon, m, ctx=None):
+def cluster_buckets(buckets, epsilon, m, ctx=None, counts=False):
     """buckets: list of int64 [n_b, >=2] arrays (posA, posB, ...) in signal order.
     -> list of float64 label arrays, labels[b][j] = cluster of the bucket's j-th signal
-    (= DBSCAN.main on the bucket stably sorted by posA, mapped back; tiddit_cluster.pyx:152-160)."""
+    (= DBSCAN.main on the bucket stably sorted by posA, mapped back; tiddit_cluster.pyx:152-160).
+    counts=True: -> (labels, x-runs per bucket, final cluster_id per bucket) (tdt_sort_dbscan_ex)."""
     ctx = ctx or _native.default_context()
     sizes = [len(b) for b in buckets]
     n = int(sum(sizes))
     off = numpy.zeros(len(buckets) + 1, dtype=numpy.int64)
     numpy.cumsum(sizes, out=off[1:])
+    runs = numpy.zeros(len(buckets), dtype=numpy.int64)
+    last = numpy.full(len(buckets), -1, dtype=numpy.int64)
     if n == 0:
-        return [numpy.zeros(0) for _ in buckets]
+        labs = [numpy.zeros(0) for _ in buckets]
+        return (labs, runs, last) if counts else labs
     def column(b, c):
         a = numpy.asarray(b, dtype=numpy.int64)
         return a[:, c] if len(a) else numpy.zeros(0, dtype=numpy.int64)
@@ -119,31 +123,128 @@ def cluster_buckets(buckets, epsilon, m, ctx=None):
     posB = numpy.ascontiguousarray(numpy.concatenate([column(b, 1) for b in buckets]))
     perm = numpy.empty(n, dtype=numpy.uint32)
     lab = numpy.empty(n, dtype=numpy.float64)
-    _native.check(ctx.lib.tdt_sort_dbscan(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets),
-                                          float(epsilon), int(m), _native.ptr(perm), _native.ptr(lab)))
+    if counts:
+        _native.check(ctx.lib.tdt_sort_dbscan_ex(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets),
+                                                 float(epsilon), int(m), _native.ptr(perm), _native.ptr(lab), _native.ptr(runs), _native.ptr(last)))
+    else:
+        _native.check(ctx.lib.tdt_sort_dbscan(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets),
+                                              float(epsilon), int(m), _native.ptr(perm), _native.ptr(lab)))
     by_signal = numpy.empty(n, dtype=numpy.float64)
     by_signal[perm] = lab
-    return [by_signal[off[b]:off[b + 1]] for b in range(len(buckets))]
+    labs = [by_signal[off[b]:off[b + 1]] for b in range(len(buckets))]
+    return (labs, runs, last) if counts else labs
 
 
-def cluster_buckets_sharded(buckets, epsilon, m, group=None, device=None):
-    """Multi-GPU form of :func:`cluster_buckets` (one process per GPU, torch.distributed initialised, backend
-    nccl = RCCL): buckets are bin-packed onto ranks by signal count, every rank clusters only its own buckets
-    on its GPU, and ONE variable-count all-gather of the label arrays gives every rank the full result
-    (SURVEY.md §8(e)).  Returns the same list of per-bucket label arrays on every rank."""
+def plan_pieces(buckets, epsilon, world, balance=1.0, min_cut=32768):
+    """The work list of the N-rank clustering step: every bucket, or — for a bucket above `balance` x (all signals / world) —
+    (and at least `min_cut` signals: below that a launch is latency, not work) its pieces cut at posA gaps >= epsilon
+    (dist.plan_bucket_cuts).  -> list of (bucket index, piece number, member indices
+    or None for a whole bucket, halo posA or None), in (bucket, piece) order; identical on every rank."""
+    from .dist import plan_bucket_cuts
+    sizes = [len(b) for b in buckets]
+    total = sum(sizes)
+    pieces = []
+    for b, bucket in enumerate(buckets):
+        ts = []
+        if world > 1 and total and sizes[b] >= min_cut and sizes[b] > balance * total / world:
+            posA = numpy.asarray(bucket, dtype=numpy.int64)[:, 0]
+            parts = min(world * 2, max(2, int(round(sizes[b] * world / total))) * 2)      # pieces of about half a rank's fair share
+            ts, width = plan_bucket_cuts(posA, epsilon, parts)
+        if not ts:
+            pieces.append((b, 0, None, None))
+            continue
+        which = numpy.searchsorted(numpy.asarray(ts, dtype=numpy.int64), posA, side="right")
+        for k in range(len(ts) + 1):
+            pieces.append((b, k, numpy.flatnonzero(which == k), (ts[k] + width) if k < len(ts) else None))
+    return pieces
+
+
+def rebase_pieces(piece_labels, piece_runs, piece_last):
+    """ids of the pieces of ONE bucket (each numbered from 0 by its own DBSCAN.main) -> the ids DBSCAN.main gives the uncut bucket
+    (DBSCAN.py:112-122): x-run r of piece k becomes r + (x-runs of the pieces before it); an extra sub-run — local id >= the piece's
+    x-run count — is numbered after ALL x-runs of the bucket, behind the extra sub-runs of the pieces before it."""
+    runs = numpy.asarray(piece_runs, dtype=numpy.int64)
+    extras = numpy.asarray(piece_last, dtype=numpy.int64) + 1 - runs
+    run_base = numpy.concatenate([[0], numpy.cumsum(runs)])
+    ext_base = numpy.concatenate([[0], numpy.cumsum(extras)])
+    total_runs = int(run_base[-1])
+    out = []
+    for k, lab in enumerate(piece_labels):
+        lab = numpy.asarray(lab, dtype=numpy.float64)
+        new = numpy.where(lab < 0, -1.0, numpy.where(lab < runs[k], lab + run_base[k], lab + (total_runs - runs[k]) + ext_base[k]))
+        out.append(new)
+    return out
+
+
+def cluster_pieces_local(buckets, pieces, ids, epsilon, m):
+    """cluster the pieces `ids` of the work list on this rank's GPU -> (labels per piece (halo dropped), x-runs, final ids)"""
+    arrays = []
+    for i in ids:
+        b, k, members, halo = pieces[i]
+        a = numpy.asarray(buckets[b], dtype=numpy.int64)[:, :2]
+        if members is not None:
+            a = a[members]
+            if halo is not None:
+                a = numpy.concatenate([a, [[halo, a[0, 1] if len(a) else 0]]])      # the halo point (dist.py): never labelled
+        arrays.append(a)
+    labs, runs, last = cluster_buckets(arrays, epsilon, m, counts=True)
+    for j, i in enumerate(ids):
+        if pieces[i][3] is not None:
+            labs[j] = labs[j][:-1]
+    return labs, runs, last
+
+
+def assemble_pieces(buckets, pieces, labels, runs, last):
+    """per-piece results of ALL pieces -> list of per-bucket label arrays in signal order"""
+    out = [None] * len(buckets)
+    i = 0
+    while i < len(pieces):
+        b = pieces[i][0]
+        j = i
+        while j < len(pieces) and pieces[j][0] == b:
+            j += 1
+        if j - i == 1 and pieces[i][2] is None:
+            out[b] = numpy.asarray(labels[i], dtype=numpy.float64)
+        else:
+            fixed = rebase_pieces(labels[i:j], runs[i:j], last[i:j])
+            lab = numpy.empty(len(buckets[b]), dtype=numpy.float64)
+            for k in range(i, j):
+                lab[pieces[k][2]] = fixed[k - i]
+            out[b] = lab
+        i = j
+    return out
+
+
+def cluster_buckets_sharded(buckets, epsilon, m, group=None, device=None, balance=1.0, min_cut=32768):
+    """Multi-GPU form of :func:`cluster_buckets` (one process per GPU, torch.distributed initialised; backend nccl = RCCL):
+    the buckets — an oversized one cut into pieces at posA gaps >= epsilon (:func:`plan_pieces`) — are bin-packed onto the ranks by
+    signal count, every rank clusters only its own on its GPU, and ONE variable-count all-gather (labels, then two counts per piece,
+    int32 on the wire) gives every rank the full result.  Returns the same list of per-bucket label arrays on
+    every rank, bit-identical to the single-GPU call."""
     import torch
     import torch.distributed as dist
-    from .dist import cluster_buckets_distributed
-    sizes = [len(b) for b in buckets]
+    from .dist import allgatherv, shard_buckets
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-
-    def cluster_local(ids):
-        labs = cluster_buckets([buckets[i] for i in ids], epsilon, m)
-        flat = numpy.concatenate(labs) if labs else numpy.zeros(0)
-        return torch.from_numpy(numpy.ascontiguousarray(flat, dtype=numpy.float64)).to(device)
-
-    return [t.cpu().numpy() for t in cluster_buckets_distributed(sizes, cluster_local, group)]
+    pieces = plan_pieces(buckets, epsilon, world, balance, min_cut)
+    psize = [len(buckets[b]) if mem is None else len(mem) for b, _, mem, _ in pieces]
+    owned = shard_buckets(psize, world)
+    labs, runs, last = cluster_pieces_local(buckets, pieces, owned[rank], epsilon, m)
+    if (runs > 0x7fffffff).any() or (last > 0x7fffffff).any():
+        raise OverflowError("cluster ids above 2^31 do not fit the int32 wire format")
+    wire = numpy.concatenate([numpy.concatenate(labs) if labs else numpy.zeros(0), runs.astype(numpy.float64), last.astype(numpy.float64)])
+    parts = allgatherv(torch.from_numpy(wire.astype(numpy.int32)).to(device), group)
+    all_lab, all_runs, all_last = [None] * len(pieces), numpy.zeros(len(pieces), numpy.int64), numpy.zeros(len(pieces), numpy.int64)
+    for r, part in enumerate(parts):
+        part = part.cpu().numpy()
+        k = len(owned[r])
+        o = 0
+        for j, i in enumerate(owned[r]):
+            all_lab[i] = part[o:o + psize[i]].astype(numpy.float64)
+            o += psize[i]
+            all_runs[i], all_last[i] = part[len(part) - 2 * k + j], part[len(part) - k + j]
+    return assemble_pieces(buckets, pieces, all_lab, all_runs, all_last)
 
 
 def _mode(values):
@@ -168,7 +269,7 @@ def _breakpoints_from_discordants(cand, is_mp):
     return pickA(A["discordants"]), pickB(B["discordants"])
 
 
-def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
+def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=False):
     import time
     t0 = time.time()
     signals, positions = _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly)
@@ -183,9 +284,15 @@ def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_in
         sharded = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
     except ImportError:
         sharded = False
-    labels = cluster_buckets_sharded(bucket_arrays, epsilon, m) if sharded else cluster_buckets(bucket_arrays, epsilon, m)
+    if sharded:
+        import os
+        labels = cluster_buckets_sharded(bucket_arrays, epsilon, m, min_cut=int(os.environ.get("TIDDIT_CLUSTER_MIN_CUT", "32768")))
+    else:
+        labels = cluster_buckets(bucket_arrays, epsilon, m)
 
     STAGE_SECONDS["sort + DBSCAN (device)"] = time.time() - t0
+    if sharded and root_only and _dist.get_rank() != 0:
+        return None                                      # the labels are on every rank; the candidates dictionary is rank 0's job
     t0 = time.time()
     candidates = {}
     for chrA in chromosomes:           # candidates[chrA] exists for every chrA that has signals (:141-145)
@@ -254,3 +361,11 @@ def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins
     tables are built: hostutil.quiet_gc.)"""
     with quiet_gc():
         return _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads)
+
+
+def main_sharded(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
+    """:func:`main` for one process per GPU (torch.distributed initialised): every rank parses the signal files, the buckets are
+    clustered where :func:`cluster_buckets_sharded` puts them, and only rank 0 regroups the signals into the candidates dictionary
+    (the other ranks return None)."""
+    with quiet_gc():
+        return _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=True)

@@ -202,11 +202,21 @@ def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
     return out[:cnt.value]
 
 
-def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50):
+def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None):
     """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
-    split rows, clip FASTA entries).  Rows are exactly what ``worker`` returns (:228)."""
+    split rows, clip FASTA entries).  The discordant and split rows are what ``worker`` returns (:228); the clip entries
+    are ``[text, ""]`` pairs whose joined text is the contig's clip FASTA in file order (one entry per read with the host
+    ingest, one per contig run of a batch with the device ingest — ``"".join`` is what every consumer does, :223-226).
+
+    shard = (rank, world): only the records that start in this rank's byte range of the file (bamio.DeviceBamReader); the
+    seam offsets are left in ``LAST_SEAM`` for dist.check_seams.  reduce_bins(hist) -> float64 array of ALL the histogram's
+    bins (the sharded caller all-reduces them there); default: this process's own bins."""
     max_ins = int(max_ins)         # the reference's `int max_ins` argument truncates a float percentile (:147,:230; probed with Cython 3.2)
-    reader = open_bam(bam_file_name)
+    if shard is None:
+        reader = open_bam(bam_file_name)
+    else:
+        from .bamio import DeviceBamReader
+        reader = DeviceBamReader(bam_file_name, shard=shard, chunk=int(os.environ.get("TIDDIT_INGEST_CHUNK", str(448 << 20))))
     header = reader.header
     names, lengths = reader.references, reader.lengths
     big = numpy.array([ln >= min_contig for ln in lengths], dtype=bool)
@@ -322,9 +332,19 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             pending.result()
     finally:
         pool.shutdown(wait=True)                              # (also on an error: no row thread outlives the scan)
+    if shard is not None:
+        LAST_SEAM.update(first_off=reader.first_off, next_off=reader.next_off, empty=reader.first_off is None)
     reader.close()
     chromosomes = [n for n, ok in zip(names, big) if ok]
-    coverage = {n: hist.finish(n) for n in chromosomes}
+    if reduce_bins is None:
+        coverage = {n: hist.finish(n) for n in chromosomes}
+    else:
+        allbins = reduce_bins(hist)
+        coverage = {}
+        for i, n in enumerate(names):
+            if big[i]:
+                o = hist.offset(i)
+                coverage[n] = allbins[o:o + hist.nbins(i)[0]].copy()
     hist.close()
     return header, chromosomes, coverage, data, splits, clips
 
@@ -332,6 +352,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
 _SCAN_CACHE = {}
 STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 SCAN_SECONDS = {}           # ... and of the last scan_signals() pass, by what the host waited for
+LAST_SEAM = {}              # seam offsets of the last sharded scan_signals() pass (dist.check_seams)
 
 
 def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bin_size, skip_index, min_anchor_len, min_clip_len):
@@ -354,14 +375,8 @@ def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bi
     return (chromosome, data[chromosome], splits[chromosome], coverage[chromosome], path)
 
 
-def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
-    t = time.time()
-    header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
-        bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
-    STAGE_SECONDS.clear()
-    STAGE_SECONDS["scan (ingest, coverage, predicates, rows)"] = time.time() - t
-    STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
-    t1 = time.time()
+def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id):
+    """the merge loop and the three writers of tiddit_signal.main (:246-332) over per-contig row lists in file order"""
     all_contigs = [c["SN"] for c in header["SQ"]]
     data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
     splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
@@ -386,7 +401,6 @@ def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_co
                     f.write(text)
                     all_clips.write(text)                # clips_{sample}.fa is the per-contig files one after the other (:328-332)
             clip_fasta.append(path)
-    print("total", time.time() - t)
     print("Writing signals to file")
 
     with open("{}_tiddit/discordants_{}.tab".format(prefix, sample_id), "w") as f:      # :298-318
@@ -408,8 +422,81 @@ def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_co
             for chrB in splits[chrA]:
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
+
+
+def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
+    t = time.time()
+    header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
+        bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
+    STAGE_SECONDS.clear()
+    STAGE_SECONDS["scan (ingest, coverage, predicates, rows)"] = time.time() - t
+    STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
+    t1 = time.time()
+    _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id)
+    print("total", time.time() - t)
     STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
     return coverage_data
+
+
+def _main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len, group):
+    """tiddit_signal.main with one process per GPU on ONE file (BASELINE configs[4]).  The reference fans out one worker per contig
+    and merges their rows in contig order (:259-284); here rank r scans the records that start in its 1/N of the file's bytes
+    (BGZF blocks are independent; the seams are checked, dist.check_seams), the 50-bp bins meet in ONE exact all-reduce, and the
+    rows of every contig are gathered on rank 0 in RANK order — the file is coordinate sorted, so that is the file order of the
+    single-process scan, and the per-fragment merge (a fragment's two reads may sit on different ranks) runs after the ordered
+    gather exactly as in :262-284.  Rank 0 writes the byte-identical .tab / clip files; every rank returns the coverage dictionary."""
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from . import dist as tdist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    t = time.time()
+
+    def reduce_bins(hist):
+        ctx = hist.ctx
+        dev = torch.device("cuda", ctx.device)
+        bins = torch.empty(hist.total_bins(), dtype=torch.float64, device=dev)
+        torch.cuda.synchronize(dev)          # torch's allocator work runs on torch's stream, the library on its own: order them
+        hist.finish_all_device(bins.data_ptr())
+        ctx.sync()
+        tdist.check_seams(LAST_SEAM["first_off"], LAST_SEAM["next_off"], LAST_SEAM["empty"], group)
+        if dist.get_backend(group) != "nccl":
+            bins = tdist.allreduce_bins(bins.cpu(), group)
+        else:
+            tdist.allreduce_bins(bins, group)
+        return bins.cpu().numpy()
+
+    header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
+        bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50, shard=(rank, world), reduce_bins=reduce_bins)
+    STAGE_SECONDS.clear()
+    STAGE_SECONDS["scan (ingest, coverage, predicates, rows; this rank's shard)"] = time.time() - t
+    STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
+    t1 = time.time()
+    mine = {c: (res_data[c], res_splits[c], ["".join(x) for x in res_clips[c]]) for c in chromosomes
+            if res_data[c] or res_splits[c] or res_clips[c]}
+    parts = tdist.gather_bytes(pickle.dumps(mine, protocol=4), 0, group)
+    STAGE_SECONDS["row gather"] = time.time() - t1
+    t1 = time.time()
+    if rank == 0:
+        parts = [pickle.loads(p) for p in parts]
+        data = {c: [] for c in chromosomes}
+        splits = {c: [] for c in chromosomes}
+        clips = {c: [] for c in chromosomes}
+        for part in parts:                                   # rank order = file order inside every contig
+            for c, (d, s, cl) in part.items():
+                data[c] += d
+                splits[c] += s
+                clips[c] += [[x, ""] for x in cl]
+        _merge_and_write(header, chromosomes, data, splits, clips, prefix, sample_id)
+    dist.barrier(group)                                      # the files exist when any rank returns
+    STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
+    return coverage_data
+
+
+def main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len, group=None):
+    """:func:`main` with one process per GPU (torch.distributed initialised; nccl = RCCL, or gloo) — see :func:`_main_sharded`"""
+    with quiet_gc():
+        return _main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len, group)
 
 
 def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):

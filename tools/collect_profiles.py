@@ -40,6 +40,11 @@ for k, d in acc.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         fe, wr = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]), sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         traffic["kernels"][k] = {"FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "bytes_per_launch": (2.0 * fe + wr) * 1024.0}
+# the kernel sources these numbers were measured on: bench.py reports a kernel's traffic only while its source file is unchanged
+import hashlib
+cs = os.path.join(REPO, "tiddit_amd", "csrc")
+traffic["sources_sha256"] = {f: hashlib.sha256(open(os.path.join(cs, f), "rb").read()).hexdigest() for f in sorted(os.listdir(cs))
+                             if f.endswith((".hip", ".h"))}
 json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, tag + "_kernel_stats.csv")).read()[:2500])
 print(json.dumps(traffic, indent=1)[:2000])
