@@ -125,9 +125,19 @@ int tdt_dbscan(tdt_ctx *ctx, const int64_t *data, size_t n, size_t stride, doubl
  * them on entry (float64: -1 or the cluster numbers 0, 1, 2, ... — every number one contiguous range, ascending along the array, as
  * x_coordinate_clustering returns them for any eps / m) and the relabelled result on return; sub-run 1 of a cluster keeps its label,
  * extra sub-runs get cluster_id + 1, cluster_id + 2, ...; *last_id = the returned cluster_id.  TDT_E_UNSUPPORTED for label arrays of
- * another shape, for clusters above 128 members and for m > 64 (use tdt_dbscan mode 0 on the data instead). */
+ * another shape, for a cluster_id below the largest label (the ids produced would collide with clusters not visited yet), for
+ * clusters above 128 members and for m > 64: tdt_dbscan_y_segments takes those. */
 int tdt_dbscan_y(tdt_ctx *ctx, const int64_t *data, size_t n, size_t stride, double eps, int m, int64_t cluster_id, double *labels,
                  int64_t *last_id);
+/* The same pass for ARBITRARY label arrays (the reference selects a cluster's members by value, DBSCAN.py:68-75: any size, any
+ * values, not necessarily contiguous).  The caller lists the members of all clusters it wants visited: y[i] (posB), seg[i] = the
+ * cluster's position in the visiting order (0 .. nseg-1; the reference's order is Python's set() iteration, which the Python
+ * front end supplies), keep[i] = the member's current label.  out[i] = keep[i] for sub-run 1, cluster_id + (extra sub-runs of the
+ * segments visited before) + s - 1 for sub-run s > 1, -1 otherwise; *last_id = the final cluster_id (:112-122).  The segments are
+ * treated as independent, which is what the reference does as long as no produced id equals a value still to be visited; callers
+ * replay one segment per call otherwise (tiddit_amd/DBSCAN.py). */
+int tdt_dbscan_y_segments(tdt_ctx *ctx, const int64_t *y, const int32_t *seg, const double *keep, size_t n, int nseg, double eps, int m,
+                          int64_t cluster_id, double *out, int64_t *last_id);
 int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const uint32_t *d_y, size_t n, uint64_t eps, int m, int64_t cluster_id,
                         double *d_labels, int64_t *d_last_id, int *too_large);
 /* Device-resident batch: nb independent buckets ((chrA,chrB) pairs), bucket b owning points

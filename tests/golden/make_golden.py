@@ -271,6 +271,73 @@ def golden_dbscan(M, out, slow):
     json.dump(prev, open(p, "w"), indent=1)
 
 
+def golden_dbscan_y_labels(M, out):
+    """DBSCAN.y_coordinate_clustering of the real reference on label arrays its own x pass would NOT produce: labels from another
+    eps / m, clusters above 128 members, a value on several ranges, arbitrary (sparse, float, negative) values, a starting
+    cluster_id below the largest label (the produced ids then collide with clusters not visited yet and get merged by the later
+    `clusters == cluster` mask, DBSCAN.py:70-72,115).  -> dbscan_y_labels.npz"""
+    D = M["DBSCAN"]
+    rng = np.random.default_rng(23)
+    cases, nc = {}, 0
+
+    def add(data, eps, m, cid, lab, kind):
+        nonlocal nc
+        data = np.ascontiguousarray(data, dtype=np.int64)
+        lab = np.ascontiguousarray(lab, dtype=np.float64)
+        got, gid = D.y_coordinate_clustering(data, eps, m, cid, lab.copy())
+        cases["c%d_data" % nc] = data
+        cases["c%d_par" % nc] = np.array([eps, m, cid, int(gid)], dtype=np.int64)
+        cases["c%d_in" % nc] = lab
+        cases["c%d_out" % nc] = np.asarray(got, dtype=np.float64)
+        cases["c%d_kind" % nc] = np.array(kind)
+        nc += 1
+
+    def points(n, span, eps, mode):
+        x = np.sort(rng.integers(0, span, n))
+        if mode == 0:
+            y = rng.integers(0, span, n)
+        elif mode == 1:
+            y = x + rng.integers(0, 3 * eps, n)
+        else:
+            y = np.where(rng.random(n) < 0.5, x + rng.integers(0, eps, n), rng.integers(0, span, n))
+        return np.stack([x, y], 1)
+
+    for rep in range(120):
+        n = int(rng.choice([3, 8, 40, 130, 300, 700]))
+        m = int(rng.choice([2, 3, 3, 4, 6]))
+        eps = int(rng.choice([5, 50, 500, 5000]))
+        data = points(n, int(rng.choice([1000, 20000, 1000000])), eps, rep % 3)
+        kind = rep % 6
+        if kind == 0:        # the x pass of ANOTHER (eps, m): contiguous ascending ids, any cluster_id at or above the largest
+            xl, xid = D.x_coordinate_clustering(data, eps * int(rng.choice([2, 10, 100])), int(rng.choice([2, 3, 5])))
+            add(data, eps, m, int(xid) + int(rng.integers(0, 4)), xl, "other_eps")
+        elif kind == 1:      # few large clusters (well above 128 members), contiguous
+            k = int(rng.integers(1, 4))
+            lab = np.sort(rng.integers(0, k, n)).astype(np.float64)
+            lab[rng.random(n) < 0.1] = -1
+            add(data, eps, m, k - 1 + int(rng.integers(0, 3)), lab, "large")
+        elif kind == 2:      # the same value on several ranges (members selected by value, not by range)
+            lab = rng.integers(-1, 6, n).astype(np.float64)
+            add(data, eps, m, 5 + int(rng.integers(0, 3)), lab, "split_ranges")
+        elif kind == 3:      # arbitrary values: sparse, large, non-integer, below -1; cluster_id above all of them
+            vals = np.array([0.0, 7.0, 2.5, 1e6, -3.0, 12345.0, 64.0, 1023.0, -1.0, 8.0])
+            lab = rng.choice(vals, n)
+            add(data, eps, m, 2_000_000 + int(rng.integers(0, 3)), lab, "arbitrary")
+        elif kind == 4:      # cluster_id BELOW the largest label: produced ids collide with unvisited clusters
+            xl, xid = D.x_coordinate_clustering(data, eps * 20, 2)
+            add(data, max(eps // 4, 1), m, int(rng.integers(-1, max(int(xid), 0) + 1)), xl, "collide")
+        else:                # collisions on random dense labels
+            lab = rng.integers(-1, 12, n).astype(np.float64)
+            add(data, eps, m, int(rng.integers(-1, 8)), lab, "collide_random")
+    # one case at a size where the visiting order of set() is far from trivial: 3000 distinct sparse values
+    n = 6000
+    data = points(n, 400000, 50, 1)
+    lab = rng.choice(rng.integers(0, 10**7, 3000), n).astype(np.float64)
+    add(data, 50, 3, 10**7, lab, "many_sparse")
+    np.savez_compressed(os.path.join(out, "dbscan_y_labels.npz"), **cases)
+    print("dbscan_y_labels:", nc, "cases")
+
+
 # ---------------------------------------------------------------------------------- cluster
 def _jsonable(c):
     if isinstance(c, dict):
@@ -430,9 +497,13 @@ def golden_sv_e2e(M, out, params=None, name="sv_e2e.json"):
 def main():
     slow = "--slow" in sys.argv
     M = build_reference()
+    if "--only-y-labels" in sys.argv:
+        golden_dbscan_y_labels(M, HERE)
+        return
     golden_coverage(M, HERE)
     golden_gc(M, HERE)
     golden_dbscan(M, HERE, slow)
+    golden_dbscan_y_labels(M, HERE)
     golden_cluster(M, HERE)
     golden_sv_e2e(M, HERE)
     golden_sv_e2e(M, HERE, params={"total_mb": 3, "seed": 11, "sv_per_mb": 8.0, "n_reads_stats": 300000}, name="sv_e2e_small.json")

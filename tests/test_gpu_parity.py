@@ -799,14 +799,58 @@ def test_y_pass_on_caller_supplied_labels(db):
             xl = np.where(kept, new_id[np.maximum(ids, 0)], -1).astype(np.float64)
             xid = int(xl.max())
         cid = xid if start_id is None else start_id
-        want, wid = oracle.y_coordinate_clustering(data, eps, m, cid, xl.copy())
+        want, wid = oracle.y_coordinate_clustering_labels(data, eps, m, cid, xl.copy())       # the literal restatement (pinned to DBSCAN.py)
         mine = xl.copy()
         got, gid = db.y_coordinate_clustering(data, eps, m, cid, mine)
         assert got is mine and gid == wid and np.array_equal(got, want), (n, eps_x, m_x, eps, m)
-    # a shape this path does not take: the same label on two separate ranges
-    bad = np.array([0.0, 0.0, -1.0, 0.0, 1.0, 1.0])
-    with pytest.raises(NotImplementedError):
-        db.y_coordinate_clustering(np.stack([np.arange(6) * 10, np.arange(6), np.arange(6)], 1).astype(np.int64), 50, 2, 1, bad)
+    # the same label on two separate ranges: members are selected by value (DBSCAN.py:72), so this is one cluster of three
+    lab = np.array([0.0, 0.0, -1.0, 0.0, 1.0, 1.0])
+    d6 = np.stack([np.arange(6) * 10, np.arange(6), np.arange(6)], 1).astype(np.int64)
+    want, wid = oracle.y_coordinate_clustering_labels(d6, 50, 2, 1, lab)
+    got, gid = db.y_coordinate_clustering(d6, 50, 2, 1, lab.copy())
+    assert gid == wid and np.array_equal(got, want)
+
+
+def test_y_pass_on_arbitrary_labels_equals_the_reference(db, golden_dir):
+    """DBSCAN.y_coordinate_clustering on every label shape the reference accepts (DBSCAN.py:66-123), against vectors made with the REAL
+    DBSCAN.py (tests/golden/dbscan_y_labels.npz): labels of another eps / m, clusters far above 128 members, a value on several
+    ranges, sparse / float / negative values, 3000 distinct values (the visiting order of set() matters), and a cluster_id below the
+    largest label, where produced ids collide with clusters not visited yet — no NotImplementedError left"""
+    z = np.load(os.path.join(golden_dir, "dbscan_y_labels.npz"))
+    n = sum(1 for k in z.files if k.endswith("_par"))
+    assert n >= 120
+    for c in range(n):
+        eps, m, cid, want_id = (int(v) for v in z["c%d_par" % c])
+        mine = z["c%d_in" % c].copy()
+        got, gid = db.y_coordinate_clustering(z["c%d_data" % c], eps, m, cid, mine)
+        assert got is mine and gid == want_id and np.array_equal(got, z["c%d_out" % c]), (c, str(z["c%d_kind" % c]))
+
+
+def test_y_pass_large_and_colliding_labels_against_the_literal_restatement(db):
+    """sizes the golden vectors do not reach: one 30 000-member cluster next to small ones (the old 128-member limit), 2 000 clusters
+    with cluster_id below the largest label (the literal replay), float labels; vs oracle.y_coordinate_clustering_labels"""
+    rng = np.random.default_rng(77)
+    x = np.sort(rng.integers(0, 3_000_000, 40_000))
+    y = x + rng.integers(0, 2000, len(x))
+    data = np.stack([x, y], 1).astype(np.int64)
+    lab = np.full(len(x), -1.0)
+    lab[1000:31_000] = 0
+    lab[31_500:31_600] = 1
+    lab[32_000:32_050] = 2.5
+    for cid in (2, 3, 10):
+        want, wid = oracle.y_coordinate_clustering_labels(data, 40, 3, cid, lab)
+        got, gid = db.y_coordinate_clustering(data, 40, 3, cid, lab.copy())
+        assert gid == wid and np.array_equal(got, want), cid
+    n = 6000
+    x = np.sort(rng.integers(0, 800_000, n))
+    data = np.stack([x, x + rng.integers(0, 300, n)], 1).astype(np.int64)
+    lab = np.sort(rng.integers(-1, 2000, n)).astype(np.float64)
+    for cid in (-1, 50, 1000, 1999):
+        want, wid = oracle.y_coordinate_clustering_labels(data, 60, 2, cid, lab)
+        got, gid = db.y_coordinate_clustering(data, 60, 2, cid, lab.copy())
+        assert gid == wid and np.array_equal(got, want), cid
+    with pytest.raises(ValueError):                               # m = 1: max() of an empty window, like the reference
+        db.y_coordinate_clustering(data, 60, 1, 5, lab.copy())
 
 
 def test_coverage_config2_whole_genome_every_contig(cov, ctx):

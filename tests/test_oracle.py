@@ -151,3 +151,30 @@ def test_np_mean_restatement_equals_numpy():
             gotm, k = oracle.np_masked_mean(v, g)
             assert got == want or (np.isnan(got) and np.isnan(want)), (n, off)
             assert (gotm == wantm or (np.isnan(gotm) and np.isnan(wantm))) and k == int((g > -1).sum()), (n, off)
+
+
+def test_y_pass_on_arbitrary_labels_pinned_to_the_reference(golden_dir):
+    """oracle.y_coordinate_clustering_labels == the real DBSCAN.y_coordinate_clustering on labels of every shape (another eps/m,
+    clusters above 128 members, a value on several ranges, sparse / float / negative values, cluster_id below the largest label)"""
+    import oracle
+    z = np.load(os.path.join(golden_dir, "dbscan_y_labels.npz"))
+    n = sum(1 for k in z.files if k.endswith("_par"))
+    kinds = set()
+    for c in range(n):
+        eps, m, cid, want_id = (int(v) for v in z["c%d_par" % c])
+        got, gid = oracle.y_coordinate_clustering_labels(z["c%d_data" % c], eps, m, cid, z["c%d_in" % c])
+        assert gid == want_id and np.array_equal(got, z["c%d_out" % c]), (c, str(z["c%d_kind" % c]))
+        kinds.add(str(z["c%d_kind" % c]))
+    assert kinds == {"other_eps", "large", "split_ranges", "arbitrary", "collide", "collide_random", "many_sparse"}
+    # the collision cases really differ from the collision-free closed form (else they would test nothing)
+    differ = 0
+    for c in range(n):
+        if str(z["c%d_kind" % c]).startswith("collide"):
+            eps, m, cid, _ = (int(v) for v in z["c%d_par" % c])
+            lab = z["c%d_in" % c]
+            hi = max(cid, int(lab.max())) + 1000
+            shifted, _ = oracle.y_coordinate_clustering_labels(z["c%d_data" % c], eps, m, hi, lab)
+            a, b = z["c%d_out" % c], shifted
+            same_partition = len(set(zip(a.tolist(), b.tolist()))) == len(set(a.tolist())) == len(set(b.tolist()))
+            differ += not same_partition
+    assert differ >= 3

@@ -57,6 +57,7 @@ SYMBOLS = {
     "tdt_gc_bins_device": (_i, [_P, _P, _i64, _i, _dbl, _P]),
     "tdt_dbscan": (_i, [_P, _P, _sz, _sz, _dbl, _i, _i, _P, ctypes.POINTER(_i64)]),
     "tdt_dbscan_y": (_i, [_P, _P, _sz, _sz, _dbl, _i, _i64, _P, ctypes.POINTER(_i64)]),
+    "tdt_dbscan_y_segments": (_i, [_P, _P, _P, _P, _sz, _i, _dbl, _i, _i64, _P, ctypes.POINTER(_i64)]),
     "tdt_dbscan_y_device": (_i, [_P, _P, _P, _sz, ctypes.c_uint64, _i, _i64, _P, _P, ctypes.POINTER(_i)]),
     "tdt_dbscan_device": (_i, [_P, _P, _P, _sz, _P, _i, ctypes.c_uint64, _i, _i, _P, _P]),
     "tdt_sort_dbscan": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P]),

@@ -867,6 +867,13 @@ extern "C" int tdt_dbscan_y(tdt_ctx *ctx, const int64_t *data, size_t n, size_t 
         }
         cur = l;
     }
+    if (cluster_id < next - 1) {
+        // extra sub-runs would be numbered cluster_id + k <= the largest label: the reference's later `clusters == cluster` masks pick
+        // them up again (DBSCAN.py:72,115) — not the closed form of this path
+        tdt_set_error("tdt_dbscan_y: cluster_id %lld is below the largest label %lld (ids would collide with clusters not visited yet)",
+                      (long long)cluster_id, next - 1);
+        return TDT_E_UNSUPPORTED;
+    }
     int64_t ymin = data[1], ymax = data[1];
     for (size_t i = 0; i < n; i++) {
         ymin = std::min(ymin, data[i * stride + 1]);
