@@ -85,6 +85,16 @@ int tdt_cov_pack_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t *d_e
                         uint64_t *d_packed);
 int tdt_cov_push_packed_device_multi(tdt_cov *cov, int n_items, const int *tids, const uint64_t *const *d_packed, const int32_t *const *d_end,
                                      const size_t *n, int min_q);
+/* BINNED records — 8 bytes per read, made for THIS histogram's bin size (2 <= bin_size < 1024, else TDT_E_UNSUPPORTED): low word =
+ * first_bin << 2 | shape (0 one bin, 1 two bins [up to 256 for bins <= 128 bp], 2 replay literally, 3 invalid), high word = the filter
+ * byte of the packed record | the two table indices bases_first_bin / bases_last_bin of tiddit_coverage.pyx:53-63 (csrc/tdt_common.h:
+ * cov_bin_record).  The division, the bin split and the validity checks are done once when the record is written — by the ingest kernel
+ * (tdt_ingest_bin_for) or by tdt_cov_pack_binned_device from the four arrays — and leave the accumulation launch.  d_start / d_end serve
+ * the reads replayed literally (shape 2) and must be given. */
+int tdt_cov_pack_binned_device(tdt_cov *cov, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq, const uint16_t *d_flag,
+                               size_t n, uint64_t *d_binned);
+int tdt_cov_push_binned_device_multi(tdt_cov *cov, int n_items, const int *tids, const uint64_t *const *d_binned, const int32_t *const *d_start,
+                                     const int32_t *const *d_end, const size_t *n, int min_q);
 /* All contigs at once: d_out holds tdt_cov_total_bins doubles, contig tid starts at tdt_cov_offset(tid)
  * (contigs are padded to 16-byte boundaries). */
 int tdt_cov_total_bins(tdt_cov *cov, int64_t *total);
@@ -315,6 +325,9 @@ int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len);
 int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n);
 /* device pointer of the batch's PACKED coverage records (see tdt_cov_push_packed_device_multi), valid until the next push */
 int tdt_ingest_packed(tdt_ingest *g, const uint64_t **d_packed);
+/* From the next push on the reader writes BINNED records for `cov` (NULL: the generic packed records again) into the column
+ * tdt_ingest_packed returns; *binned = 1 when it does (0: that histogram's bin size has no binned form, the column stays generic). */
+int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned);
 int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 

@@ -883,9 +883,17 @@ def test_coverage_config2_whole_genome_every_contig(cov, ctx):
             w, k = oracle.coverage_stream(s, e, mq, fl.view(np.uint16), L, z, q)
             want.append(w)
             kept += k
-        for layout in ("packed", "four arrays"):
+        for layout in ("binned", "packed", "four arrays"):
             h = cov.CoverageHistogram(contigs, z)
-            if layout == "packed":
+            if layout == "binned":                      # records made for THIS bin size (what the bound ingest kernel writes)
+                bn = torch.empty(sum(n), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                offs = np.concatenate([[0], np.cumsum(n)])
+                for c in range(C):
+                    h.pack_binned_device(c, reads[c][0].data_ptr(), reads[c][1].data_ptr(), reads[c][2].data_ptr(), reads[c][3].data_ptr(), n[c],
+                                         bn.data_ptr() + 8 * int(offs[c]))
+                h.push_binned_device_multi([(c, bn.data_ptr() + 8 * int(offs[c]), reads[c][0].data_ptr(), reads[c][1].data_ptr(), n[c]) for c in range(C)], q)
+            elif layout == "packed":
                 h.push_packed_device_multi([(c, packed[c].data_ptr(), reads[c][1].data_ptr(), n[c]) for c in range(C)], q)
             else:
                 h.push_device_multi([(c, reads[c][0].data_ptr(), reads[c][1].data_ptr(), reads[c][2].data_ptr(), reads[c][3].data_ptr(), n[c])
@@ -894,13 +902,15 @@ def test_coverage_config2_whole_genome_every_contig(cov, ctx):
                 assert np.array_equal(h.finish(contigs[c][0]), want[c]), (z, layout, c)
             assert h.kept() == kept, (z, layout)
             h.close()
+            if layout == "binned":
+                del bn
 
 
 @pytest.mark.parametrize("seed", range(8))
 def test_coverage_random_parameter_sweep(cov, ctx, seed):
     """Random bin sizes on both sides of every kernel switch (1, the table-driven 2..1023 with their 24-bit division constants, the
     difference-pair flavour <= 128, >= 1024), contig lengths that are and are not multiples of the bin, short / long / mixed reads,
-    sorted and shuffled streams, several filters — packed records and the four arrays against the scalar oracle"""
+    sorted and shuffled streams, several filters — binned records, packed records and the four arrays against the scalar oracle"""
     torch = pytest.importorskip("torch")
     from tiddit_amd import _native
     dev = torch.device("cuda:0")
@@ -931,9 +941,19 @@ def test_coverage_random_parameter_sweep(cov, ctx, seed):
         pk = torch.empty(n, dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         _native.check(ctx.lib.tdt_cov_pack_device(ctx.handle, ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), n, pk.data_ptr()))
-        for layout in ("packed", "four arrays"):
+        for layout in ("binned", "packed", "four arrays"):
             h = cov.CoverageHistogram([("c", LN)], z)
-            if layout == "packed":
+            if layout == "binned":
+                bn = torch.empty(n, dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                if not h.has_binned():                  # bin sizes 1 and >= 1024 have no binned form: refused, not silently handled
+                    with pytest.raises(_native.TdtError):
+                        h.pack_binned_device("c", ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), n, bn.data_ptr())
+                    h.close()
+                    continue
+                h.pack_binned_device("c", ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), n, bn.data_ptr())
+                h.push_binned_device_multi([("c", bn.data_ptr(), ts[0].data_ptr(), ts[1].data_ptr(), n)], q)
+            elif layout == "packed":
                 h.push_packed_device_multi([("c", pk.data_ptr(), ts[1].data_ptr(), n)], q)
             else:
                 h.push_device_multi([("c", ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), n)], q)
@@ -993,3 +1013,66 @@ def test_dbscan_random_parameter_sweep(ctx, nat, seed):
         key = (seed, nb, m, eps, mode, bool(srt), sizes.tolist())
         assert np.array_equal(tl.cpu().numpy()[:len(x)], want), key
         assert np.array_equal(tid.cpu().numpy(), np.array(lastid)), key
+
+
+def _native_mod():
+    from tiddit_amd import _native
+    return _native
+
+
+def test_binned_records_fields_and_edge_reads(cov, ctx):
+    """cov_bin_record (csrc/tdt_common.h) field by field against tiddit_coverage.pyx:50-63 computed in numpy, and the reads that must
+    leave the register path: three or more bins (500-bp flavour), a last bin that is the contig's last (other denominator, :67-69),
+    single-bin reads IN the contig's last bin (which do use bin_size, :53-57), invalid reads (IndexError when they pass the filter)"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    for z, LN in ((500, 10_250), (50, 10_030), (128, 9_000), (129, 9_000), (2, 101), (1023, 40_000)):
+        rng = np.random.default_rng(z)
+        n = 20_000
+        start = np.sort(rng.integers(0, LN, n))
+        span = np.where(rng.random(n) < 0.5, rng.integers(1, 2 * z + 2, n), rng.integers(1, 8 * z, n))
+        end = np.minimum(start + span, LN)
+        mapq = rng.choice([0, 5, 20, 60, 255], n).astype(np.uint8)
+        flag = rng.choice([0, 0x4, 0x400, 0x10], n, p=[.85, .05, .05, .05]).astype(np.uint16)
+        s32, e32 = start.astype(np.int32), end.astype(np.int32)
+        ts = [torch.from_numpy(a).to(dev) for a in (s32, e32, mapq, flag.view(np.int16))]
+        h = cov.CoverageHistogram([("c", LN)], z)
+        bn = torch.empty(n, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        h.pack_binned_device("c", ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr(), ts[3].data_ptr(), n, bn.data_ptr())
+        ctx.sync()
+        rec = bn.cpu().numpy().view(np.uint64)
+        lo, hi = (rec & 0xffffffff).astype(np.int64), (rec >> 32).astype(np.int64)
+        nb = -(-LN // z)
+        fb, eb = start // z, (end - 1) // z
+        small = z <= 128
+        shape = np.where(eb == fb, 0, np.where((eb >= nb - 1) | (eb - fb > (255 if small else 1)), 2, 1))
+        assert np.array_equal(lo >> 2, fb) and np.array_equal(lo & 3, shape)
+        assert np.array_equal(hi >> 30, ((flag & 0x400) != 0) * 2 + ((flag & 0x4) != 0)) and np.array_equal((hi >> 24) & 63, np.minimum(mapq, 63))
+        w1, w2 = (8, 8) if small else (12, 12)
+        bf = np.where(shape == 0, end - start, np.where(shape == 1, (fb + 1) * z - start, 0))
+        bl = np.where(shape == 1, (end - 1) - eb * z, 0)
+        assert np.array_equal(hi & ((1 << w1) - 1), bf) and np.array_equal((hi >> w1) & ((1 << w2) - 1), bl)
+        if small:
+            assert np.array_equal((hi >> 16) & 0xff, np.where(shape == 1, eb - fb, 0))
+        assert (shape == 2).sum() > 50 and ((shape == 0) & (fb == nb - 1)).sum() > 0
+        for q in (0, 20):
+            h.reset()
+            h.push_binned_device_multi([("c", bn.data_ptr(), ts[0].data_ptr(), ts[1].data_ptr(), n)], q)
+            want, kept = oracle.coverage_stream(s32, e32, mapq, flag, LN, z, q)
+            assert np.array_equal(h.finish("c"), want) and h.kept() == kept, (z, q)
+        # a read that ends beyond the contig, and one with end <= start: IndexError if (and only if) it passes the filter
+        for bad_end, bad_flag, raises in ((LN + 3 * z, 0, True), (int(s32[5]), 0, True), (LN + 3 * z, 0x400, False)):
+            e2, f2 = e32.copy(), flag.copy()
+            e2[5], f2[5] = bad_end, bad_flag
+            t1, t3 = torch.from_numpy(e2).to(dev), torch.from_numpy(f2.view(np.int16)).to(dev)
+            torch.cuda.synchronize()
+            h.reset()
+            h.pack_binned_device("c", ts[0].data_ptr(), t1.data_ptr(), ts[2].data_ptr(), t3.data_ptr(), n, bn.data_ptr())
+            h.push_binned_device_multi([("c", bn.data_ptr(), ts[0].data_ptr(), t1.data_ptr(), n)], 0)
+            if raises:
+                with pytest.raises(_native_mod().TdtError):
+                    h.finish("c")
+            else:
+                h.finish("c")
+        h.close()

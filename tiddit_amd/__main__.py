@@ -86,6 +86,8 @@ def run_cov(args):
         bam_header = reader.header
         coverage_data, end_bin_size = tiddit_coverage.create_coverage(bam_header, args.z)
         hist = tiddit_coverage.CoverageHistogram(bam_header, args.z)
+        if hasattr(reader, "bin_for"):
+            reader.bin_for(hist)                 # the ingest kernel writes the coverage records for this bin size
         import numpy
         for b in reader.batches():
             if isinstance(b, DeviceBatch):

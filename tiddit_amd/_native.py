@@ -45,6 +45,8 @@ SYMBOLS = {
     "tdt_cov_push_device_multi": (_i, [_P, _i, _P, _P, _P, _P, _P, _P, _i]),
     "tdt_cov_pack_device": (_i, [_P, _P, _P, _P, _P, _sz, _P]),
     "tdt_cov_push_packed_device_multi": (_i, [_P, _i, _P, _P, _P, _P, _i]),
+    "tdt_cov_pack_binned_device": (_i, [_P, _i, _P, _P, _P, _P, _sz, _P]),
+    "tdt_cov_push_binned_device_multi": (_i, [_P, _i, _P, _P, _P, _P, _P, _i]),
     "tdt_cov_total_bins": (_i, [_P, ctypes.POINTER(_i64)]),
     "tdt_cov_offset": (_i, [_P, _i, ctypes.POINTER(_i64)]),
     "tdt_cov_finish_all_device": (_i, [_P, _P]),
@@ -91,6 +93,7 @@ SYMBOLS = {
     "tdt_ingest_prefetch": (_i, [_P, _P, _sz]),
     "tdt_ingest_arrays": (_i, [_P, _PP, ctypes.POINTER(_sz)]),
     "tdt_ingest_packed": (_i, [_P, _PP]),
+    "tdt_ingest_bin_for": (_i, [_P, _P, ctypes.POINTER(_i)]),
     "tdt_ingest_edges": (_i, [_P, _P, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "tdt_copy_to_host": (_i, [_P, _P, _P, _sz]),

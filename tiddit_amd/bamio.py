@@ -367,6 +367,7 @@ class DeviceBatch:
 
     def __init__(self, reader, n, ptrs, raw_len, runs):
         self._reader, self._n, self._raw_len, self.runs = reader, n, raw_len, runs
+        self.binned_for = None          # the CoverageHistogram whose bin size the "packed" column was written for (None: generic packed records)
         self.dev = {k: int(ptrs[i] or 0) for i, (k, _) in enumerate(_FIELDS)}
         self.dev["raw"] = int(ptrs[13] or 0)
         self._host = {}
@@ -383,6 +384,8 @@ class DeviceBatch:
                 raise RuntimeError("DeviceBatch used after the reader moved on to the next batch")
             if name == "raw":
                 a = np.empty(self._raw_len, dtype=np.uint8)
+            elif name == "packed":
+                a = np.empty(self._n, dtype=np.uint64)
             else:
                 a = np.empty(self._n, dtype=dict(_FIELDS)[name])
             ctx = self._reader.ctx
@@ -434,6 +437,15 @@ class DeviceBamReader:
                     f.seek(x + 16)
                     x += struct.unpack("<H", f.read(2))[0] + 1
             self._x_hi = min(x, fsize)
+
+    def bin_for(self, hist):
+        """From the next batch on, the 8-byte coverage records the ingest kernel writes are BINNED records for `hist`'s bin size
+        (CoverageHistogram.push_device_batch then takes the cheaper launch); None returns to the generic packed records.  -> whether
+        the reader now writes binned records (bin sizes 1 and >= 1024 have none)."""
+        on = ctypes.c_int(0)
+        _native.check(self.ctx.lib.tdt_ingest_bin_for(self._h, hist.handle if hist is not None else None, ctypes.byref(on)))
+        self._binned_for = hist if on.value else None
+        return bool(on.value)
 
     def _spans(self):
         """(buffer, consumed) spans of whole BGZF blocks, read ahead by a helper thread into rotating pinned buffers"""
@@ -596,7 +608,8 @@ class DeviceBamReader:
             b = DeviceBatch(self, n.value, ptrs, raw_len.value, None)
             pk = ctypes.c_void_p()
             _native.check(lib.tdt_ingest_packed(self._h, ctypes.byref(pk)))
-            b.dev["packed"] = int(pk.value or 0)         # 8-byte coverage records (csrc/tdt_common.h: cov_pack_record)
+            b.dev["packed"] = int(pk.value or 0)         # 8-byte coverage records (csrc/tdt_common.h: cov_pack_record / cov_bin_record)
+            b.binned_for = getattr(self, "_binned_for", None)
             if ne.value == ctypes.c_size_t(-1).value:                   # not coordinate sorted: runs from the tid column
                 tid = b.tid
                 lo = np.concatenate([[0], np.flatnonzero(np.diff(tid)) + 1])

@@ -50,7 +50,7 @@ struct CovItem {
     int nbins;
     int aligned;                         // all four arrays vector-load aligned
     unsigned first_block;                // first workgroup of this item inside a multi-contig launch
-    unsigned pad_;
+    unsigned binned;                     // `packed` holds cov_bin_record records (start and end then serve the literal path)
 };
 
 struct CovParams {
@@ -200,6 +200,14 @@ __global__ void cov_pack(const int32_t *__restrict__ start, const int32_t *__res
     for (; i < n; i += stride) out[i] = cov_pack_record(start[i], end[i], mapq[i], flag[i]);
 }
 
+__global__ void cov_pack_binned(const int32_t *__restrict__ start, const int32_t *__restrict__ end, const uint8_t *__restrict__ mapq,
+                                const uint16_t *__restrict__ flag, unsigned long long n, int nbins, unsigned z, unsigned magic, int shift, int mode1,
+                                unsigned long long *__restrict__ out) {
+    unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = cov_bin_record(start[i], end[i], mapq[i], flag[i], nbins, z, magic, shift, mode1 != 0);
+}
+
 // MODE 0 (many reads per bin, e.g. --cov at 500 bp): contributions to bins K, K+1, K+2 are folded into three
 //   registers per lane and merged across the wave by a prefix scan over runs of equal K.
 // MODE 1 (few reads per bin, e.g. --sv at 50 bp, where a 150-bp read covers 3-5 bins and neighbouring lanes hardly
@@ -227,8 +235,11 @@ __global__ void cov_pack(const int32_t *__restrict__ start, const int32_t *__res
 #ifndef COV_MIN_WAVES1
 #define COV_MIN_WAVES1 4                           // ... MODE 1
 #endif
-template <bool LDS_LUT, int MODE, bool Z1, int RPL, bool PACKED>
-__global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (PACKED ? COV_MIN_WAVES : COV_MIN_WAVES4)) void cov_accumulate(CovParams P) {
+// REC: the record layout of the stream — 0: four arrays (start, end, mapq, flag), 1: 8-byte packed records (cov_pack_record),
+//      2: 8-byte BINNED records (cov_bin_record: first bin, table indices and shape precomputed for this histogram's bin size)
+template <bool LDS_LUT, int MODE, bool Z1, int RPL, int REC>
+__global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? COV_MIN_WAVES : COV_MIN_WAVES4)) void cov_accumulate(CovParams P) {
+    constexpr bool PACKED = REC != 0;                  // 8-byte records in I.packed
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
     // everything lives in the dynamic region (a static __shared__ in front of it would shift its
     // base off 16-byte alignment): [0..11] scratch (4 scan words, then the bin of every tile's last read), [12..) window
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (PACKED ?
     }
     // window base: the bin of the chunk's first read; every thread derives it from the same (scalar) load
     auto bin_of_read = [&](unsigned long long idx) {
+        if constexpr (REC == 2) return (int)((unsigned)I.packed[idx] >> 2);     // (clamped to the contig's bins when the record was made)
         int s = PACKED ? (int)(unsigned)I.packed[idx] : I.start[idx];
         s = s < 0 ? 0 : s;
         const int b = div(s);
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (PACKED ?
     };
 
     unsigned nkept = 0;
+    unsigned nkept_s = 0;                              // kept reads counted by wave ballots (binned records): the same value in every lane
     bool bad = false;
 
     for (unsigned long long t0 = r0; t0 < r1; t0 += TILE) {
@@ -398,6 +411,116 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (PACKED ?
             }
         }
 
+        if constexpr (REC == 2) {
+            // ---- binned records (cov_bin_record, tdt_common.h): low word = first_bin << 2 | shape, high word = filter byte | table indices.
+            // Everything that depends only on the read and the bin size — the division, the single-/two-bin split, the bases in the
+            // first and last bin with the "one short" quirk (tiddit_coverage.pyx:50-63), the validity checks — was done once when the
+            // record was written (ingest / tdt_cov_pack_binned_device).  What is left per read: its bin relative to the lane key, the
+            // read filter (one range test), two table reads and the three 64-bit adds.  Kept-read counts and the "some read needs the
+            // literal path" flag are wave ballots in SGPRs (scalar unit), not per-lane VALU work.
+            static_assert(LDS_LUT && !Z1, "binned records exist for 2 <= bin_size < 1024");
+            const unsigned K4 = (unsigned)cur.w[0] & ~3u;        // lane key: the first bin of the lane's first read (any K is correct)
+            const int K = (int)(K4 >> 2);
+            const unsigned ko = (unsigned)(K - base);
+            const unsigned minq24 = (unsigned)P.min_q << 24, qlim = (64u - (unsigned)P.min_q) << 24;
+            unsigned long long slow_any = 0;
+            unsigned long long a0 = 0, a1 = 0, a2 = 0;
+            if constexpr (MODE == 0) {
+                const bool safe = ko < (unsigned)(WIN - 3);
+                const unsigned kw = safe ? ko : 0u;
+                const char *pairA = reinterpret_cast<const char *>(lutS + 2 * (z + 1));       // (v, 0) entries, then the (0, v) ones
+                const unsigned zb = (z + 1u) << 4;
+#pragma unroll
+                for (int j = 0; j < RPL; j++) {
+                    const unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
+                    const unsigned d = lo - K4;                  // (first bin - K) << 2 | shape: the register path takes 0, 1 (bin K) and 4, 5 (bin K+1)
+                    const bool cand = hi - minq24 < qlim;        // __main__.py:231-235 / tiddit_signal.pyx:171-181 as one range test
+                    const bool fast = cand & safe & ((d & ~5u) == 0u);
+                    nkept_s += (unsigned)__popcll(__ballot(fast));
+                    slow_any |= __ballot(cand & !fast);
+                    const unsigned rzb = (d & 4u) ? zb : 0u;     // first bin K+1: the (0, v) table
+                    const unsigned xo = fast ? ((hi & 0xfffu) << 4) + rzb : 0u;
+                    const ulonglong2 X = *reinterpret_cast<const ulonglong2 *>(pairA + xo);
+                    const bool multi = fast & ((d & 1u) != 0u);
+                    const unsigned yo = multi ? (((hi >> 12) & 0xfffu) << 4) + rzb : 0u;
+                    const ulonglong2 Y = *reinterpret_cast<const ulonglong2 *>(pairA + yo);
+                    a0 += X.x;
+                    a1 += X.y + Y.x;
+                    a2 += Y.y;
+                }
+                if (slow_any) {                                  // wave-uniform; rare: reads of three or more bins, the contig's last bin, unsorted input
+                    const unsigned long long idx = t0 + (unsigned long long)tid * RPL;
+#pragma unroll
+                    for (int j = 0; j < RPL; j++) {
+                        const unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
+                        const unsigned d = lo - K4;
+                        if ((hi - minq24 < qlim) && !(safe & ((d & ~5u) == 0u))) {
+                            if ((lo & 3u) == COV_BN_INVALID || idx + j >= r1) bad = true;
+                            else { nkept++; slow_read(I.start[idx + j], I.end[idx + j]); }
+                        }
+                    }
+                }
+                wave_scan3_u64(a0, a1, a2);
+                const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
+                const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
+                const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(a0), q1 = dpp_u64<DPP_WAVE_SHR1>(a1), q2 = dpp_u64<DPP_WAVE_SHR1>(a2);
+                if (safe && Knext != K) {  // run tail (lane 63 always: it reads ~K)
+                    if (a0) atomicAdd(&win[kw], a0);
+                    if (a1) atomicAdd(&win[kw + 1], a1);
+                    if (a2) atomicAdd(&win[kw + 2], a2);
+                }
+                if (safe && Kprev != K && lane != 0) {  // run head
+                    if (q0) atomicAdd(&win[kw], 0ull - q0);
+                    if (q1) atomicAdd(&win[kw + 1], 0ull - q1);
+                    if (q2) atomicAdd(&win[kw + 2], 0ull - q2);
+                }
+            } else {
+                // small bins (MODE 1): difference pairs in the window words, see above; fields bf:8 | bl:8 | bins after the first:8
+                const unsigned long long *tabA = lutS + 2 * (z + 1), *tabL = tabA + 2 * (z + 1);
+                const bool safe = ko < (unsigned)(WIN - COV_DQMAX - 2);
+                const unsigned kw = safe ? ko : 0u;
+                unsigned d1 = 0, d2 = 0;
+                unsigned long long vL[RPL];
+                unsigned woff[RPL];
+#pragma unroll
+                for (int j = 0; j < RPL; j++) {
+                    const unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
+                    const unsigned d = lo - K4;
+                    const bool cand = hi - minq24 < qlim;
+                    const bool fast = cand & safe & ((d & ~5u) == 0u);
+                    nkept_s += (unsigned)__popcll(__ballot(fast));
+                    slow_any |= __ballot(cand & !fast);
+                    const bool r1_ = (d & 4u) != 0u;             // first bin = K + 1
+                    const bool multi = fast & ((d & 1u) != 0u);
+                    const unsigned long long vv = tabA[(fast ? (hi & 0xffu) : 0u) + (r1_ ? z + 1u : 0u)];   // (to bin K, to bin K+1)
+                    a0 += (unsigned)vv;
+                    a1 += (unsigned)(vv >> 32);
+                    d1 += (multi & !r1_) ? 1u : 0u;
+                    d2 += (multi & r1_) ? 1u : 0u;
+                    vL[j] = tabL[multi ? ((hi >> 8) & 0xffu) : z + 1u];          // the last bin's quotient with the -1 of the difference pair
+                    woff[j] = multi ? kw + (d >> 2) + ((hi >> 16) & 0xffu) : (unsigned)WIN;
+                }
+#pragma unroll
+                for (int j = 0; j < RPL; j++) atomicAdd(&win[woff[j]], vL[j]);
+                atomicAdd(&win[kw], a0);
+                atomicAdd(&win[kw + 1], a1 + ((unsigned long long)d1 << COV_DBIT));
+                atomicAdd(&win[kw + 2], (unsigned long long)d2 << COV_DBIT);
+                if (slow_any) {
+                    const unsigned long long idx = t0 + (unsigned long long)tid * RPL;
+#pragma unroll
+                    for (int j = 0; j < RPL; j++) {
+                        const unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
+                        const unsigned d = lo - K4;
+                        if ((hi - minq24 < qlim) && !(safe & ((d & ~5u) == 0u))) {
+                            if ((lo & 3u) == COV_BN_INVALID || idx + j >= r1) bad = true;
+                            else { nkept++; slow_read(I.start[idx + j], I.end[idx + j]); }
+                        }
+                    }
+                }
+            }
+            cur = nxt;
+            continue;
+        }
         int sv[RPL], ev[RPL];
         unsigned mq[RPL], fl[RPL];
         constexpr unsigned FMASK = PACKED ? 0x3u : 0x404u;       // unmapped / duplicate bits of fl[]
@@ -644,6 +767,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (PACKED ?
     // kept-read count: one atomic per wave, spread over COV_KEPT_SLOTS cache lines (thousands of
     // same-address atomics serialise at ~12 ns each and would bound the whole launch)
     for (int d = 32; d > 0; d >>= 1) nkept += __shfl_down(nkept, d);
+    nkept += nkept_s;
     if (lane == 0 && nkept)
         atomicAdd(P.kept + (size_t)((blockIdx.x * (COV_THREADS / 64) + (tid >> 6)) % COV_KEPT_SLOTS) * 16, (unsigned long long)nkept);
     if (bad) atomicOr(P.status, 1);
@@ -683,6 +807,7 @@ struct tdt_cov {
     unsigned long long *d_lut_end = nullptr;  // [n_contigs][bin_size+1]
     int *d_status = nullptr;                  // [0] status bits; kept counters start 128 B further
     unsigned long long *d_kept = nullptr;     // COV_KEPT_SLOTS counters, 128 B apart
+    int *d_nbins = nullptr;                   // bins of every contig (what cov_bin_record needs on the device)
     // staging slots for host pushes
     void *d_stage[2] = {nullptr, nullptr};
     void *h_stage[2] = {nullptr, nullptr};
@@ -816,6 +941,11 @@ extern "C" int tdt_cov_create(tdt_ctx *ctx, const int64_t *contig_len, int n_con
     if ((e = hipMalloc((void **)&c->d_lut_main, lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut)");
     if ((e = hipMalloc((void **)&c->d_lut_end, (size_t)n_contigs * lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut_end)");
     if ((e = hipMalloc((void **)&c->d_status, COV_STATUS_BYTES)) != hipSuccess) return fail("hipMalloc(status)");
+    {
+        std::vector<int> nb32(c->nbins.begin(), c->nbins.end());
+        if ((e = hipMalloc((void **)&c->d_nbins, (size_t)n_contigs * 4)) != hipSuccess) return fail("hipMalloc(nbins)");
+        if ((e = hipMemcpy(c->d_nbins, nb32.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(nbins)");
+    }
     c->d_kept = (unsigned long long *)((char *)c->d_status + 128);
     if ((e = hipMemcpy(c->d_lut_main, lut.data(), lut_n * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(lut)");
     if ((e = hipMemcpy(c->d_lut_end, lute.data(), (size_t)n_contigs * lut_n * 8, hipMemcpyHostToDevice)) != hipSuccess)
@@ -836,6 +966,7 @@ extern "C" void tdt_cov_destroy(tdt_cov *c) {
     if (c->d_lut_main) (void)hipFree(c->d_lut_main);
     if (c->d_lut_end) (void)hipFree(c->d_lut_end);
     if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_nbins) (void)hipFree(c->d_nbins);
     for (int i = 0; i < 2; i++) {
         if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
@@ -879,7 +1010,7 @@ static CovItem cov_item(tdt_cov *c, int tid, const int32_t *d_start, const int32
     it.aligned = (((uintptr_t)d_start | (uintptr_t)d_end) & 15) == 0 && ((uintptr_t)d_mapq & (COV_RPL - 1)) == 0 &&
                  ((uintptr_t)d_flag & (2 * COV_RPL - 1)) == 0;
     it.first_block = 0;
-    it.pad_ = 0;
+    it.binned = 0;
     return it;
 }
 
@@ -913,22 +1044,27 @@ static int cov_launch_items(tdt_cov *c, const CovItem &single, const CovItem *d_
                        (small ? (3 * ((size_t)c->bin_size + 1) + 1) * 8 : 0) + ((!small && lds_lut && c->shift >= 0) ? 4 * ((size_t)c->bin_size + 1) * 8 : 0);
     // small bins: few reads share a bin, a read covers several -> difference-pair kernel
     const bool packed = single.packed != nullptr;
-    if (small && packed)
-        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    const bool binned = packed && single.binned;              // (one layout per launch: the push entry points build their items alike)
+    if (binned && small)
+        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1, 2>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (binned)
+        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL, 2>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+    else if (small && packed)
+        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1, 1>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (small)
-        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<true, 1, false, COV_RPL1, 0>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (lds_lut && c->shift >= 0 && packed)
-        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL, 1>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (lds_lut && c->shift >= 0)
-        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<true, 0, false, COV_RPL, 0>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (lds_lut && packed)
-        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL, 1>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (lds_lut)
-        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<true, 0, true, COV_RPL, 0>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else if (packed)
-        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL, true>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL, 1>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     else
-        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL, false>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
+        hipLaunchKernelGGL((cov_accumulate<false, 0, false, COV_RPL, 0>), dim3(grid), dim3(COV_THREADS), lds, c->ctx->stream, P);
     TDT_CHECK_LAUNCH();
     return TDT_OK;
 }
@@ -1018,6 +1154,85 @@ extern "C" int tdt_cov_push_packed_device_multi(tdt_cov *c, int n_items, const i
     if (items.empty()) return TDT_OK;
     if (blocks >= 0x7fffffffull) {
         tdt_set_error("tdt_cov_push_packed_device_multi: too many reads for one launch");
+        return TDT_E_ARG;
+    }
+    void *d_items = nullptr;
+    int rc = tdt_scratch(c->ctx, 7, items.size() * sizeof(CovItem), &d_items);
+    if (rc) return rc;
+    TDT_HIP(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(CovItem), hipMemcpyHostToDevice, c->ctx->stream));
+    return cov_launch_items(c, items[0], (const CovItem *)d_items, (int)items.size(), (unsigned)blocks, min_q);
+}
+
+// ---- binned records: cov_bin_record for THIS histogram's bin size (2 <= bin_size < 1024)
+int tdt_cov_bin_spec(tdt_cov *c, CovBinSpec *out) {          // (C++ linkage: the ingest kernel writes such records itself, tdt_ingest.hip)
+    *out = CovBinSpec();
+    if (!c) return TDT_E_ARG;
+    if (c->bin_size < 2 || c->bin_size + 1 > COV_LUT_LDS_MAX) return TDT_OK;       // z stays 0: no binned records for this bin size
+    out->z = (unsigned)c->bin_size;
+    out->magic = c->magic;
+    out->shift = c->shift;
+    out->mode1 = c->small_bins ? 1 : 0;
+    out->d_nbins = c->d_nbins;
+    out->n_contigs = c->n_contigs;
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_pack_binned_device(tdt_cov *c, int tid, const int32_t *d_start, const int32_t *d_end, const uint8_t *d_mapq,
+                                          const uint16_t *d_flag, size_t n, uint64_t *d_binned) {
+    if (!c || tid < 0 || tid >= c->n_contigs || (n && (!d_start || !d_end || !d_mapq || !d_flag || !d_binned))) {
+        tdt_set_error("tdt_cov_pack_binned_device: bad argument");
+        return TDT_E_ARG;
+    }
+    CovBinSpec sp;
+    tdt_cov_bin_spec(c, &sp);
+    if (!sp.z) {
+        tdt_set_error("tdt_cov_pack_binned_device: binned records exist for 2 <= bin_size < 1024 (this histogram: %d)", c->bin_size);
+        return TDT_E_UNSUPPORTED;
+    }
+    if (!n) return TDT_OK;
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(cov_pack_binned, dim3((unsigned)blocks), dim3(256), 0, c->ctx->stream, d_start, d_end, d_mapq, d_flag, (unsigned long long)n,
+                       (int)c->nbins[tid], sp.z, sp.magic, sp.shift, sp.mode1, (unsigned long long *)d_binned);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
+extern "C" int tdt_cov_push_binned_device_multi(tdt_cov *c, int n_items, const int *tids, const uint64_t *const *d_binned,
+                                                const int32_t *const *d_start, const int32_t *const *d_end, const size_t *n, int min_q) {
+    if (!c || n_items < 0 || (n_items && (!tids || !d_binned || !d_start || !d_end || !n))) {
+        tdt_set_error("tdt_cov_push_binned_device_multi: bad argument");
+        return TDT_E_ARG;
+    }
+    if (c->bin_size < 2 || c->bin_size + 1 > COV_LUT_LDS_MAX) {
+        tdt_set_error("tdt_cov_push_binned_device_multi: binned records exist for 2 <= bin_size < 1024 (this histogram: %d)", c->bin_size);
+        return TDT_E_UNSUPPORTED;
+    }
+    if (min_q > 63) {
+        tdt_set_error("tdt_cov_push_binned_device_multi: records keep min(mapq, 63); min_q %d needs the unpacked entry point", min_q);
+        return TDT_E_UNSUPPORTED;
+    }
+    if (min_q < 0) min_q = 0;
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    std::vector<CovItem> items;
+    unsigned long long blocks = 0;
+    for (int i = 0; i < n_items; i++) {
+        if (tids[i] < 0 || tids[i] >= c->n_contigs || (n[i] && (!d_binned[i] || !d_start[i] || !d_end[i]))) {
+            tdt_set_error("tdt_cov_push_binned_device_multi: bad item %d (the literal path needs the start and end arrays)", i);
+            return TDT_E_ARG;
+        }
+        if (n[i] == 0 || c->nbins[tids[i]] == 0) continue;
+        CovItem it = cov_item_packed(c, tids[i], (const unsigned long long *)d_binned[i], d_end[i], n[i]);
+        it.start = d_start[i];
+        it.binned = 1;
+        it.first_block = (unsigned)blocks;
+        blocks += (n[i] + COV_READS_PER_BLOCK - 1) / COV_READS_PER_BLOCK;
+        items.push_back(it);
+    }
+    if (items.empty()) return TDT_OK;
+    if (blocks >= 0x7fffffffull) {
+        tdt_set_error("tdt_cov_push_binned_device_multi: too many reads for one launch");
         return TDT_E_ARG;
     }
     void *d_items = nullptr;

@@ -133,7 +133,9 @@ struct IngestOut {
     uint32_t *cigar_first, *cigar_last;
     uint64_t *rec_off;
     int64_t *sa_off;
-    unsigned long long *packed;      // cov_pack_record of (pos, end, mapq, flag): what the coverage kernels read
+    unsigned long long *packed;      // cov_pack_record of (pos, end, mapq, flag) — or, when the reader is bound to a histogram
+                                     // (tdt_ingest_bin_for), cov_bin_record for its bin size: what the coverage kernels read
+    CovBinSpec bin;                  // bin.z != 0: binned records
 };
 
 __device__ __forceinline__ long long aux_value_size(unsigned char t, const unsigned char *p, const unsigned char *end) {
@@ -183,7 +185,15 @@ __global__ __launch_bounds__(64) void bam_decode_fields(const unsigned char *__r
         O.end[i] = (int)(pos + rlen);
         O.mapq[i] = r[9];
         O.flag[i] = (uint16_t)fl;
-        O.packed[i] = cov_pack_record(pos, (int)(pos + rlen), r[9], fl);
+        {
+            const int tid_ = (int)ld_u32(r);
+            if (O.bin.z) {
+                const int nb_ = (tid_ >= 0 && tid_ < O.bin.n_contigs) ? O.bin.d_nbins[tid_] : 0;          // unplaced reads: no bins (never pushed)
+                O.packed[i] = cov_bin_record(pos, (int)(pos + rlen), r[9], fl, nb_, O.bin.z, O.bin.magic, O.bin.shift, O.bin.mode1 != 0);
+            } else {
+                O.packed[i] = cov_pack_record(pos, (int)(pos + rlen), r[9], fl);
+            }
+        }
         O.mate_tid[i] = (int)ld_u32(r + 20);
         O.mate_pos[i] = (int)ld_u32(r + 24);
         O.tlen[i] = (int)ld_u32(r + 28);
@@ -593,6 +603,25 @@ extern "C" int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_
                          O.sa_off, g->out.p};
     for (int i = 0; i < 14; i++) out14[i] = g->n_records || i == 13 ? p[i] : nullptr;
     if (raw_len) *raw_len = g->out_len;
+    return TDT_OK;
+}
+
+// From the next push on, the batch's 8-byte coverage records are cov_bin_record records for `cov`'s bin size (what
+// tdt_cov_push_binned_device_multi reads); cov == NULL, or a histogram whose bin size has no binned form, returns to the generic
+// cov_pack_record.  *binned tells the caller which of the two the reader now writes.
+int tdt_cov_bin_spec(tdt_cov *c, CovBinSpec *out);     // tdt_coverage.hip
+extern "C" int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned) {
+    if (!g) {
+        tdt_set_error("tdt_ingest_bin_for: bad argument");
+        return TDT_E_ARG;
+    }
+    g->O.bin = CovBinSpec();
+    if (cov) {
+        int rc = tdt_cov_bin_spec(cov, &g->O.bin);
+        if (rc) return rc;
+        if (g->O.bin.n_contigs != g->n_ref) g->O.bin = CovBinSpec();      // not this file's contig table
+    }
+    if (binned) *binned = g->O.bin.z != 0;
     return TDT_OK;
 }
 

@@ -130,6 +130,7 @@ def coverage_sharded(bam_file_name, bin_size, min_q, group=None, ctx=None, chunk
     reader = DeviceBamReader(bam_file_name, ctx=ctx, chunk=chunk, shard=(rank, world))
     header = reader.header
     hist = tiddit_coverage.CoverageHistogram(header, bin_size, ctx=ctx)
+    reader.bin_for(hist)
     n = 0
     for b in reader.batches():
         hist.push_device_batch(b, min_q)

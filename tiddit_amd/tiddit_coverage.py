@@ -136,6 +136,26 @@ class CoverageHistogram:
         _native.check(self.lib.tdt_cov_push_packed_device_multi(self.handle, k, _native.ptr(tids), _native.ptr(pk), _native.ptr(en), _native.ptr(ns),
                                                                 int(min_q)))
 
+    def has_binned(self):
+        """binned records (csrc/tdt_common.h: cov_bin_record) exist for 2 <= bin_size < 1024"""
+        return 2 <= self.bin_size < 1024
+
+    def pack_binned_device(self, contig, d_start, d_end, d_mapq, d_flag, n, d_out):
+        """four device arrays of one contig -> n binned records for THIS histogram's bin size at d_out (8 B each)"""
+        _native.check(self.lib.tdt_cov_pack_binned_device(self.handle, self._tid(contig), d_start, d_end, d_mapq, d_flag, n, d_out))
+
+    def push_binned_device_multi(self, items, min_q):
+        """items: list of (contig, d_binned, d_start, d_end, n): 8-byte binned records of this histogram's bin size (pack_binned_device /
+        a DeviceBamReader bound with ``bin_for``) plus the start / end arrays the literal path replays long reads from — ONE launch."""
+        k = len(items)
+        tids = numpy.array([self._tid(it[0]) for it in items], dtype=numpy.int32)
+        pk = numpy.array([it[1] for it in items], dtype=numpy.uint64)
+        st = numpy.array([it[2] for it in items], dtype=numpy.uint64)
+        en = numpy.array([it[3] for it in items], dtype=numpy.uint64)
+        ns = numpy.array([it[4] for it in items], dtype=numpy.uint64)
+        _native.check(self.lib.tdt_cov_push_binned_device_multi(self.handle, k, _native.ptr(tids), _native.ptr(pk), _native.ptr(st), _native.ptr(en),
+                                                                _native.ptr(ns), int(min_q)))
+
     def push_device_batch(self, batch, min_q, want=None):
         """every per-contig run of a DeviceBatch (bamio.DeviceBamReader) in ONE launch, through the 8-byte packed records the
         ingest kernel wrote when min_q fits their 6-bit mapq field; want[tid] false skips a contig"""
@@ -143,7 +163,9 @@ class CoverageHistogram:
         runs = [(t, lo, hi) for t, lo, hi in batch.runs if t >= 0 and (want is None or want[t])]
         if not runs:
             return
-        if d.get("packed") and int(min_q) <= 63:
+        if d.get("packed") and int(min_q) <= 63 and getattr(batch, "binned_for", None) is self:
+            self.push_binned_device_multi([(t, d["packed"] + 8 * lo, d["pos"] + 4 * lo, d["end"] + 4 * lo, hi - lo) for t, lo, hi in runs], min_q)
+        elif d.get("packed") and int(min_q) <= 63 and getattr(batch, "binned_for", None) is None:
             self.push_packed_device_multi([(t, d["packed"] + 8 * lo, d["end"] + 4 * lo, hi - lo) for t, lo, hi in runs], min_q)
         else:
             self.push_device_multi([(t, d["pos"] + 4 * lo, d["end"] + 4 * lo, d["mapq"] + lo, d["flag"] + 2 * lo, hi - lo) for t, lo, hi in runs], min_q)

@@ -221,6 +221,8 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     names, lengths = reader.references, reader.lengths
     big = numpy.array([ln >= min_contig for ln in lengths], dtype=bool)
     hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(names, lengths)], bin_size)
+    if hasattr(reader, "bin_for"):
+        reader.bin_for(hist)                     # the ingest kernel writes the coverage records for this bin size
     data = {n: [] for n in names}
     splits = {n: [] for n in names}
     clips = {n: [] for n in names}
