@@ -1049,10 +1049,12 @@ def test_binned_records_fields_and_edge_reads(cov, ctx):
         shape = np.where(eb == fb, 0, np.where((eb >= nb - 1) | (eb - fb > (255 if small else 1)), 2, 1))
         assert np.array_equal(lo >> 2, fb) and np.array_equal(lo & 3, shape)
         assert np.array_equal(hi >> 30, ((flag & 0x400) != 0) * 2 + ((flag & 0x4) != 0)) and np.array_equal((hi >> 24) & 63, np.minimum(mapq, 63))
-        w1, w2 = (8, 8) if small else (12, 12)
         bf = np.where(shape == 0, end - start, np.where(shape == 1, (fb + 1) * z - start, 0))
         bl = np.where(shape == 1, (end - 1) - eb * z, 0)
-        assert np.array_equal(hi & ((1 << w1) - 1), bf) and np.array_equal((hi >> w1) & ((1 << w2) - 1), bl)
+        if small:
+            assert np.array_equal(hi & 0xff, bf) and np.array_equal((hi >> 8) & 0xff, bl)
+        else:                                       # the first-bin index is stored scaled to the 16-byte table entries
+            assert np.array_equal(hi & 0x3fff, bf << 4) and np.array_equal((hi >> 14) & 0x3ff, bl)
         if small:
             assert np.array_equal((hi >> 16) & 0xff, np.where(shape == 1, eb - fb, 0))
         assert (shape == 2).sum() > 50 and ((shape == 0) & (fb == nb - 1)).sum() > 0

@@ -81,7 +81,8 @@ __host__ __device__ __forceinline__ unsigned long long cov_pack_record(int start
 //       shape 3 (COV_BN_INVALID) start < 0, end <= start or a bin beyond the contig: the reference raises IndexError when such a
 //                                read passes the filter
 //   high word = duplicate:1 | unmapped:1 | min(mapq,63):6 (top byte, as in cov_pack_record: the read filter is one range test)
-//               | table indices: MODE 0  bases_last_bin:12 | bases_first_bin:12
+//               | table indices: MODE 0  bases_last_bin:10 | bases_first_bin:10 | 0000   (the first-bin index already scaled to the
+//                                        16-byte table entries: the accumulation launch masks it out with one AND)
 //                                MODE 1  bins_after_first:8 | bases_last_bin:8 | bases_first_bin:8
 //   bases_first_bin = end - start (single) or (first_bin+1)*bin_size - start; bases_last_bin = (end-1) - end_bin*bin_size, the
 //   reference's one-short count (:63).
@@ -111,13 +112,13 @@ __host__ __device__ __forceinline__ unsigned long long cov_bin_record(int start,
             fb = fb > last_bin ? last_bin : fb;
         } else if (eb == fb) {
             shape = COV_BN_SINGLE;
-            fields = (unsigned)(end - start);
+            fields = mode1 ? (unsigned)(end - start) : (unsigned)(end - start) << 4;
         } else if (eb >= last_bin || eb - fb > (mode1 ? 255 : 1)) {
             shape = COV_BN_SLOW;
         } else {
             shape = COV_BN_MULTI;
             const unsigned bf = (unsigned)(fb + 1) * z - (unsigned)start, bl = (unsigned)(end - 1) - (unsigned)eb * z;
-            fields = mode1 ? (bf | (bl << 8) | ((unsigned)(eb - fb) << 16)) : (bf | (bl << 12));
+            fields = mode1 ? (bf | (bl << 8) | ((unsigned)(eb - fb) << 16)) : ((bf << 4) | (bl << 14));
         }
     } else if (start >= 0 && nbins > 0) {
         fb = div(start);

@@ -116,6 +116,86 @@ __device__ __forceinline__ void wave_scan3_u64(unsigned long long &a0, unsigned 
     a2 = ((unsigned long long)h2 << 32) | l2;
 }
 
+// Lane predicates as 64-bit masks in SGPRs (one bit per lane), so that their algebra, the kept-read count (s_bcnt1) and the "any lane
+// needs the literal path" flag run on the scalar unit.  (The compiler's own ballot of a combined predicate materialises it in a VGPR
+// and compares again: two vector instructions per use.)
+__device__ __forceinline__ unsigned long long cov_mask_lt(unsigned a, unsigned lim_uniform) {   // a < lim
+    unsigned long long m;
+    asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "s"(lim_uniform), "v"(a));
+    return m;
+}
+__device__ __forceinline__ unsigned long long cov_mask_eq0(unsigned a) {
+    unsigned long long m;
+    asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    return m;
+}
+__device__ __forceinline__ unsigned long long cov_mask_ne0(unsigned a) {
+    unsigned long long m;
+    asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    return m;
+}
+__device__ __forceinline__ unsigned cov_select(unsigned long long m, unsigned if_set, unsigned if_clear) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+
+// the same for two values (each DPP read is still three instructions behind the write of its register)
+#define COV_SCAN2_STEP(CTRL)                                                                    \
+    asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\t"                                \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"                          \
+                 "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n\t"                                \
+                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL                                 \
+                 : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1)::"vcc")
+
+__device__ __forceinline__ void wave_scan2_u64(unsigned long long &a0, unsigned long long &a1) {
+    unsigned l0 = (unsigned)a0, h0 = (unsigned)(a0 >> 32), l1 = (unsigned)a1, h1 = (unsigned)(a1 >> 32);
+    asm volatile("s_nop 1" ::: "memory");  // the values were just written by plain VALU
+    COV_SCAN2_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN2_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN2_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN2_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN2_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    COV_SCAN2_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::: "memory");
+    a0 = ((unsigned long long)h0 << 32) | l0;
+    a1 = ((unsigned long long)h1 << 32) | l1;
+}
+
+// 16 bytes at an LDS byte address held in a register (ds_read_b128, no generic-pointer arithmetic)
+__device__ __forceinline__ ulonglong2 cov_lds_read128(unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned long long cov_v2u64 __attribute__((ext_vector_type(2)));
+    const cov_v2u64 v = *reinterpret_cast<const cov_v2u64 __attribute__((address_space(3))) *>(addr);
+    return make_ulonglong2(v.x, v.y);
+#else
+    (void)addr;
+    return make_ulonglong2(0, 0);
+#endif
+}
+
+__device__ __forceinline__ unsigned long long cov_lds_read64(unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const unsigned long long __attribute__((address_space(3))) *>(addr);
+#else
+    return addr;
+#endif
+}
+__device__ __forceinline__ void cov_lds_add64(unsigned addr, unsigned long long v) {           // ds_add_u64
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long __attribute__((address_space(3))) *>(addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    (void)addr; (void)v;
+#endif
+}
+// r + (the lane's bit of mask): one v_addc
+__device__ __forceinline__ unsigned cov_add_bit(unsigned r, unsigned long long mask) {
+    unsigned out;
+    unsigned long long cout;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(out), "=s"(cout) : "v"(r), "s"(mask));
+    return out;
+}
+
 // out-of-window contributions (unsorted input, reads longer than the window): plain HBM atomics.
 // noinline keeps the LDS path a real ds_add_u64 instead of a flat atomic on a selected pointer.
 __device__ __noinline__ void cov_global_add(unsigned long long *acc, int bin, unsigned long long v) {
@@ -425,25 +505,34 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
             const unsigned minq24 = (unsigned)P.min_q << 24, qlim = (64u - (unsigned)P.min_q) << 24;
             unsigned long long slow_any = 0;
             unsigned long long a0 = 0, a1 = 0, a2 = 0;
+#ifdef COV_EXP_LOADONLY  // measurement variant: the loads alone (the ceiling of this access pattern)
+            for (int j = 0; j < RPL; j++) a0 += cur.w[j];
+            if (a0 == 0x1234567ull) contribute(K, a0);
+            cur = nxt;
+            continue;
+#endif
             if constexpr (MODE == 0) {
                 const bool safe = ko < (unsigned)(WIN - 3);
                 const unsigned kw = safe ? ko : 0u;
-                const char *pairA = reinterpret_cast<const char *>(lutS + 2 * (z + 1));       // (v, 0) entries, then the (0, v) ones
-                const unsigned zb = (z + 1u) << 4;
+                // LDS byte addresses of the (v, 0) table and of the (0, v) table behind it, in registers: a table read is then
+                // `field + table` with the masked case `table` itself (entry 0 = (0, 0)) — no address add behind the select
+                const unsigned tA = (unsigned)(size_t)(lutS + 2 * (z + 1)), zb4 = (z + 1u) << 2;
+                const unsigned notsafe = safe ? 0u : 8u;
 #pragma unroll
                 for (int j = 0; j < RPL; j++) {
                     const unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
                     const unsigned d = lo - K4;                  // (first bin - K) << 2 | shape: the register path takes 0, 1 (bin K) and 4, 5 (bin K+1)
-                    const bool cand = hi - minq24 < qlim;        // __main__.py:231-235 / tiddit_signal.pyx:171-181 as one range test
-                    const bool fast = cand & safe & ((d & ~5u) == 0u);
-                    nkept_s += (unsigned)__popcll(__ballot(fast));
-                    slow_any |= __ballot(cand & !fast);
-                    const unsigned rzb = (d & 4u) ? zb : 0u;     // first bin K+1: the (0, v) table
-                    const unsigned xo = fast ? ((hi & 0xfffu) << 4) + rzb : 0u;
-                    const ulonglong2 X = *reinterpret_cast<const ulonglong2 *>(pairA + xo);
-                    const bool multi = fast & ((d & 1u) != 0u);
-                    const unsigned yo = multi ? (((hi >> 12) & 0xfffu) << 4) + rzb : 0u;
-                    const ulonglong2 Y = *reinterpret_cast<const ulonglong2 *>(pairA + yo);
+                    // __main__.py:231-235 / tiddit_signal.pyx:171-181 as one range test of the filter byte
+                    const unsigned long long m_cand = cov_mask_lt(hi - minq24, qlim);
+                    const unsigned long long m_fast = m_cand & cov_mask_eq0((d & ~5u) | notsafe);
+                    nkept_s += (unsigned)__builtin_popcountll(m_fast);
+                    slow_any |= m_cand & ~m_fast;
+                    const unsigned tab = __umul24(d & 4u, zb4) + tA;                  // first bin K+1: the (0, v) table
+                    const unsigned xa = cov_select(m_fast, (hi & 0x3ff0u) + tab, tA);
+                    const ulonglong2 X = cov_lds_read128(xa);
+                    const unsigned long long m_multi = m_fast & cov_mask_ne0(d & 1u);
+                    const unsigned ya = cov_select(m_multi, (((hi >> 14) & 0x3ffu) << 4) + tab, tA);
+                    const ulonglong2 Y = cov_lds_read128(ya);
                     a0 += X.x;
                     a1 += X.y + Y.x;
                     a2 += Y.y;
@@ -452,7 +541,8 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
                     const unsigned long long idx = t0 + (unsigned long long)tid * RPL;
 #pragma unroll
                     for (int j = 0; j < RPL; j++) {
-                        const unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
+                        unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
+                        asm volatile("" : "+v"(lo), "+v"(hi));       // recomputed here, not kept alive from the loop above (registers)
                         const unsigned d = lo - K4;
                         if ((hi - minq24 < qlim) && !(safe & ((d & ~5u) == 0u))) {
                             if ((lo & 3u) == COV_BN_INVALID || idx + j >= r1) bad = true;
@@ -460,50 +550,69 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
                         }
                     }
                 }
-                wave_scan3_u64(a0, a1, a2);
+                // bin K+2 only ever receives the last-bin part of a two-bin read that starts in bin K+1 — reads behind a bin boundary inside
+                // the lane's eight, a few lanes per wave and hardly two of them on one bin: those go to the window directly, and only
+                // the sums of bins K and K+1 take the wavefront merge (two values instead of three through the scan)
+#ifdef COV_EXP_NOATOMIC
+                if (a0 + a1 + a2 == 0x1234567ull) win[0] = a0;
+                cur = nxt;
+                continue;
+#endif
+#ifdef COV_EXP_NOSCAN
+                if (a0 + a1 + a2 == 0x1234567ull) win[0] = a0;
+                if (a2) atomicAdd(&win[kw + 2], a2);
+                cur = nxt;
+                continue;
+#endif
+                if (a2) atomicAdd(&win[kw + 2], a2);
+                wave_scan2_u64(a0, a1);
                 const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
                 const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
-                const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(a0), q1 = dpp_u64<DPP_WAVE_SHR1>(a1), q2 = dpp_u64<DPP_WAVE_SHR1>(a2);
+                const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(a0), q1 = dpp_u64<DPP_WAVE_SHR1>(a1);
                 if (safe && Knext != K) {  // run tail (lane 63 always: it reads ~K)
                     if (a0) atomicAdd(&win[kw], a0);
                     if (a1) atomicAdd(&win[kw + 1], a1);
-                    if (a2) atomicAdd(&win[kw + 2], a2);
                 }
                 if (safe && Kprev != K && lane != 0) {  // run head
                     if (q0) atomicAdd(&win[kw], 0ull - q0);
                     if (q1) atomicAdd(&win[kw + 1], 0ull - q1);
-                    if (q2) atomicAdd(&win[kw + 2], 0ull - q2);
                 }
             } else {
-                // small bins (MODE 1): difference pairs in the window words, see above; fields bf:8 | bl:8 | bins after the first:8
-                const unsigned long long *tabA = lutS + 2 * (z + 1), *tabL = tabA + 2 * (z + 1);
+                // small bins (MODE 1): difference pairs in the window words, see above; fields bf:8 | bl:8 | bins after the first:8.
+                // Predicates are SGPR masks; table and window accesses go through LDS byte addresses held in registers, the masked
+                // case being the table's zero entry / the window's spare word.
                 const bool safe = ko < (unsigned)(WIN - COV_DQMAX - 2);
                 const unsigned kw = safe ? ko : 0u;
-                unsigned d1 = 0, d2 = 0;
+                const unsigned notsafe = safe ? 0u : 8u;
+                const unsigned tA = (unsigned)(size_t)(lutS + 2 * (z + 1)), zb2 = (z + 1u) << 1;            // tabA, then tabB = tabA + (z+1) entries
+                const unsigned tL = tA + ((z + 1u) << 4), tL0 = tL + ((z + 1u) << 3);                        // tabL and its zero entry
+                const unsigned wK = (unsigned)(size_t)(win + kw), wSpare = (unsigned)(size_t)(win + WIN);
+                unsigned d12 = 0, d2 = 0;                        // reads that put their +1 on bin K+1 or K+2 / on K+2
                 unsigned long long vL[RPL];
                 unsigned woff[RPL];
 #pragma unroll
                 for (int j = 0; j < RPL; j++) {
                     const unsigned lo = (unsigned)cur.w[j], hi = (unsigned)(cur.w[j] >> 32);
                     const unsigned d = lo - K4;
-                    const bool cand = hi - minq24 < qlim;
-                    const bool fast = cand & safe & ((d & ~5u) == 0u);
-                    nkept_s += (unsigned)__popcll(__ballot(fast));
-                    slow_any |= __ballot(cand & !fast);
-                    const bool r1_ = (d & 4u) != 0u;             // first bin = K + 1
-                    const bool multi = fast & ((d & 1u) != 0u);
-                    const unsigned long long vv = tabA[(fast ? (hi & 0xffu) : 0u) + (r1_ ? z + 1u : 0u)];   // (to bin K, to bin K+1)
+                    const unsigned long long m_cand = cov_mask_lt(hi - minq24, qlim);
+                    const unsigned long long m_fast = m_cand & cov_mask_eq0((d & ~5u) | notsafe);
+                    nkept_s += (unsigned)__builtin_popcountll(m_fast);
+                    slow_any |= m_cand & ~m_fast;
+                    const unsigned r4 = d & 4u;                  // first bin = K + 1
+                    const unsigned tab = __umul24(r4, zb2) + tA;
+                    const unsigned long long vv = cov_lds_read64(cov_select(m_fast, ((hi & 0xffu) << 3) + tab, tA));   // (to bin K, to bin K+1)
                     a0 += (unsigned)vv;
                     a1 += (unsigned)(vv >> 32);
-                    d1 += (multi & !r1_) ? 1u : 0u;
-                    d2 += (multi & r1_) ? 1u : 0u;
-                    vL[j] = tabL[multi ? ((hi >> 8) & 0xffu) : z + 1u];          // the last bin's quotient with the -1 of the difference pair
-                    woff[j] = multi ? kw + (d >> 2) + ((hi >> 16) & 0xffu) : (unsigned)WIN;
+                    const unsigned long long m_multi = m_fast & cov_mask_ne0(d & 1u);
+                    d12 = cov_add_bit(d12, m_multi);
+                    d2 = cov_add_bit(d2, m_multi & cov_mask_ne0(r4));
+                    vL[j] = cov_lds_read64(cov_select(m_multi, (((hi >> 8) & 0xffu) << 3) + tL, tL0));     // the last bin's quotient with the -1 of the pair
+                    woff[j] = cov_select(m_multi, (((d >> 2) + ((hi >> 16) & 0xffu)) << 3) + wK, wSpare);
                 }
 #pragma unroll
-                for (int j = 0; j < RPL; j++) atomicAdd(&win[woff[j]], vL[j]);
+                for (int j = 0; j < RPL; j++) cov_lds_add64(woff[j], vL[j]);
                 atomicAdd(&win[kw], a0);
-                atomicAdd(&win[kw + 1], a1 + ((unsigned long long)d1 << COV_DBIT));
+                atomicAdd(&win[kw + 1], a1 + ((unsigned long long)(d12 - d2) << COV_DBIT));
                 atomicAdd(&win[kw + 2], (unsigned long long)d2 << COV_DBIT);
                 if (slow_any) {
                     const unsigned long long idx = t0 + (unsigned long long)tid * RPL;
