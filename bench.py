@@ -186,7 +186,23 @@ def main():
         ctx.sync()
     torch.cuda.synchronize()
     pack_ms = pk_a.elapsed_time(pk_b)
-    items = [(c, packed[c].data_ptr(), reads[c][1].data_ptr(), n_reads[c]) for c in range(C)]
+    items_packed = [(c, packed[c].data_ptr(), reads[c][1].data_ptr(), n_reads[c]) for c in range(C)]
+    # ... and as the ingest kernel leaves it when the reader is bound to THIS histogram (DeviceBamReader.bin_for): 8-byte binned records
+    # (first bin << 2 | shape, filter byte, table indices — csrc/tdt_common.h: cov_bin_record), made here by the library's packing kernel
+    binned = [torch.empty(n_reads[c], dtype=torch.int64, device=dev) for c in range(C)]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        if rep:
+            pk_a.record(stream)
+        for c in range(C):
+            hist.pack_binned_device(c, reads[c][0].data_ptr(), reads[c][1].data_ptr(), reads[c][2].data_ptr(), reads[c][3].data_ptr(), n_reads[c],
+                                    binned[c].data_ptr())
+        if rep:
+            pk_b.record(stream)
+        ctx.sync()
+    torch.cuda.synchronize()
+    bin_pack_ms = pk_a.elapsed_time(pk_b)
+    items = [(c, binned[c].data_ptr(), reads[c][0].data_ptr(), reads[c][1].data_ptr(), n_reads[c]) for c in range(C)]
 
     ev_pairs = []
 
@@ -195,7 +211,7 @@ def main():
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
-        hist.push_packed_device_multi(items, args.min_q)      # all contigs of the genome in ONE cov_accumulate launch
+        hist.push_binned_device_multi(items, args.min_q)      # all contigs of the genome in ONE cov_accumulate launch
         if timed:
             b.record(stream)
             ev_pairs.append((a, b))
@@ -239,7 +255,22 @@ def main():
             ev4.append((a, b))
     torch.cuda.synchronize()
     ms4 = sorted(a.elapsed_time(b) for a, b in ev4)
-    traffic = profiled_traffic("cov_accumulate<true, 0, false, 8, true>")
+    evp = []                                                 # ... and from the bin-size-agnostic packed records (cov_pack_record)
+    for kp in range(args.warmup + min(args.steps, 10)):
+        hist.reset()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        hist.push_packed_device_multi(items_packed, args.min_q)
+        b.record(stream)
+        if kp >= args.warmup:
+            evp.append((a, b))
+    torch.cuda.synchronize()
+    msp = sorted(a.elapsed_time(b) for a, b in evp)
+    hist.reset()                                             # (the headline layout's bins are the ones verified below)
+    hist.push_binned_device_multi(items, args.min_q)
+    hist.finish_all_device(out_all.data_ptr())
+    torch.cuda.synchronize()
+    traffic = profiled_traffic("cov_accumulate<true, 0, false, 8, 2>")
     if traffic is not None and world == 1:
         traffic *= 1.0     # (the profile was taken on this very workload: 600 M reads per launch)
     elif traffic is not None:
@@ -256,10 +287,13 @@ def main():
         "config": {"workload": "BASELINE configs[1]: coverage histogram, %d contigs x %d bp (%.2f Gb), %dx 150-bp sorted "
                                "stream, %d-bp bins, q>=%d filter; contigs split over the %d rank(s)" % (C_all, L, C_all * L / 1e9, args.depth, z, args.min_q, world),
                    "reads": job_reads, "bins": job_bins, "reads_rank0": total_reads, "bins_rank0": total_bins, "launches_per_step": 3,
-                   "layout": "8-byte packed records in HBM (reference_start int32 | span:24 mapq:6 unmapped:1 duplicate:1), what the ingest kernel writes; "
-                             "'four_array_layout' times the same launch from separate start/end/mapq/flag arrays (11 B/read), "
-                             "'pack_from_four_arrays_ms' the one-off conversion (tdt_cov_pack_device, outside the timed region)",
-                   "pack_from_four_arrays_ms": pack_ms,
+                   "layout": "8-byte BINNED records in HBM (first_bin << 2 | shape, filter byte, the two table indices of tiddit_coverage.pyx:53-63: "
+                             "csrc/tdt_common.h cov_bin_record) — what the ingest kernel writes when the reader is bound to this histogram "
+                             "(DeviceBamReader.bin_for): the division and the bin split are done once where the record is made.  "
+                             "'packed_layout' times the same launch from the bin-size-agnostic packed records (start | span:24 mapq:6 flags), "
+                             "'four_array_layout' from separate start/end/mapq/flag arrays (11 B/read), 'pack_*_ms' the one-off conversions from "
+                             "four arrays (outside the timed region)",
+                   "pack_binned_from_four_arrays_ms": bin_pack_ms, "pack_from_four_arrays_ms": pack_ms,
                    "arithmetic": "int64 accumulation of the reference's float32 quotients at 2^-S fixed point (exact), float64 bins out"},
         "reads_per_sec": job_reads / (t_cov / args.steps),
         "roofline": {"bound": "hbm", "kernel": "cov_accumulate", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -267,10 +301,13 @@ def main():
                      "frac_traffic": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": kern_ms,
                      "median_launch_ms": kern_all[len(kern_all) // 2], "min_launch_ms": kern_all[0],
                      "algorithmic_bytes_per_launch": alg_bytes_launch,
-                     "bytes_model": "8 B/read (packed record) + 8 B/bin: what this launch's input layout holds",
-                     "pack_from_four_arrays_ms": pack_ms,
-                     "from_four_arrays_incl_pack": {"ms": pack_ms + kern_ms, "frac": alg_bytes_4 / ((pack_ms + kern_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                    "note": "a caller holding SURVEY §8(d)'s four arrays pays the one-off packing pass first; the device ingest writes packed records itself"}},
+                     "bytes_model": "8 B/read (binned record) + 8 B/bin: what this launch's input layout holds",
+                     "pack_binned_from_four_arrays_ms": bin_pack_ms,
+                     "from_four_arrays_incl_pack": {"ms": bin_pack_ms + kern_ms, "frac": alg_bytes_4 / ((bin_pack_ms + kern_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                    "note": "a caller holding SURVEY §8(d)'s four arrays pays the one-off packing pass first; the device ingest writes the records itself"}},
+        "packed_layout": {"avg_launch_ms": sum(msp) / len(msp), "median_launch_ms": msp[len(msp) // 2], "min_launch_ms": msp[0],
+                          "algorithmic_bytes_per_launch": alg_bytes_launch, "bytes_model": "8 B/read (packed record) + 8 B/bin",
+                          "frac": alg_bytes_launch / (sum(msp) / len(msp) * 1e-3) / 1e9 / HBM_PEAK_GBS},
         "four_array_layout": {"avg_launch_ms": sum(ms4) / len(ms4), "median_launch_ms": ms4[len(ms4) // 2], "min_launch_ms": ms4[0],
                               "algorithmic_bytes_per_launch": alg_bytes_4, "bytes_model": "11 B/read (start i32, end i32, mapq u8, flag u16) + 8 B/bin",
                               "frac": alg_bytes_4 / (sum(ms4) / len(ms4) * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -345,12 +382,17 @@ def main():
         out_sv = torch.empty(hist_sv.total_bins(), dtype=torch.float64, device=dev)
         sv_ev = []
 
+        for c in range(C):                                   # the same buffers, re-made for the 50-bp histogram (the headline is done with them)
+            hist_sv.pack_binned_device(c, reads[c][0].data_ptr(), reads[c][1].data_ptr(), reads[c][2].data_ptr(), reads[c][3].data_ptr(), n_reads[c],
+                                       binned[c].data_ptr())
+        ctx.sync()
+
         def sv_step(timed):
             hist_sv.reset()
             if timed:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(stream)
-            hist_sv.push_packed_device_multi(items, qs_)
+            hist_sv.push_binned_device_multi(items, qs_)
             if timed:
                 b.record(stream)
                 sv_ev.append((a, b))
@@ -376,7 +418,7 @@ def main():
         sv_ms = sum(sv_all) / len(sv_all)
         sv_bytes = 8.0 * total_reads + 8.0 * sum(nb_sv)                 # packed records + bins (see the headline's bytes_model)
         sv_ach = sv_bytes / (sv_ms * 1e-3) / 1e9
-        sv_traffic = profiled_traffic("cov_accumulate<true, 1, false, 4, true>")
+        sv_traffic = profiled_traffic("cov_accumulate<true, 1, false, 4, 2>")
         if sv_traffic is not None:
             sv_traffic *= total_reads / float(job_reads)
         svres = {"metric": "cov bins/sec, SV flavour (50-bp bins, q>=5)", "value": C_all * -(-L // zs) / (t_sv / args.steps), "unit": "bins/s",
@@ -388,7 +430,7 @@ def main():
                               "frac_traffic": None if sv_traffic is None else sv_traffic / (sv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "avg_launch_ms": sv_ms, "median_launch_ms": sv_all[len(sv_all) // 2],
                               "min_launch_ms": sv_all[0], "algorithmic_bytes_per_launch": sv_bytes,
-                              "bytes_model": "8 B/read (packed record) + 8 B/bin"}}
+                              "bytes_model": "8 B/read (binned record) + 8 B/bin"}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             import oracle
             t_cpu = 0.0
@@ -407,7 +449,7 @@ def main():
         result["coverage_sv"] = svres
         del out_sv
         hist_sv.close()
-    del reads, outs, out_all, packed
+    del reads, outs, out_all, packed, binned
     hist.close()
     torch.cuda.empty_cache()
 
@@ -510,7 +552,36 @@ def main():
             nm = int(offm[-1])
             pam, pbm = pa[:nm].copy(), pb[:nm].copy()
             t_many, permm, labm = time_sort_dbscan(pam, pbm, offm)
-            sres = {"metric": "tdt_sort_dbscan from host int64 columns (what tiddit_cluster.main calls), signals/sec",
+            # what tiddit_cluster.main calls now: int32 columns built in pinned memory, no host pass, labels back in signal order (4 B each)
+            from tiddit_amd.hostutil import PinnedPool
+            pool = PinnedPool()
+
+            def time_columns(posA, posB, off, tag):
+                nn = len(posA)
+                a32, b32, l32 = pool.take(tag + "a", nn, np.int32), pool.take(tag + "b", nn, np.int32), pool.take(tag + "l", nn, np.int32)
+                a32[:], b32[:] = posA, posB
+                ts = []
+                for _ in range(1 + max(3, min(args.steps, 10))):
+                    t1 = time.perf_counter()
+                    _native.check(ctx.lib.tdt_cluster_columns(ctx.handle, _native.ptr(a32), _native.ptr(b32), nn, _native.ptr(off), len(off) - 1,
+                                                              500.0, 3, int(posA.max()), _native.ptr(l32), None, None))
+                    ts.append(time.perf_counter() - t1)
+                return sorted(ts[1:])[len(ts[1:]) // 2], l32.copy()
+            tc_one, lc1 = time_columns(pa, pb, np.array([0, n], dtype=np.int64), "one")
+            tc_many, lcm = time_columns(pam, pbm, offm, "many")
+            by1 = np.empty(n)
+            by1[perm1] = lab1
+            bym = np.empty(nm)
+            bym[permm] = labm
+            if not (np.array_equal(lc1.astype(np.float64), by1) and np.array_equal(lcm.astype(np.float64), bym)):
+                raise SystemExit("PARITY FAILURE: tdt_cluster_columns differs from tdt_sort_dbscan")
+            pool.close()
+            sres = {"metric": "tdt_sort_dbscan from host int64 columns (the round-2 call of tiddit_cluster.main), signals/sec",
+                    "cluster_columns": {"metric": "tdt_cluster_columns: pinned int32 columns in, int32 labels in signal order out (what tiddit_cluster.main calls)",
+                                        "one_bucket": {"signals": n, "ms": 1e3 * tc_one, "value": n / tc_one},
+                                        "many_buckets": {"signals": nm, "buckets": int(len(sizes)), "ms": 1e3 * tc_many, "value": nm / tc_many},
+                                        "note": "H2D 8 B/signal by DMA from the caller's pinned columns (posB rides behind the sort of the posA digits), radix sort on the significant "
+                                                "digits, both clustering passes, labels scattered to signal order on the device, D2H 4 B/signal; labels verified equal to tdt_sort_dbscan's"},
                     "one_bucket": {"signals": n, "ms": 1e3 * t_one, "value": n / t_one},
                     "many_buckets": {"signals": nm, "buckets": int(len(sizes)), "largest_bucket": int(sizes.max()), "ms": 1e3 * t_many, "value": nm / t_many},
                     "unit": "signals/s", "note": "includes the host passes over the two int64 columns (16 B/signal read), the H2D copy of their 32-bit offsets (8 B/signal), the device radix sort by (bucket, posA), both clustering passes and the D2H copy of order + int32 labels (8 B/signal)"}

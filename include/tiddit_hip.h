@@ -166,6 +166,14 @@ int tdt_sort_dbscan(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size
  * bucket into pieces at gaps >= eps needs to re-base the pieces' ids (DBSCAN.py:112-122 numbers extra sub-runs after ALL x-runs). */
 int tdt_sort_dbscan_ex(tdt_ctx *ctx, const int64_t *posA, const int64_t *posB, size_t n, const int64_t *bucket_off, int nb,
                        double eps, int m, uint32_t *perm_out, double *labels_out, int64_t *runs_out, int64_t *last_out);
+/* The same for 32-bit columns (alignment positions are below 2^31), without any host pass over the data: labels come back as int32 in
+ * SIGNAL order (labels_by_signal[i] = cluster of the i-th input signal, -1 = noise), 4 bytes per signal over PCIe.  max_pos bounds posA
+ * (e.g. the longest contig; <= 0: unknown) so that only the digits that can differ are sorted.  Columns and labels in pinned memory
+ * (tdt_host_alloc) are moved by DMA directly; pageable memory is staged.  runs_out / last_out as in tdt_sort_dbscan_ex (may be NULL). */
+int tdt_cluster_columns(tdt_ctx *ctx, const int32_t *posA, const int32_t *posB, size_t n, const int64_t *bucket_off, int nb, double eps, int m,
+                        int64_t max_pos, int32_t *labels_by_signal, int64_t *runs_out, int64_t *last_out);
+int tdt_host_alloc(size_t bytes, void **out);     /* pinned host memory */
+int tdt_host_free(void *p);
 
 /* ---- multi-GPU exchange (one process per GPU, RCCL over xGMI) ------------------------------------- *
  * The clustering path shards by (chrA,chrB) bucket (tiddit_cluster.pyx:140-154 keeps no cross-bucket state): every rank

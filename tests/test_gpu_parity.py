@@ -398,6 +398,54 @@ def test_sort_dbscan(ctx, nat):
         assert np.array_equal(lab[lo:hi], oracle.dbscan_main(d, 300, 3)), b
 
 
+def test_cluster_columns_int32_signal_order(ctx, nat):
+    """tdt_cluster_columns: int32 columns (pageable and pinned), labels in SIGNAL order, x-run counts and final ids per bucket — against
+    stable argsort + the oracle per bucket; negative coordinates, a max_pos bound, one bucket and many, duplicates in posA"""
+    from tiddit_amd import tiddit_cluster
+    from tiddit_amd.hostutil import PinnedPool
+    rng = np.random.default_rng(31)
+    pool = PinnedPool()
+    for nb, shift, bound in ((1, 0, 0), (40, 0, 0), (40, 0, 1), (7, -50_000, 0)):
+        x, y, off, _, _ = _bucketed_case(rng, nb)
+        x = (x // 5) * 5 + shift
+        y = y + shift
+        for b in range(nb):
+            p = rng.permutation(off[b + 1] - off[b])
+            x[off[b]:off[b + 1]] = x[off[b]:off[b + 1]][p]
+            y[off[b]:off[b + 1]] = y[off[b]:off[b + 1]][p]
+        n = len(x)
+        for pinned in (False, True):
+            if pinned:
+                xa, ya, lab = pool.take("a", n, np.int32), pool.take("b", n, np.int32), pool.take("l", n, np.int32)
+                xa[:], ya[:] = x, y
+            else:
+                xa, ya, lab = x.astype(np.int32), y.astype(np.int32), np.empty(n, dtype=np.int32)
+            runs, last = np.zeros(nb, dtype=np.int64), np.zeros(nb, dtype=np.int64)
+            mp = int(x.max()) if bound else 0
+            nat.check(ctx.lib.tdt_cluster_columns(ctx.handle, nat.ptr(xa), nat.ptr(ya), n, nat.ptr(off), nb, 300.0, 3, mp, nat.ptr(lab),
+                                                  nat.ptr(runs), nat.ptr(last)))
+            for b in range(nb):
+                lo, hi = int(off[b]), int(off[b + 1])
+                if lo == hi:
+                    assert runs[b] == 0 and last[b] == -1
+                    continue
+                order = np.argsort(x[lo:hi], kind="stable")
+                d = np.stack([x[lo:hi][order], y[lo:hi][order]], 1).astype(np.int64)
+                xl, xid = oracle.x_coordinate_clustering(d, 300, 3)
+                yl, yid = oracle.y_coordinate_clustering(d, 300, 3, xid, xl.copy())
+                want = np.empty(hi - lo)
+                want[order] = yl
+                assert np.array_equal(lab[lo:hi].astype(np.float64), want), (nb, shift, bound, pinned, b)
+                assert runs[b] == xid + 1 and last[b] == yid
+        # the Python entry point on the same buckets (int32 route) and on coordinates beyond int32 (int64 route)
+        buckets = [np.stack([x[off[b]:off[b + 1]], y[off[b]:off[b + 1]]], 1).astype(np.int64) for b in range(nb)]
+        a = tiddit_cluster.cluster_buckets(buckets, 300, 3)
+        big = [bk + (1 << 33) for bk in buckets]
+        c = tiddit_cluster.cluster_buckets(big, 300, 3)
+        assert all(np.array_equal(u, v) for u, v in zip(a, c))
+    pool.close()
+
+
 # ------------------------------------------------------------------------------------- cluster
 def _jsonable(c):
     if isinstance(c, dict):

@@ -64,6 +64,9 @@ SYMBOLS = {
     "tdt_dbscan_device": (_i, [_P, _P, _P, _sz, _P, _i, ctypes.c_uint64, _i, _i, _P, _P]),
     "tdt_sort_dbscan": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P]),
     "tdt_sort_dbscan_ex": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _P, _P, _P, _P]),
+    "tdt_cluster_columns": (_i, [_P, _P, _P, _sz, _P, _i, _dbl, _i, _i64, _P, _P, _P]),
+    "tdt_host_alloc": (_i, [_sz, _PP]),
+    "tdt_host_free": (_i, [_P]),
     "tdt_comm_unique_id": (_i, [_P]),
     "tdt_comm_init": (_i, [_P, _P, _i, _i, _PP]),
     "tdt_comm_destroy": (_i, [_P]),

@@ -1085,6 +1085,162 @@ extern "C" int tdt_sort_dbscan_ex(tdt_ctx *ctx, const int64_t *posA, const int64
 }
 
 
+// ---- the same, without host passes: 32-bit columns in (straight from the parsed signal tables), int32 labels in SIGNAL order out.
+// Keys are (bucket << 32 | posA biased to unsigned); only the digits that can differ are sorted (max_pos bounds posA, e.g. the longest
+// contig).  The posB column travels on the copy stream while the posA digits are being sorted; labels are scattered back to signal
+// order on the device, so 4 B/signal return.  Pinned caller memory (tdt_host_alloc) is read and written by DMA directly; pageable
+// memory goes through the context's pinned block.
+__global__ __launch_bounds__(DB_THREADS) void sc_make_keys(const int *__restrict__ a, int n, const int *__restrict__ boff, int nb,
+                                                           unsigned long long *__restrict__ key, unsigned *__restrict__ val) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    key[i] = ((unsigned long long)(unsigned)db_bucket(boff, nb, i) << 32) | ((unsigned)a[i] ^ 0x80000000u);   // order of signed values
+    val[i] = (unsigned)i;
+}
+
+__global__ __launch_bounds__(DB_THREADS) void sc_unpack(const unsigned long long *__restrict__ ksorted, const unsigned *__restrict__ vsorted,
+                                                        const int *__restrict__ b, int n, unsigned *__restrict__ xs, unsigned *__restrict__ ysrt) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i >= n) return;
+    xs[i] = (unsigned)ksorted[i];
+    ysrt[i] = (unsigned)b[vsorted[i]] ^ 0x80000000u;
+}
+
+__global__ __launch_bounds__(DB_THREADS) void sc_scatter_labels(const double *__restrict__ lab, const unsigned *__restrict__ perm, int n,
+                                                                int *__restrict__ out) {
+    const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    if (i < n) out[perm[i]] = (int)lab[i];
+}
+
+static bool sc_is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+extern "C" int tdt_cluster_columns(tdt_ctx *ctx, const int32_t *posA, const int32_t *posB, size_t n, const int64_t *bucket_off, int nb,
+                                   double eps, int m, int64_t max_pos, int32_t *labels_by_signal, int64_t *runs_out, int64_t *last_out) {
+    if (!ctx || nb < 1 || !bucket_off || (n && (!posA || !posB || !labels_by_signal))) {
+        tdt_set_error("tdt_cluster_columns: bad argument");
+        return TDT_E_ARG;
+    }
+    if (m < 2) {
+        tdt_set_error("tdt_cluster_columns: m must be >= 2");
+        return TDT_E_ARG;
+    }
+    if (n >= 0x7fffffffull || bucket_off[0] != 0 || bucket_off[nb] != (int64_t)n) {
+        tdt_set_error("tdt_cluster_columns: bad bucket offsets / n");
+        return TDT_E_ARG;
+    }
+    if (n == 0) {
+        for (int b = 0; b < nb; b++) {
+            if (runs_out) runs_out[b] = 0;
+            if (last_out) last_out[b] = -1;
+        }
+        return TDT_OK;
+    }
+    TDT_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream, cs = ctx->copy_stream;
+    const size_t szN4 = db_align(n * 4), szN8 = db_align(n * 8);
+    void *d = nullptr;
+    int rc = tdt_scratch(ctx, 5, 7 * szN4 + 3 * szN8 + db_align((size_t)(nb + 1) * 4) + db_align((size_t)nb * 16 + 64) + 256, &d);
+    if (rc) return rc;
+    char *p = (char *)d;
+    int *da = (int *)p; p += szN4;
+    int *db = (int *)p; p += szN4;
+    unsigned *dxs = (unsigned *)p; p += szN4;
+    unsigned *dys = (unsigned *)p; p += szN4;
+    unsigned *dv0 = (unsigned *)p; p += szN4;
+    unsigned *dv1 = (unsigned *)p; p += szN4;
+    int *dlab32 = (int *)p; p += szN4;
+    unsigned long long *dk = (unsigned long long *)p; p += szN8;
+    unsigned long long *dks = (unsigned long long *)p; p += szN8;
+    double *dlab = (double *)p; p += szN8;
+    int *dboff = (int *)p; p += db_align((size_t)(nb + 1) * 4);
+    long long *dcnt = (long long *)p;
+    // staging only for pageable caller memory
+    const bool pin_in = sc_is_pinned(posA) && sc_is_pinned(posB), pin_out = sc_is_pinned(labels_by_signal);
+    void *h = nullptr;
+    rc = tdt_pinned(ctx, 1, n * 8 + (size_t)(nb + 1) * 4 + 64, &h);
+    if (rc) return rc;
+    int *hboff = (int *)((char *)h + n * 8);
+    TDT_HIP(hipStreamSynchronize(st));                       // an earlier call may still be using the pinned block / the scratch
+    for (int b = 0; b <= nb; b++) hboff[b] = (int)bucket_off[b];
+    const int32_t *srcA = posA, *srcB = posB;
+    if (!pin_in) {
+        const int nth = (int)std::max<size_t>(1, std::min<size_t>((size_t)tdt_host_thread_count(), n / (1u << 18) + 1));
+        std::vector<std::thread> th;
+        auto part = [&](int t) {
+            const size_t i0 = n * (size_t)t / nth, i1 = n * (size_t)(t + 1) / nth;
+            memcpy((int *)h + i0, posA + i0, (i1 - i0) * 4);
+            memcpy((int *)h + n + i0, posB + i0, (i1 - i0) * 4);
+        };
+        for (int t = 1; t < nth; t++) th.emplace_back(part, t);
+        part(0);
+        for (auto &x : th) x.join();
+        srcA = (const int32_t *)h;
+        srcB = (const int32_t *)h + n;
+    }
+    TDT_HIP(hipMemcpyAsync(dboff, hboff, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
+    TDT_HIP(hipMemcpyAsync(da, srcA, n * 4, hipMemcpyHostToDevice, st));
+    TDT_HIP(hipMemcpyAsync(db, srcB, n * 4, hipMemcpyHostToDevice, cs));           // rides along with the sort of the posA digits
+    TDT_HIP(hipEventRecord(ctx->ev[3], cs));
+    const int blocks = ((int)n + DB_THREADS - 1) / DB_THREADS;
+    hipLaunchKernelGGL(sc_make_keys, dim3(blocks), dim3(DB_THREADS), 0, st, (const int *)da, (int)n, (const int *)dboff, nb, dk, dv0);
+    TDT_CHECK_LAUNCH();
+    const uint64_t span = max_pos > 0 && max_pos < 0x7fffffffll ? (uint64_t)max_pos + 1 : 0x80000000ull;
+    // biased keys: non-negative positions are 0x80000000 + pos, so the top bit is constant and only the span's digits differ
+    unsigned long long mask = (1ull << tdt_ceil_log2_u64(span)) - 1ull;
+    if (max_pos <= 0) mask = 0xffffffffull;                  // no bound given: all 32 bits (negative values included)
+    if (nb > 1) mask |= ((1ull << tdt_ceil_log2_u64((uint64_t)nb)) - 1ull) << 32;
+    unsigned long long *ks = nullptr;
+    unsigned *vs = nullptr;
+    rc = tdt_radix_sort_pairs(ctx, dk, dv0, dks, dv1, n, mask, &ks, &vs);
+    if (rc) return rc;
+    TDT_HIP(hipStreamWaitEvent(st, ctx->ev[3], 0));
+    hipLaunchKernelGGL(sc_unpack, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned long long *)ks, (const unsigned *)vs, (const int *)db, (int)n,
+                       dxs, dys);
+    TDT_CHECK_LAUNCH();
+    if (runs_out) {
+        rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 1, dlab, (int64_t *)dcnt);
+        if (rc) return rc;
+    }
+    rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, (runs_out || last_out) ? (int64_t *)(dcnt + nb) : nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sc_scatter_labels, dim3(blocks), dim3(DB_THREADS), 0, st, (const double *)dlab, (const unsigned *)vs, (int)n, dlab32);
+    TDT_CHECK_LAUNCH();
+    int *dst = pin_out ? labels_by_signal : (int *)h;
+    TDT_HIP(hipMemcpyAsync(dst, dlab32, n * 4, hipMemcpyDeviceToHost, st));
+    std::vector<long long> hc((size_t)nb * 2);
+    if (runs_out || last_out) TDT_HIP(hipMemcpyAsync(hc.data(), dcnt, (size_t)nb * 16, hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipStreamSynchronize(st));
+    if (!pin_out) memcpy(labels_by_signal, h, n * 4);
+    for (int b = 0; b < nb; b++) {
+        if (runs_out) runs_out[b] = hc[b] + 1;
+        if (last_out) last_out[b] = hc[nb + b];
+    }
+    return TDT_OK;
+}
+
+// pinned host memory for callers that build their columns in place (numpy arrays over it: tiddit_amd/hostutil.py)
+extern "C" int tdt_host_alloc(size_t bytes, void **out) {
+    if (!out) return TDT_E_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        tdt_set_error("tdt_host_alloc: pinned allocation of %zu bytes failed", bytes);
+        return TDT_E_NOMEM;
+    }
+    return TDT_OK;
+}
+extern "C" int tdt_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+    return TDT_OK;
+}
+
 #ifdef DT_PROF
 // variant builds only: per-phase cycles of dbt_tile summed over the workgroups of the last launch
 extern "C" int tdt_debug_dt_prof(unsigned long long *out16) {

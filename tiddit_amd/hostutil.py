@@ -15,3 +15,39 @@ def quiet_gc():
     finally:
         if was:
             gc.enable()
+
+
+class PinnedPool:
+    """Grow-only pinned host buffers (``tdt_host_alloc``) handed out as numpy arrays: columns built in them cross PCIe by DMA
+    without a staging copy.  One pool per purpose; ``take(name, n, dtype)`` returns a view of at least n elements that stays valid
+    until the next ``take`` of the same name with a larger size (or ``close``)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def take(self, name, n, dtype):
+        import ctypes
+        import numpy
+        from . import _native
+        dtype = numpy.dtype(dtype)
+        need = max(int(n), 1) * dtype.itemsize
+        ent = self._buf.get(name)
+        if ent is None or ent[1] < need:
+            lib = _native.load()
+            if ent is not None:
+                lib.tdt_host_free(ctypes.c_void_p(ent[0]))
+            cap = need + need // 4 + 4096
+            p = ctypes.c_void_p()
+            _native.check(lib.tdt_host_alloc(cap, ctypes.byref(p)))
+            ent = (p.value, cap)
+            self._buf[name] = ent
+        raw = (ctypes.c_char * ent[1]).from_address(ent[0])
+        return numpy.frombuffer(raw, dtype=dtype, count=int(n))
+
+    def close(self):
+        import ctypes
+        from . import _native
+        lib = _native.load()
+        for p, _ in self._buf.values():
+            lib.tdt_host_free(ctypes.c_void_p(p))
+        self._buf.clear()

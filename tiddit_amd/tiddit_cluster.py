@@ -101,11 +101,18 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
     return signals, positions
 
 
-def cluster_buckets(buckets, epsilon, m, ctx=None, counts=False):
-    """buckets: list of int64 [n_b, >=2] arrays (posA, posB, ...) in signal order.
+_POOL = None
+
+
+def cluster_buckets(buckets, epsilon, m, ctx=None, counts=False, max_pos=0):
+    """buckets: list of integer [n_b, >=2] arrays (posA, posB, ...) in signal order.
     -> list of float64 label arrays, labels[b][j] = cluster of the bucket's j-th signal
     (= DBSCAN.main on the bucket stably sorted by posA, mapped back; tiddit_cluster.pyx:152-160).
-    counts=True: -> (labels, x-runs per bucket, final cluster_id per bucket) (tdt_sort_dbscan_ex)."""
+    counts=True: -> (labels, x-runs per bucket, final cluster_id per bucket).
+    The columns go to the device as int32 built in pinned memory (``tdt_cluster_columns``: no host pass over them, labels come
+    back in signal order, 4 B each); max_pos (e.g. the longest contig) bounds posA so that only its significant digits are
+    sorted.  Coordinates outside int32 take the int64 entry point (``tdt_sort_dbscan_ex``)."""
+    global _POOL
     ctx = ctx or _native.default_context()
     sizes = [len(b) for b in buckets]
     n = int(sum(sizes))
@@ -116,21 +123,35 @@ def cluster_buckets(buckets, epsilon, m, ctx=None, counts=False):
     if n == 0:
         labs = [numpy.zeros(0) for _ in buckets]
         return (labs, runs, last) if counts else labs
-    def column(b, c):
-        a = numpy.asarray(b, dtype=numpy.int64)
-        return a[:, c] if len(a) else numpy.zeros(0, dtype=numpy.int64)
-    posA = numpy.ascontiguousarray(numpy.concatenate([column(b, 0) for b in buckets]))
-    posB = numpy.ascontiguousarray(numpy.concatenate([column(b, 1) for b in buckets]))
-    perm = numpy.empty(n, dtype=numpy.uint32)
-    lab = numpy.empty(n, dtype=numpy.float64)
-    if counts:
+    arrs = [numpy.asarray(b) for b in buckets]
+    for a in arrs:
+        if len(a) and not numpy.issubdtype(a.dtype, numpy.integer):
+            raise TypeError("signal positions must be integers (got dtype %s)" % a.dtype)
+    lo = min(int(a[:, :2].min()) for a in arrs if len(a))
+    hi = max(int(a[:, :2].max()) for a in arrs if len(a))
+    if lo >= -(1 << 31) and hi < (1 << 31):
+        if _POOL is None:
+            from .hostutil import PinnedPool
+            _POOL = PinnedPool()
+        posA, posB, lab32 = (_POOL.take(k, n, numpy.int32) for k in ("posA", "posB", "labels"))
+        for a, o in zip(arrs, off[:-1]):
+            if len(a):
+                posA[o:o + len(a)] = a[:, 0]
+                posB[o:o + len(a)] = a[:, 1]
+        bound = int(max_pos) if max_pos and lo >= 0 and hi <= max_pos else (hi if lo >= 0 else 0)
+        _native.check(ctx.lib.tdt_cluster_columns(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets), float(epsilon),
+                                                  int(m), bound, _native.ptr(lab32), _native.ptr(runs) if counts else None,
+                                                  _native.ptr(last) if counts else None))
+        by_signal = lab32.astype(numpy.float64)
+    else:
+        posA = numpy.ascontiguousarray(numpy.concatenate([a[:, 0] for a in arrs if len(a)]), dtype=numpy.int64)
+        posB = numpy.ascontiguousarray(numpy.concatenate([a[:, 1] for a in arrs if len(a)]), dtype=numpy.int64)
+        perm = numpy.empty(n, dtype=numpy.uint32)
+        lab = numpy.empty(n, dtype=numpy.float64)
         _native.check(ctx.lib.tdt_sort_dbscan_ex(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets),
                                                  float(epsilon), int(m), _native.ptr(perm), _native.ptr(lab), _native.ptr(runs), _native.ptr(last)))
-    else:
-        _native.check(ctx.lib.tdt_sort_dbscan(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(buckets),
-                                              float(epsilon), int(m), _native.ptr(perm), _native.ptr(lab)))
-    by_signal = numpy.empty(n, dtype=numpy.float64)
-    by_signal[perm] = lab
+        by_signal = numpy.empty(n, dtype=numpy.float64)
+        by_signal[perm] = lab
     labs = [by_signal[off[b]:off[b + 1]] for b in range(len(buckets))]
     return (labs, runs, last) if counts else labs
 
