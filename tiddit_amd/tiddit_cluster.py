@@ -66,8 +66,16 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
         return signals.setdefault(chrA, {}).setdefault(chrB, [])
 
     for sample in samples:
-        for line in open("{}_tiddit/discordants_{}.tab".format(prefix, sample)):
-            c = line.rstrip().split("\t")
+        disc_path, split_path = "{}_tiddit/discordants_{}.tab".format(prefix, sample), "{}_tiddit/splits_{}.tab".format(prefix, sample)
+        cached = None
+        if skip_assembly:
+            from . import tiddit_signal
+            cached = tiddit_signal.written_tables(disc_path, split_path)      # this process wrote these very files: their rows are still here
+        if cached is not None:
+            disc_iter = ([r[0], r[1], r[2]] + [str(v) for v in r[3]] for r in cached[0])     # the columns `line.split("\t")` would give
+        else:
+            disc_iter = (line.rstrip().split("\t") for line in open(disc_path))
+        for c in disc_iter:
             chrA, chrB = c[1], c[2]
             if contig_length[chrA] < min_contig or contig_length[chrB] < min_contig:
                 continue
@@ -84,8 +92,11 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
         if not skip_assembly:
             files.append(("A", "{}_tiddit/contigs_{}.tab"))
         for kind, pattern in files:
-            for line in open(pattern.format(prefix, sample)):
-                c = line.rstrip().split("\t")
+            if kind == "S" and cached is not None:
+                rows_iter = ([r[0], r[1], r[2]] + [str(v) for v in r[3]] for r in cached[1])
+            else:
+                rows_iter = (line.rstrip().split("\t") for line in open(pattern.format(prefix, sample)))
+            for c in rows_iter:
                 chrA, chrB = c[1], c[2]
                 if contig_length[chrA] < min_contig or contig_length[chrB] < min_contig:
                     continue

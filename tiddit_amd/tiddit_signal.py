@@ -355,6 +355,7 @@ _SCAN_CACHE = {}
 STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 SCAN_SECONDS = {}           # ... and of the last scan_signals() pass, by what the host waited for
 LAST_SEAM = {}              # seam offsets of the last sharded scan_signals() pass (dist.check_seams)
+WRITTEN_TABLES = {}         # (discordants path, splits path) -> stamps + the rows the last main() wrote there (tiddit_cluster reads them back)
 
 
 def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bin_size, skip_index, min_anchor_len, min_clip_len):
@@ -405,7 +406,9 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
             clip_fasta.append(path)
     print("Writing signals to file")
 
-    with open("{}_tiddit/discordants_{}.tab".format(prefix, sample_id), "w") as f:      # :298-318
+    disc_rows, split_rows = [], []        # the rows as written: tiddit_cluster in the same process takes them from here (no text re-parse)
+    disc_path, split_path = "{}_tiddit/discordants_{}.tab".format(prefix, sample_id), "{}_tiddit/splits_{}.tab".format(prefix, sample_id)
+    with open(disc_path, "w") as f:      # :298-318
         for chrA in data:
             for chrB in data[chrA]:
                 for fragment, reads in data[chrA][chrB].items():
@@ -419,11 +422,34 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                         first, second = second, first
                     out = first[0:-1] + second[0:-1]
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, out))))
-    with open("{}_tiddit/splits_{}.tab".format(prefix, sample_id), "w") as f:           # :320-326
+                    disc_rows.append((fragment, chrA, chrB, out))
+    with open(split_path, "w") as f:           # :320-326
         for chrA in splits:
             for chrB in splits[chrA]:
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
+                    split_rows.append((fragment, chrA, chrB, fields))
+    WRITTEN_TABLES.clear()
+    WRITTEN_TABLES[(os.path.abspath(disc_path), os.path.abspath(split_path))] = (_file_stamp(disc_path), _file_stamp(split_path), disc_rows, split_rows)
+
+
+def _file_stamp(path):
+    st = os.stat(path)
+    return (st.st_size, st.st_mtime_ns, st.st_ino)
+
+
+def written_tables(disc_path, split_path):
+    """the (discordant, split) rows of the last `main` of THIS process if the two files on disk are still the ones it wrote
+    (size, mtime, inode) — else None, and the caller parses the text.  Rows: (fragment, chrA, chrB, fields as written, not yet str)."""
+    ent = WRITTEN_TABLES.get((os.path.abspath(disc_path), os.path.abspath(split_path)))
+    if ent is None:
+        return None
+    try:
+        if _file_stamp(disc_path) != ent[0] or _file_stamp(split_path) != ent[1]:
+            return None
+    except OSError:
+        return None
+    return ent[2], ent[3]
 
 
 def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
