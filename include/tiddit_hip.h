@@ -336,6 +336,12 @@ int tdt_ingest_packed(tdt_ingest *g, const uint64_t **d_packed);
 /* From the next push on the reader writes BINNED records for `cov` (NULL: the generic packed records again) into the column
  * tdt_ingest_packed returns; *binned = 1 when it does (0: that histogram's bin size has no binned form, the column stays generic). */
 int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned);
+/* Keep the current batch beyond the next push: its device buffers (everything tdt_ingest_arrays / tdt_ingest_packed returned) move into
+ * *handle and stay valid until tdt_ingest_release; the reader continues with fresh buffers.  Used by `tiddit --sv` to scan the batches its
+ * library statistics were sampled from without reading and inflating them a second time. */
+typedef struct tdt_retained tdt_retained;
+int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle);
+int tdt_ingest_release(tdt_retained *handle);
 int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 

@@ -396,6 +396,63 @@ class DeviceBatch:
     def record(self, i):
         return RecordView(self, i)
 
+    def release(self):
+        """free the device buffers of a RETAINED batch (DeviceBamReader.retain); a no-op for ordinary batches"""
+        h = getattr(self, "_retained", None)
+        if h:
+            self._reader.ctx.lib.tdt_ingest_release(h)
+            self._retained = None
+            self._live = False
+
+
+class ScanCarry:
+    """What `tiddit --sv`'s library-statistics pass hands to the signal pass of the same file: the reader (positioned behind the
+    sampled batches), its batch iterator, the retained batches and the 50-bp histogram their coverage records were written for."""
+
+    def __init__(self, path, reader, iterator, batches, hist):
+        import os
+        self.path, self.stamp = os.path.abspath(path), os.stat(path).st_mtime_ns
+        self.reader, self.iterator, self.batches, self.hist = reader, iterator, batches, hist
+
+    def drop(self):
+        for b in self.batches:
+            b.release()
+        self.batches = []
+        try:
+            self.iterator.close()
+        except Exception:
+            pass
+        self.reader.close()
+        if self.hist is not None:
+            self.hist.close()
+
+
+_CARRY = None
+
+
+def set_carry(carry):
+    global _CARRY
+    if _CARRY is not None:
+        _CARRY.drop()
+    _CARRY = carry
+
+
+def take_carry(path, bin_size):
+    """the carry of `path` if the statistics pass of this process left one for that bin size (the caller owns it then), else None"""
+    global _CARRY
+    import os
+    c, _CARRY = _CARRY, None
+    if c is None:
+        return None
+    try:
+        ok = c.path == os.path.abspath(path) and c.stamp == os.stat(path).st_mtime_ns and c.hist.bin_size == int(bin_size)
+    except OSError:
+        ok = False
+    if not ok:
+        c.drop()
+        return None
+    return c
+
 
 class DeviceBamReader:
     """BAM reader whose inflate, record finding and field decode run on the MI355X (``tdt_ingest_*``): the file's BGZF
@@ -422,6 +479,7 @@ class DeviceBamReader:
         self._stop = threading.Event()
         fsize = os.path.getsize(path)
         self.shard = shard
+        self.retain = False              # True: every batch keeps its device buffers until DeviceBatch.release() (tdt_ingest_retain)
         self.first_off = self.next_off = None
         if shard is None:
             self._b_lo, self._b_hi, self._x_hi = 0, fsize, fsize
@@ -571,7 +629,7 @@ class DeviceBamReader:
             pending = spans.poll()                                  # span k+1 already read?  start its PCIe copy now: it overlaps
             if pending:                                             # the kernels of span k (never waits for the disk)
                 _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(pending[0]), pending[1]))
-            if prev is not None:
+            if prev is not None and not getattr(prev, "_retained", None):
                 prev._live = False
             n = ctypes.c_size_t(0)
             skip = (self._skip if self._b_lo == 0 else nothing) if first else 0
@@ -622,6 +680,10 @@ class DeviceBamReader:
                 _native.check(lib.tdt_copy_to_host(ctx.handle, _native.ptr(t), b.dev["tid"] + 4 * int(l), 4))
                 tids[j] = t[0]
             b.runs = [(int(t), int(l), int(h)) for t, l, h in zip(tids, lo, hi)]
+            if self.retain:
+                rh = ctypes.c_void_p()
+                _native.check(lib.tdt_ingest_retain(self._h, ctypes.byref(rh)))
+                b._retained = rh
             prev = b
             yield b
         c, hc = ctypes.c_size_t(0), ctypes.c_size_t(0)

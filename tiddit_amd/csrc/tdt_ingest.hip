@@ -625,6 +625,60 @@ extern "C" int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned) {
     return TDT_OK;
 }
 
+// Keep the current batch: its inflated records and field arrays move into a handle and stay valid until tdt_ingest_release, while the
+// reader goes on with fresh buffers (the partial record behind the batch is carried over).  `tiddit --sv` samples its library statistics
+// from the first reads of the file and then scans the whole file for signals: the sampled batches are retained and scanned where they
+// lie instead of being read and inflated a second time.
+struct tdt_retained {
+    tdt_ctx *ctx;
+    void *out, *soa;
+};
+extern "C" int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle) {
+    if (!g || !handle) {
+        tdt_set_error("tdt_ingest_retain: bad argument");
+        return TDT_E_ARG;
+    }
+    *handle = nullptr;
+    if (g->failed) {
+        tdt_set_error("tdt_ingest_retain: the stream is in an error state");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(g->ctx->device));
+    hipStream_t st = g->ctx->stream;
+    tdt_buf fresh;
+    if (g->out.cap) {
+        if (hipMalloc(&fresh.p, g->out.cap) != hipSuccess) {
+            (void)hipGetLastError();
+            tdt_set_error("tdt_ingest_retain: device allocation of %zu bytes failed", g->out.cap);
+            return TDT_E_NOMEM;
+        }
+        fresh.cap = g->out.cap;
+        if (g->carry) TDT_HIP(hipMemcpyAsync(fresh.p, (char *)g->out.p + g->tail_off, g->carry, hipMemcpyDeviceToDevice, st));
+        TDT_HIP(hipStreamSynchronize(st));
+    }
+    tdt_retained *r = new tdt_retained{g->ctx, g->out.p, g->soa.p};
+    g->out = fresh;
+    g->tail_off = 0;
+    g->soa = tdt_buf();
+    {
+        IngestOut fresh_o{};
+        fresh_o.bin = g->O.bin;
+        g->O = fresh_o;
+    }
+    g->n_records = 0;
+    *handle = r;
+    return TDT_OK;
+}
+extern "C" int tdt_ingest_release(tdt_retained *r) {
+    if (!r) return TDT_OK;
+    (void)hipSetDevice(r->ctx->device);
+    (void)hipStreamSynchronize(r->ctx->stream);
+    if (r->out) (void)hipFree(r->out);
+    if (r->soa) (void)hipFree(r->soa);
+    delete r;
+    return TDT_OK;
+}
+
 // the packed coverage records of the current batch (tdt_cov_push_packed_device_multi reads them; `end` serves its escapes)
 extern "C" int tdt_ingest_packed(tdt_ingest *g, const uint64_t **d_packed) {
     if (!g || !d_packed) {

@@ -212,7 +212,13 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     seam offsets are left in ``LAST_SEAM`` for dist.check_seams.  reduce_bins(hist) -> float64 array of ALL the histogram's
     bins (the sharded caller all-reduces them there); default: this process's own bins."""
     max_ins = int(max_ins)         # the reference's `int max_ins` argument truncates a float percentile (:147,:230; probed with Cython 3.2)
-    if shard is None:
+    carry = None
+    if shard is None and os.environ.get("TIDDIT_HOST_INGEST") != "1":
+        from . import bamio
+        carry = bamio.take_carry(bam_file_name, bin_size)      # the statistics pass of this process left its sampled batches in HBM
+    if carry is not None:
+        reader = carry.reader
+    elif shard is None:
         reader = open_bam(bam_file_name)
     else:
         from .bamio import DeviceBamReader
@@ -220,9 +226,13 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     header = reader.header
     names, lengths = reader.references, reader.lengths
     big = numpy.array([ln >= min_contig for ln in lengths], dtype=bool)
-    hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(names, lengths)], bin_size)
-    if hasattr(reader, "bin_for"):
-        reader.bin_for(hist)                     # the ingest kernel writes the coverage records for this bin size
+    if carry is not None:
+        hist = carry.hist                        # (the retained batches' coverage records were written for it)
+        hist.reset()
+    else:
+        hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(names, lengths)], bin_size)
+        if hasattr(reader, "bin_for"):
+            reader.bin_for(hist)                 # the ingest kernel writes the coverage records for this bin size
     data = {n: [] for n in names}
     splits = {n: [] for n in names}
     clips = {n: [] for n in names}
@@ -264,8 +274,18 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     pending = None
     t0 = time.time()
+    def all_batches():
+        if carry is None:
+            yield from reader.batches()
+            return
+        for b in carry.batches:                  # already in HBM
+            yield b
+            b.release()
+        carry.batches = []
+        yield from carry.iterator                # the rest of the file, from where the statistics pass stopped
+
     try:
-        for b in reader.batches():
+        for b in all_batches():
             t1 = time.time()
             T["ingest (inflate + decode, device)"] += t1 - t0
             if not isinstance(b, DeviceBatch):

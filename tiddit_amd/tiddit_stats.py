@@ -16,7 +16,19 @@ from .bamio import open_bam
 def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     library = {}
     t = time.time()
+    import os
+    from . import bamio
+    bamio.set_carry(None)
     reader = open_bam(bam_file_name)
+    # `tiddit --sv` scans the same file for signals next (tiddit_signal.main): the sampled batches stay in HBM with their coverage records
+    # written for the 50-bp histogram, and that pass starts from them instead of reading and inflating this part of the file again
+    carry = isinstance(reader, bamio.DeviceBamReader) and os.environ.get("TIDDIT_NO_CARRY") != "1"
+    kept, hist = [], None
+    if carry:
+        from . import tiddit_coverage
+        hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(reader.references, reader.lengths)], 50, ctx=reader.ctx)
+        reader.bin_for(hist)
+        reader.retain = True
     lib = _native.load()
     state = numpy.zeros(6, dtype=numpy.int64)
     chunks = []
@@ -32,8 +44,11 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     # one worker runs the loop of batch k (ctypes drops the GIL) while the device inflates and decodes batch k + 1; batches are
     # scanned in order, and the pass stops one batch after the loop has seen its n_reads-th read
     pending = None
+    batches = reader.batches()
     with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
-        for b in reader.batches():
+        for b in batches:
+            if carry:
+                kept.append(b)
             cols = [numpy.ascontiguousarray(getattr(b, k)) for k in ("tid", "pos", "mate_tid", "mate_pos", "tlen", "l_seq", "flag", "mapq")]
             if pending is not None:
                 pending.result()
@@ -43,7 +58,11 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
             pending = pool.submit(scan, cols, len(b))
         if pending is not None:
             pending.result()
-    reader.close()
+    if carry:
+        reader.retain = False
+        bamio.set_carry(bamio.ScanCarry(bam_file_name, reader, batches, kept, hist))
+    else:
+        reader.close()
     insert_size = numpy.concatenate(chunks) if chunks else numpy.zeros(0, dtype=numpy.int32)
     is_innie, is_outtie = int(state[3]), int(state[4])
     # numpy.average of the read lengths: an exact integer sum over an exact count
