@@ -691,16 +691,21 @@ def main():
         barrier()
         fsize = os.path.getsize(path)
 
+        timing_on, batch_times = [False], []
+        ingest_chunk = [448 << 20]                                # the reader's default span
+
         def ingest_pass():
             if use_dist:     # ONE file, byte-range shards, seam check, one exact all-reduce of the 500-bp bins (dist.coverage_sharded)
                 _, _, k = tdist.coverage_sharded(path, 500, 20, ctx=ctx)
                 tk = torch.tensor([k], dtype=torch.int64, device=dev)
                 dist.all_reduce(tk)
                 return int(tk.item())
-            r = bamio.DeviceBamReader(path, ctx=ctx)
+            r = bamio.DeviceBamReader(path, ctx=ctx, chunk=ingest_chunk[0])
+            r.collect_timing = timing_on[0]
             k = 0
             for b in r.batches():
                 k += len(b)
+            batch_times[:] = r.timings
             r.close()
             return k
 
@@ -722,6 +727,28 @@ def main():
                 "ms_per_step": 1e3 * t_in, "bam_MB_per_sec": fsize / t_in / 1e6,
                 "config": {"workload": "%d-record coordinate-sorted BAM (%.0f MB BGZF, zlib level 6, reads cut from a common reference), inflate + CRC32 + record decode on the device%s"
                                        % (nrec, fsize / 1e6, "" if world == 1 else "; the ONE file read as %d byte-range shards, 500-bp coverage bins all-reduced (exact)" % world)}}
+        if world == 1:
+            # where a pass spends its time, batch by batch (one extra pass with the stage timers on: they wait for every batch's decode kernel)
+            keys = ("read_ms", "wait_for_reader_ms", "block_table_ms", "h2d_ms", "inflate_crc_ms", "find_records_ms", "chain_check_ms", "decode_ms", "push_wall_ms")
+            ires["per_batch"] = {"note": "read_ms: positional reads of the span by the reader thread (overlaps the device work of the previous batch); "
+                                         "wait_for_reader_ms: what the consumer actually waited for it; h2d_ms: PCIe copy of the compressed span (prefetched = on the copy "
+                                         "stream behind the previous batch's kernels); inflate_crc / find_records / decode: kernels (HIP events); block_table / chain_check: host"}
+            for label, chunk in (("span_448MB", 448 << 20), ("span_64MB", 64 << 20)):
+                ingest_chunk[0] = chunk
+                ingest_pass()                                     # buffers of this span size
+                t1 = time.perf_counter()
+                ingest_pass()
+                t_plain = time.perf_counter() - t1
+                timing_on[0] = True
+                t1 = time.perf_counter()
+                ingest_pass()
+                t_timed = time.perf_counter() - t1
+                timing_on[0] = False
+                ires["per_batch"][label] = {"batches": len(batch_times), "pass_wall_ms": 1e3 * t_plain, "pass_wall_ms_with_timers": 1e3 * t_timed,
+                                            "sum_ms": {k: round(sum(b[k] for b in batch_times), 3) for k in keys},
+                                            "h2d_prefetched_batches": sum(1 for b in batch_times if b["h2d_prefetched"]),
+                                            "rows": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in b.items()} for b in batch_times[:8]]}
+            ingest_chunk[0] = 448 << 20
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             lib = ctx.lib
             threads = int(lib.tdt_host_threads(0))

@@ -339,6 +339,10 @@ int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned);
 /* Keep the current batch beyond the next push: its device buffers (everything tdt_ingest_arrays / tdt_ingest_packed returned) move into
  * *handle and stay valid until tdt_ingest_release; the reader continues with fresh buffers.  Used by `tiddit --sv` to scan the batches its
  * library statistics were sampled from without reading and inflating them a second time. */
+/* Where the last push spent its time (ms): [0] BGZF block table (host), [1] host-to-device copy of the span (the prefetch copy when
+ * [6] = 1: it ran on the copy stream behind the previous batch's kernels), [2] inflate + CRC kernels, [3] record-finding kernel,
+ * [4] chain check (host), [5] field decode + contig-edge kernels, [6] prefetched, [7] wall time of the push call. */
+int tdt_ingest_timing(tdt_ingest *g, double *out8);
 typedef struct tdt_retained tdt_retained;
 int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle);
 int tdt_ingest_release(tdt_retained *handle);

@@ -10,6 +10,7 @@ tests and synthetic configs.  Semantics follow the SAM/BAM spec v1; ``end`` is h
 """
 import ctypes
 import struct
+import time
 import zlib
 
 import numpy as np
@@ -480,6 +481,8 @@ class DeviceBamReader:
         fsize = os.path.getsize(path)
         self.shard = shard
         self.retain = False              # True: every batch keeps its device buffers until DeviceBatch.release() (tdt_ingest_retain)
+        self.collect_timing = os.environ.get("TIDDIT_INGEST_TIMING") == "1"     # per-batch stage times in self.timings (tdt_ingest_timing)
+        self.timings = []
         self.first_off = self.next_off = None
         if shard is None:
             self._b_lo, self._b_hi, self._x_hi = 0, fsize, fsize
@@ -535,6 +538,7 @@ class DeviceBamReader:
             try:
                 k, carry = 0, np.zeros(0, dtype=np.uint8)
                 eof = False
+                read_ms, got = 0.0, 0
                 while True:
                     buf = bufs[k % 4]
                     have = len(carry)
@@ -552,7 +556,9 @@ class DeviceBamReader:
                                     raise ValueError("short read")
                                 n += g
                             return n
+                        t_rd = time.perf_counter()
                         got = sum(pool.map(rd, range(0, want, piece)))
+                        read_ms = 1e3 * (time.perf_counter() - t_rd)
                         fo += got
                         have += got
                         eof = fo >= fsize
@@ -563,7 +569,7 @@ class DeviceBamReader:
                     if nb.value == 0:
                         raise ValueError("truncated BGZF block at end of file" if eof else "BGZF block larger than the read window")
                     carry = buf[consumed.value:have].copy()
-                    if not put((buf, consumed.value, fo - have)):
+                    if not put((buf, consumed.value, fo - have, read_ms if not eof or got else 0.0)):
                         return
                     k += 1
                 put(None)
@@ -622,10 +628,12 @@ class DeviceBamReader:
         prev, first = None, True
         pending = False                                             # False: span k+1 not looked at yet; None: end of the range
         while True:
+            t_wait = time.perf_counter()
             cur = spans.next() if pending is False else pending
+            wait_ms = 1e3 * (time.perf_counter() - t_wait)
             if cur is None:
                 break
-            buf, consumed, abs0 = cur
+            buf, consumed, abs0, read_ms = cur
             pending = spans.poll()                                  # span k+1 already read?  start its PCIe copy now: it overlaps
             if pending:                                             # the kernels of span k (never waits for the disk)
                 _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(pending[0]), pending[1]))
@@ -655,6 +663,12 @@ class DeviceBamReader:
             else:
                 _native.check(lib.tdt_ingest_push(self._h, _native.ptr(buf), consumed, skip, ctypes.byref(n)))
             first = False
+            if self.collect_timing:
+                tm = (ctypes.c_double * 8)()
+                _native.check(lib.tdt_ingest_timing(self._h, tm))
+                self.timings.append({"records": int(n.value), "bgzf_MB": consumed / 1e6, "read_ms": read_ms, "wait_for_reader_ms": wait_ms,
+                                     "block_table_ms": tm[0], "h2d_ms": tm[1], "inflate_crc_ms": tm[2], "find_records_ms": tm[3], "chain_check_ms": tm[4],
+                                     "decode_ms": tm[5], "h2d_prefetched": bool(tm[6]), "push_wall_ms": tm[7]})
             if not n.value:
                 continue
             ptrs = (ctypes.c_void_p * 14)()

@@ -249,7 +249,17 @@ struct tdt_ingest {
     bool edges_overflow = false;
     bool failed = false;                           // a push returned an error: the stream position is undefined from then on
     size_t host_chases = 0;                        // batches whose record chain had to be chased on the host
+    // where the last push spent its time (tdt_ingest_timing): HIP events on the launch / copy stream + host clocks
+    hipEvent_t tev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0-1 h2d, 1-2 inflate+crc, 2-3 find, 4-5 decode, 6-7 prefetch copy
+    double t_table_ms = 0, t_chain_ms = 0, t_wall_ms = 0;
+    bool t_prefetched = false, t_have_decode = false, t_have_pf = false;
 };
+
+static double ing_now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 
 static int ing_grow(tdt_ingest *g, tdt_buf &b, size_t bytes, bool keep = false) {
     if (b.cap >= bytes) return TDT_OK;
@@ -280,6 +290,11 @@ extern "C" int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out) {
     tdt_ingest *g = new tdt_ingest();
     g->ctx = ctx;
     g->n_ref = n_ref;
+    for (auto &e : g->tev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            (void)hipGetLastError();
+            e = nullptr;
+        }
     *out = g;
     return TDT_OK;
 }
@@ -291,6 +306,8 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
     (void)hipStreamSynchronize(g->ctx->copy_stream);
     for (auto &p : g->pf)
         if (p.done) (void)hipEventDestroy(p.done);
+    for (auto &e : g->tev)
+        if (e) (void)hipEventDestroy(e);
     for (tdt_buf *b : {&g->comp, &g->pf[0].buf, &g->pf[1].buf, &g->table, &g->out, &g->seg, &g->soa})
         if (b->p) (void)hipFree(b->p);
     if (g->pin.p) (void)hipHostFree(g->pin.p);
@@ -313,8 +330,11 @@ extern "C" int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t le
     int rc = ing_grow(g, slot->buf, comp_pad);
     if (rc) return rc;
     if (!slot->done) TDT_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+    if (g->tev[6]) (void)hipEventRecord(g->tev[6], ctx->copy_stream);
     TDT_HIP(hipMemcpyAsync(slot->buf.p, comp, len, hipMemcpyHostToDevice, ctx->copy_stream));
     TDT_HIP(hipMemsetAsync((char *)slot->buf.p + len, 0, comp_pad - len, ctx->copy_stream));
+    if (g->tev[7]) (void)hipEventRecord(g->tev[7], ctx->copy_stream);
+    g->t_have_pf = g->tev[6] && g->tev[7];
     TDT_HIP(hipEventRecord(slot->done, ctx->copy_stream));
     slot->host = comp;
     slot->len = len;
@@ -338,7 +358,9 @@ extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_
         tdt_set_error("tdt_ingest_push: an earlier push on this stream failed; create a new tdt_ingest");
         return TDT_E_ARG;
     }
+    const double t0 = ing_now_ms();
     const int rc = ing_push(g, comp, len, skip, own_bytes, n_records, first_off, next_off);
+    g->t_wall_ms = ing_now_ms() - t0;
     if (rc != TDT_OK) g->failed = true;
     return rc;
 }
@@ -358,8 +380,13 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     hipStream_t st = ctx->stream;
     std::vector<BzDesc> blocks;
     size_t produced = 0;
+    const double t_begin = ing_now_ms();
+    g->t_have_decode = false;
+    g->t_prefetched = false;
     int rc = tdt_bz_block_table(comp, len, blocks, &produced);
     if (rc) return rc;
+    g->t_table_ms = ing_now_ms() - t_begin;
+    g->t_chain_ms = 0;
     const size_t carry = g->carry;
     const size_t T = carry + produced;
     if (T >= 0xfffffff0ull) {
@@ -385,18 +412,22 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         tdt_ingest::Prefetch *hit = nullptr;
         for (auto &p : g->pf)
             if (p.host == comp && p.len == len && p.buf.cap >= comp_pad) hit = &p;
+        if (g->tev[0]) (void)hipEventRecord(g->tev[0], st);
         if (hit) {
             std::swap(g->comp, hit->buf);                         // the span is already on the device (copy stream)
             TDT_HIP(hipStreamWaitEvent(st, hit->done, 0));
             hit->host = nullptr;
+            g->t_prefetched = true;
         } else {
             TDT_HIP(hipMemcpyAsync(g->comp.p, comp, len, hipMemcpyHostToDevice, st));
             TDT_HIP(hipMemsetAsync((char *)g->comp.p + len, 0, comp_pad - len, st));
         }
+        if (g->tev[1]) (void)hipEventRecord(g->tev[1], st);
         unsigned char *d_comp = (unsigned char *)g->comp.p;
         TDT_HIP(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
         rc = tdt_bz_launch(ctx, d_comp, d_blocks, nb, d_out, true, d_status, d_summary);
         if (rc) return rc;
+        if (g->tev[2]) (void)hipEventRecord(g->tev[2], st);
         unsigned summary[2] = {0, 0};
         TDT_HIP(hipMemcpyAsync(summary, d_summary, 8, hipMemcpyDeviceToHost, st));
         TDT_HIP(hipStreamSynchronize(st));
@@ -444,8 +475,10 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     hipLaunchKernelGGL(bam_find_records, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, unknown_start ? -1ll : (long long)skip,
                        (long long)limit, g->n_ref, nseg, d_first, d_exit, d_count);
     TDT_CHECK_LAUNCH();
+    if (g->tev[3]) (void)hipEventRecord(g->tev[3], st);
     TDT_HIP(hipMemcpyAsync(h_first, d_first, 3 * segb, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipStreamSynchronize(st));
+    const double t_chain0 = ing_now_ms();
     for (int s = 0; s < nseg; s++) h_base[s] = ING_NONE;
     size_t cur = skip, n = 0;
     bool confirmed = getenv("TIDDIT_INGEST_HOST_CHASE") == nullptr;
@@ -564,8 +597,12 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
             TDT_HIP(hipMemcpyAsync(d_first, h_first, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
             TDT_HIP(hipMemcpyAsync(d_count, h_count, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
         }
+        g->t_chain_ms = ing_now_ms() - t_chain0;
+        if (g->tev[4]) (void)hipEventRecord(g->tev[4], st);
         hipLaunchKernelGGL(bam_decode_fields, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, nseg, d_first, d_base, d_count, O);
         TDT_CHECK_LAUNCH();
+        if (g->tev[5]) (void)hipEventRecord(g->tev[5], st);
+        g->t_have_decode = g->tev[4] && g->tev[5];
         TDT_HIP(hipMemsetAsync(d_edges + 1023, 0, 4, st));
         hipLaunchKernelGGL(bam_tid_edges, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, O.tid, N, d_edges, 1023u, d_edges + 1023);
         TDT_CHECK_LAUNCH();
@@ -676,6 +713,36 @@ extern "C" int tdt_ingest_release(tdt_retained *r) {
     if (r->out) (void)hipFree(r->out);
     if (r->soa) (void)hipFree(r->soa);
     delete r;
+    return TDT_OK;
+}
+
+// Where the last push spent its time, in milliseconds: out[0] block table (host), out[1] host-to-device copy of the compressed span
+// (on the launch stream; of the prefetch on the copy stream when out[6] = 1, then it ran behind the previous batch's kernels),
+// out[2] inflate + CRC kernels, out[3] record finding kernel, out[4] chain check on the host, out[5] field decode + contig edges
+// kernels, out[6] the span had been prefetched, out[7] wall time of the push call.  Waits for the decode kernel of that push.
+extern "C" int tdt_ingest_timing(tdt_ingest *g, double *out8) {
+    if (!g || !out8) {
+        tdt_set_error("tdt_ingest_timing: bad argument");
+        return TDT_E_ARG;
+    }
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    auto span = [&](int a, int b) -> double {
+        float ms = 0;
+        if (!g->tev[a] || !g->tev[b]) return 0;
+        if (hipEventSynchronize(g->tev[b]) != hipSuccess || hipEventElapsedTime(&ms, g->tev[a], g->tev[b]) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        return ms;
+    };
+    out8[0] = g->t_table_ms;
+    out8[1] = g->t_prefetched ? (g->t_have_pf ? span(6, 7) : 0) : span(0, 1);
+    out8[2] = span(1, 2);
+    out8[3] = span(2, 3);
+    out8[4] = g->t_chain_ms;
+    out8[5] = g->t_have_decode ? span(4, 5) : 0;
+    out8[6] = g->t_prefetched ? 1 : 0;
+    out8[7] = g->t_wall_ms;
     return TDT_OK;
 }
 
