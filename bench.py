@@ -137,15 +137,34 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TIDDIT_BENCH_SHARE_GPU=1 (tests only): the N ranks share GPU 0 and exchange over gloo — the N-rank code paths of every section on a
+    # one-GPU box.  Production: one rank per GPU, backend "nccl" (= RCCL on ROCm).
+    share = os.environ.get("TIDDIT_BENCH_SHARE_GPU") == "1"
+    gpu = 0 if share else local_rank
+    if share:
+        os.environ["TIDDIT_HIP_DEVICE"] = "0"
+        os.environ["TIDDIT_DIST_BACKEND"] = "gloo"
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("TIDDIT_BENCH_FORCE_DIST") == "1")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # backend "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # backend "nccl" is RCCL on ROCm
+    wire = torch.device("cpu") if share else dev
+
+    def rank_max(x):
+        """slowest rank's time"""
+        if not use_dist:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=wire)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     from tiddit_amd import _native, dist as tdist, synth, tiddit_coverage  # noqa: F401
-    ctx = _native.default_context(local_rank)
+    ctx = _native.default_context(gpu)
     stream = torch.cuda.Stream(device=dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -229,10 +248,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t_cov = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([t_cov], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_cov = float(tt.item())
+    t_cov = rank_max(t_cov)
     ms_per_step = 1e3 * t_cov / args.steps
     kern_all = sorted(a.elapsed_time(b) for a, b in ev_pairs)
     kern_ms = sum(kern_all) / len(kern_all)                                      # avg cov_accumulate launch (whole genome)
@@ -410,10 +426,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         t_sv = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([t_sv], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_sv = float(tt.item())
+        t_sv = rank_max(t_sv)
         sv_all = sorted(a.elapsed_time(b) for a, b in sv_ev)
         sv_ms = sum(sv_all) / len(sv_all)
         sv_bytes = 8.0 * total_reads + 8.0 * sum(nb_sv)                 # packed records + bins (see the headline's bytes_model)
@@ -455,7 +468,7 @@ def main():
 
     # ---------------------------------------------------------------- clustering, ONE bucket list shared by the ranks (configs[4]'s shape)
     if not args.no_dbscan:
-        result["dbscan_shared"] = dbscan_shared(args, ctx, stream, dev, rank, world, use_dist, barrier)
+        result["dbscan_shared"] = dbscan_shared(args, ctx, stream, dev, rank, world, use_dist, barrier, wire, rank_max)
 
     # ---------------------------------------------------------------- clustering (configs[2]): one chr pair, one GPU
     if not args.no_dbscan and world == 1:
@@ -493,10 +506,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         t_db = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([t_db], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_db = float(tt.item())
+        t_db = rank_max(t_db)
         k_ms = sum(a.elapsed_time(b) for a, b in dev_ms) / len(dev_ms)
         db_ach = 16.0 * n / (k_ms * 1e-3) / 1e9
         t1_, t2_ = profiled_traffic("dbt_tile<true, false, false>"), profiled_traffic("dbt_finish1")
@@ -648,10 +658,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         t_gc = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([t_gc], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_gc = float(tt.item())
+        t_gc = rank_max(t_gc)
         g_ms = sum(a.elapsed_time(b) for a, b in gev) / len(gev)
         g_ach = (G + G / 50.0) / (g_ms * 1e-3) / 1e9
         g_traffic = profiled_traffic("gc_small_bins")
@@ -697,7 +704,7 @@ def main():
         def ingest_pass():
             if use_dist:     # ONE file, byte-range shards, seam check, one exact all-reduce of the 500-bp bins (dist.coverage_sharded)
                 _, _, k = tdist.coverage_sharded(path, 500, 20, ctx=ctx)
-                tk = torch.tensor([k], dtype=torch.int64, device=dev)
+                tk = torch.tensor([k], dtype=torch.int64, device=wire)
                 dist.all_reduce(tk)
                 return int(tk.item())
             r = bamio.DeviceBamReader(path, ctx=ctx, chunk=ingest_chunk[0])
@@ -719,10 +726,7 @@ def main():
         ctx.sync()
         barrier()
         t_in = (time.perf_counter() - t0) / isteps
-        if use_dist:
-            tt = torch.tensor([t_in], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_in = float(tt.item())
+        t_in = rank_max(t_in)
         ires = {"metric": "BAM records decoded/sec (file -> packed arrays in HBM)", "value": nrec / t_in, "unit": "records/s",
                 "ms_per_step": 1e3 * t_in, "bam_MB_per_sec": fsize / t_in / 1e6,
                 "config": {"workload": "%d-record coordinate-sorted BAM (%.0f MB BGZF, zlib level 6, reads cut from a common reference), inflate + CRC32 + record decode on the device%s"
@@ -873,7 +877,7 @@ def shared_step(bucket_sizes, cluster_local, use_dist, group=None):
     return tdist.cluster_buckets_distributed(bucket_sizes, cluster_local, group, flat=True)
 
 
-def dbscan_shared(args, ctx, stream, dev, rank, world, use_dist, barrier):
+def dbscan_shared(args, ctx, stream, dev, rank, world, use_dist, barrier, wire=None, rank_max=lambda x: x):
     import ctypes
     import torch
     import torch.distributed as dist
@@ -904,7 +908,7 @@ def dbscan_shared(args, ctx, stream, dev, rank, world, use_dist, barrier):
             b.record(stream)
             ev.append((a, b))
             stream.synchronize()
-        return lab[:nmine]
+        return lab[:nmine] if wire is None or wire == dev else lab[:nmine].to(wire)
 
     for _ in range(args.warmup):
         shared_step(sizes, cluster_local, use_dist)
@@ -918,11 +922,7 @@ def dbscan_shared(args, ctx, stream, dev, rank, world, use_dist, barrier):
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    t = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([t], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t = float(tt.item())
+    t = rank_max(time.perf_counter() - t0)
     labels = tdist.split_gathered(sizes, owned_all, parts)
     k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
     res = {"metric": "signals clustered/sec, one shared list of (chrA,chrB) buckets", "value": total / (t / args.steps), "unit": "signals/s",
