@@ -1,7 +1,7 @@
 """BASELINE configs[3] on the GPU: `tiddit --sv --skip_assembly` end to end on a WGS-shaped synthetic BAM (24 chromosomes with
 GRCh38's relative lengths + chrM + two scaffolds below --min_contig, 30x, 150-bp pairs, planted DEL/DUP/INV/BND with SA-tagged
-split reads; tests/sv_e2e_common.py regenerates it from the fixture's seeds).  Everything the run leaves behind is compared with
-tests/golden/sv_e2e.json: signal tables and clip FASTA (restatement of tiddit_signal.pyx), 50-bp coverage of every contig,
+split reads; tests/sv_e2e_common.py regenerates it from the fixture's seeds) at 3 Mb, 24 Mb and 240 Mb — the last one is the very file
+bench.py's sv_e2e section times (48 M records, 4.3 GB).  Everything the run leaves behind is compared with tests/golden/sv_e2e*.json: signal tables and clip FASTA (restatement of tiddit_signal.pyx), 50-bp coverage of every contig,
 GC bins, the ploidy table (compiled tiddit_coverage_analysis) and the ENTIRE candidates dictionary of the compiled
 tiddit_cluster.main — keys, breakpoints, regions, insertion order."""
 import hashlib
@@ -21,7 +21,7 @@ def h(t):
     return hashlib.sha256(t.encode()).hexdigest()
 
 
-@pytest.fixture(scope="module", params=["sv_e2e_small.json", "sv_e2e.json"])
+@pytest.fixture(scope="module", params=["sv_e2e_small.json", "sv_e2e.json", "sv_e2e_large.json"])   # 3 Mb, 24 Mb, 240 Mb (the bench's file)
 def run(request, golden_dir, tmp_path_factory):
     from tiddit_amd import __main__ as cli
     fx = load_fixture(golden_dir, request.param)

@@ -569,6 +569,9 @@ class DeviceBamReader:
                     if nb.value == 0:
                         raise ValueError("truncated BGZF block at end of file" if eof else "BGZF block larger than the read window")
                     carry = buf[consumed.value:have].copy()
+                    # the PCIe copy of this span starts now, on the copy stream, behind whatever the device is doing for the span before it
+                    # (the push of exactly this (pointer, length) then finds it on the device)
+                    _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(buf), consumed.value))
                     if not put((buf, consumed.value, fo - have, read_ms if not eof or got else 0.0)):
                         return
                     k += 1
@@ -634,9 +637,7 @@ class DeviceBamReader:
             if cur is None:
                 break
             buf, consumed, abs0, read_ms = cur
-            pending = spans.poll()                                  # span k+1 already read?  start its PCIe copy now: it overlaps
-            if pending:                                             # the kernels of span k (never waits for the disk)
-                _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(pending[0]), pending[1]))
+            pending = spans.poll()                                  # span k+1 already read?  (its PCIe copy was started by the reader thread)
             if prev is not None and not getattr(prev, "_retained", None):
                 prev._live = False
             n = ctypes.c_size_t(0)

@@ -13,6 +13,7 @@
 //   4. bam_decode_fields: one lane per accepted segment re-walks its records and writes the same thirteen arrays as
 //      tdt_bam_decode (bam_endpos for `end`, the SA:Z offset, first/last CIGAR op, ...).
 #include "tdt_common.h"
+#include <mutex>
 
 #include <algorithm>
 
@@ -239,7 +240,10 @@ struct tdt_ingest {
         const uint8_t *host = nullptr;             // what the slot holds: host pointer / length of the span (null = free)
         size_t len = 0;
         hipEvent_t done = nullptr;
-    } pf[2];
+        hipEvent_t t0 = nullptr, t1 = nullptr;     // around the copy, for tdt_ingest_timing
+    } pf[3];                                       // spans the reader can be ahead by: queued, held back by the full queue, taken but not pushed yet
+    std::mutex pf_mu;                              // the slots are filled by the reader thread (tdt_ingest_prefetch) and emptied by the pushing one
+    hipEvent_t hit_t0 = nullptr, hit_t1 = nullptr; // the timing events of the slot the last push consumed
     tdt_buf pin;                                   // pinned staging for the segment table / edges
     size_t carry = 0, tail_off = 0;                // bytes of the partial record at out[tail_off..), moved to the front by the next push
     size_t out_len = 0;                            // carry + inflated bytes of the current batch
@@ -252,7 +256,7 @@ struct tdt_ingest {
     // where the last push spent its time (tdt_ingest_timing): HIP events on the launch / copy stream + host clocks
     hipEvent_t tev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0-1 h2d, 1-2 inflate+crc, 2-3 find, 4-5 decode, 6-7 prefetch copy
     double t_table_ms = 0, t_chain_ms = 0, t_wall_ms = 0;
-    bool t_prefetched = false, t_have_decode = false, t_have_pf = false;
+    bool t_prefetched = false, t_have_decode = false;
 };
 
 static double ing_now_ms() {
@@ -304,11 +308,16 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipStreamSynchronize(g->ctx->copy_stream);
-    for (auto &p : g->pf)
+    for (auto &p : g->pf) {
         if (p.done) (void)hipEventDestroy(p.done);
+        if (p.t0) (void)hipEventDestroy(p.t0);
+        if (p.t1) (void)hipEventDestroy(p.t1);
+    }
+    if (g->hit_t0) (void)hipEventDestroy(g->hit_t0);
+    if (g->hit_t1) (void)hipEventDestroy(g->hit_t1);
     for (auto &e : g->tev)
         if (e) (void)hipEventDestroy(e);
-    for (tdt_buf *b : {&g->comp, &g->pf[0].buf, &g->pf[1].buf, &g->table, &g->out, &g->seg, &g->soa})
+    for (tdt_buf *b : {&g->comp, &g->pf[0].buf, &g->pf[1].buf, &g->pf[2].buf, &g->table, &g->out, &g->seg, &g->soa})
         if (b->p) (void)hipFree(b->p);
     if (g->pin.p) (void)hipHostFree(g->pin.p);
     delete g;
@@ -325,16 +334,39 @@ extern "C" int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t le
     tdt_ctx *ctx = g->ctx;
     TDT_HIP(hipSetDevice(ctx->device));
     const size_t comp_pad = (len + 4096 + 255) & ~(size_t)255;
-    tdt_ingest::Prefetch *slot = g->pf[0].host ? &g->pf[1] : &g->pf[0];   // a free slot (a second pending one is overwritten)
+    std::lock_guard<std::mutex> lock(g->pf_mu);        // (may be called from the thread that reads the file while another one pushes)
+    tdt_ingest::Prefetch *slot = nullptr;
+    for (auto &p : g->pf)
+        if (!p.host) {
+            slot = &p;
+            break;
+        }
+    if (!slot) return TDT_OK;                            // every slot holds a span that has not been pushed yet: this one is copied by its push
     // (a buffer swapped into a slot by an earlier push is free: that push waited for its inflate kernel before returning)
-    int rc = ing_grow(g, slot->buf, comp_pad);
-    if (rc) return rc;
-    if (!slot->done) TDT_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
-    if (g->tev[6]) (void)hipEventRecord(g->tev[6], ctx->copy_stream);
+    if (slot->buf.cap < comp_pad) {                     // grow without touching the launch stream (ing_grow's copy path is not needed here)
+        void *np_ = nullptr;
+        const size_t cap = comp_pad + comp_pad / 4 + 4096;
+        if (hipMalloc(&np_, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            tdt_set_error("tdt_ingest_prefetch: device allocation of %zu bytes failed", cap);
+            return TDT_E_NOMEM;
+        }
+        if (slot->buf.p) {
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            (void)hipFree(slot->buf.p);
+        }
+        slot->buf.p = np_;
+        slot->buf.cap = cap;
+    }
+    if (!slot->done) {
+        TDT_HIP(hipEventCreateWithFlags(&slot->done, hipEventDisableTiming));
+        (void)hipEventCreate(&slot->t0);
+        (void)hipEventCreate(&slot->t1);
+    }
+    if (slot->t0) (void)hipEventRecord(slot->t0, ctx->copy_stream);
     TDT_HIP(hipMemcpyAsync(slot->buf.p, comp, len, hipMemcpyHostToDevice, ctx->copy_stream));
     TDT_HIP(hipMemsetAsync((char *)slot->buf.p + len, 0, comp_pad - len, ctx->copy_stream));
-    if (g->tev[7]) (void)hipEventRecord(g->tev[7], ctx->copy_stream);
-    g->t_have_pf = g->tev[6] && g->tev[7];
+    if (slot->t1) (void)hipEventRecord(slot->t1, ctx->copy_stream);
     TDT_HIP(hipEventRecord(slot->done, ctx->copy_stream));
     slot->host = comp;
     slot->len = len;
@@ -409,16 +441,26 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         if (rc) return rc;
         BzDesc *d_blocks = (BzDesc *)g->table.p;
         unsigned *d_status = (unsigned *)((char *)g->table.p + tab), *d_summary = (unsigned *)((char *)d_status + stb);
-        tdt_ingest::Prefetch *hit = nullptr;
-        for (auto &p : g->pf)
-            if (p.host == comp && p.len == len && p.buf.cap >= comp_pad) hit = &p;
         if (g->tev[0]) (void)hipEventRecord(g->tev[0], st);
-        if (hit) {
-            std::swap(g->comp, hit->buf);                         // the span is already on the device (copy stream)
-            TDT_HIP(hipStreamWaitEvent(st, hit->done, 0));
-            hit->host = nullptr;
-            g->t_prefetched = true;
-        } else {
+        bool was_hit = false;
+        {
+            std::lock_guard<std::mutex> lock(g->pf_mu);
+            tdt_ingest::Prefetch *hit = nullptr;
+            for (auto &p : g->pf)
+                if (p.host == comp && p.len == len && p.buf.cap >= comp_pad) hit = &p;
+            if (hit) {
+                std::swap(g->comp, hit->buf);                     // the span is already on the device (copy stream)
+                TDT_HIP(hipStreamWaitEvent(st, hit->done, 0));
+                std::swap(g->hit_t0, hit->t0);                    // (the slot gets the previous pair back: events are reused)
+                std::swap(g->hit_t1, hit->t1);
+                if (!hit->t0) (void)hipEventCreate(&hit->t0);
+                if (!hit->t1) (void)hipEventCreate(&hit->t1);
+                hit->host = nullptr;
+                g->t_prefetched = true;
+                was_hit = true;
+            }
+        }
+        if (!was_hit) {
             TDT_HIP(hipMemcpyAsync(g->comp.p, comp, len, hipMemcpyHostToDevice, st));
             TDT_HIP(hipMemsetAsync((char *)g->comp.p + len, 0, comp_pad - len, st));
         }
@@ -736,7 +778,13 @@ extern "C" int tdt_ingest_timing(tdt_ingest *g, double *out8) {
         return ms;
     };
     out8[0] = g->t_table_ms;
-    out8[1] = g->t_prefetched ? (g->t_have_pf ? span(6, 7) : 0) : span(0, 1);
+    if (g->t_prefetched) {
+        float ms = 0;
+        if (g->hit_t0 && g->hit_t1 && hipEventSynchronize(g->hit_t1) == hipSuccess && hipEventElapsedTime(&ms, g->hit_t0, g->hit_t1) == hipSuccess) out8[1] = ms;
+        else (void)hipGetLastError();
+    } else {
+        out8[1] = span(0, 1);
+    }
     out8[2] = span(1, 2);
     out8[3] = span(2, 3);
     out8[4] = g->t_chain_ms;
