@@ -122,6 +122,7 @@ def parse():
     ap.add_argument("--no-next", action="store_true", help="skip the small next-row kernels (masked medians, regional evidence counts)")
     ap.add_argument("--no-sv-e2e", action="store_true", help="skip BASELINE configs[3]: tiddit --sv --skip_assembly on a WGS-shaped synthetic BAM")
     ap.add_argument("--sv-mb", type=int, default=240, help="genome size (Mb, 24 chromosomes with GRCh38's relative lengths, 30x 150-bp pairs) of that BAM")
+    ap.add_argument("--sv-cpu-full-mb", type=int, default=300, help="up to this genome size the CPU legs of sv_e2e run on the whole file, above it on a bounded sample of contigs")
     ap.add_argument("--ingest-mb", type=int, default=8, help="Mb per contig (2 contigs, 30x, 100-bp reads) of the BAM the ingest pass reads")
     return ap.parse_args()
 
@@ -992,41 +993,124 @@ def sv_e2e(args, ctx, with_oracle, rank=0, world=1, local_rank=0, barrier=lambda
                                   "" if world == 1 else "; ONE job on %d ranks: byte-range shards of the file, rows gathered on rank 0, buckets packed / cut over the ranks" % world)},
            "bam_generation_s": t_gen, "candidates": sum(1 for l in open(out + ".candidates.tab") if not l.startswith("#"))}
     if with_oracle:
-        import oracle
-        from oracle import cluster_oracle, signal_oracle
-        from tiddit_amd import tiddit_cluster, tiddit_stats
-        with contextlib.redirect_stdout(io.StringIO()):
-            lib = tiddit_stats.statistics(bam, fa, 5, 100000, 25000000)
-        max_ins = lib["percentile_insert_size"]
-        t0 = time.perf_counter()
-        cov, disc, split, clips, each, n_rec = signal_oracle.signal_main_file(bam, 5, max_ins, "WGS", 10000, 60, 25)
-        t_sig = time.perf_counter() - t0
-        ok = (open(out + "_tiddit/discordants_WGS.tab").read() == disc and open(out + "_tiddit/splits_WGS.tab").read() == split and
-              open(out + "_tiddit/clips_WGS.fa").read() == clips)
-        if not ok:
-            raise SystemExit("PARITY FAILURE: signal tables / clip FASTA differ from the CPU restatement")
-        names = [n for n, _ in contigs]
-        eps = int(lib["avg_insert_size"] / 2.0) or 50
-        cargs = (names, dict(contigs), ["WGS"], lib["mp"], eps, 3, max_ins, 10000, True, 3)
-        t0 = time.perf_counter()
-        want = cluster_oracle.main(out, *cargs)
-        t_cl = time.perf_counter() - t0
-        got = tiddit_cluster.main(out, *cargs)
-        if cluster_oracle.canonical(got) != cluster_oracle.canonical(want):
-            raise SystemExit("PARITY FAILURE: candidates differ from the CPU restatement")
-        from tiddit_amd import tiddit_signal
-        with contextlib.redirect_stdout(io.StringIO()):
-            _, chroms, gcov, _, _, _ = tiddit_signal.scan_signals(bam, 5, max_ins, 10000, 60, 25, 50)
-        for c in cov:
-            if not np.array_equal(gcov[c], cov[c]):
-                raise SystemExit("PARITY FAILURE: 50-bp coverage of %s differs from the CPU restatement" % c)
-        res["records"] = int(n_rec)
-        res["records_per_sec"] = n_rec / walls[-1]
-        res["cpu_baseline"] = {"value": t_sig + t_cl, "unit": "s", "cores": 1, "kind": "port",
-                               "sample": "the same file: signal extraction + coverage %.1f s (zlib inflate, C record walk + tiddit_signal.worker chain, Python rows), "
-                                         "clustering %.1f s (C DBSCAN restatement + Python regroup); library statistics, GC and ploidy not included" % (t_sig, t_cl)}
-        res["parity_checked"] = "signal tables, clip FASTA, 50-bp coverage of every contig and the whole candidates dictionary equal the CPU restatement"
+        res.update(sv_e2e_cpu_legs(mb, bam, fa, out, contigs, walls[-1], args.sv_cpu_full_mb))
     return res
+
+
+def sv_e2e_cpu_legs(mb, bam, fa, out, contigs, gpu_wall, full_mb=300):
+    """The CPU restatement of the same stages on the same file, timed on one core and on all cores, and the product's outputs compared
+    with it.  Up to 300 Mb the whole file; beyond that a BOUNDED SAMPLE: the library statistics as they are (a prefix of the file) and,
+    for everything else, a run of contigs at the end of the genome holding >= 4 % of it (oracle/signal_oracle.signal_main_sample finds
+    them by a binary search over the BGZF blocks) — rows, clips, coverage, GC, ploidy medians and candidates of those contigs."""
+    import contextlib
+    import io
+    import shutil
+    import oracle
+    from oracle import cluster_oracle, signal_oracle
+    from tiddit_amd import bamio, tiddit_cluster, tiddit_signal, tiddit_stats
+    names = [n for n, _ in contigs]
+    length = dict(contigs)
+    big = [t for t, (n, ln) in enumerate(contigs) if ln >= 10000]
+    total = float(sum(ln for _, ln in contigs))
+    if mb <= full_mb:
+        tids = list(big)
+    else:
+        tids, acc = [], 0
+        for t in reversed(big):
+            tids.insert(0, t)
+            acc += contigs[t][1]
+            if acc >= 0.04 * total:
+                break
+    frac = sum(contigs[t][1] for t in tids) / total
+    S = [names[t] for t in tids]
+    inS = set(S)
+    ncores = os.cpu_count() or 1
+    T1 = {}
+    # ---- library statistics (one core; the all-cores leg cannot split a sequential sample either: the reference does not)
+    t0 = time.perf_counter()
+    lib_cpu = signal_oracle.statistics_prefix(bam, 5, 100000, 25000000)
+    T1["library statistics"] = time.perf_counter() - t0
+    with contextlib.redirect_stdout(io.StringIO()):
+        lib = tiddit_stats.statistics(bam, fa, 5, 100000, 25000000)
+    bamio.set_carry(None)
+    if any(lib[k] != v for k, v in lib_cpu.items()):
+        raise SystemExit("PARITY FAILURE: library statistics differ from the CPU restatement")
+    max_ins = lib["percentile_insert_size"]
+    # ---- signal extraction + coverage: one core, then one process per contig on all cores
+    t0 = time.perf_counter()
+    cov, disc, split, clip_each, n_rec = signal_oracle.signal_main_sample(bam, tids, 5, max_ins, 60, 25, 1)
+    T1["signal extraction + coverage"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    covP, discP, splitP, clipP, _ = signal_oracle.signal_main_sample(bam, tids, 5, max_ins, 60, 25, min(ncores, len(tids)))
+    t_sig_all = time.perf_counter() - t0
+    if discP != disc or splitP != split or clipP != clip_each or any(not np.array_equal(covP[c], cov[c]) for c in S):
+        raise SystemExit("PARITY FAILURE: the CPU restatement on all cores differs from the one-core run")
+    keep = lambda text: "".join(l + "\n" for l in text.splitlines() if l.split("\t")[1] in inS and l.split("\t")[2] in inS)
+    if keep(open(out + "_tiddit/discordants_WGS.tab").read()) != keep(disc) or keep(open(out + "_tiddit/splits_WGS.tab").read()) != keep(split):
+        raise SystemExit("PARITY FAILURE: signal tables differ from the CPU restatement")
+    for c in S:
+        if open(out + "_tiddit/clips/%s.fa" % c).read() != clip_each[c]:
+            raise SystemExit("PARITY FAILURE: clip FASTA of %s differs from the CPU restatement" % c)
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, chroms, gcov, _, _, _ = tiddit_signal.scan_signals(bam, 5, max_ins, 10000, 60, 25, 50)
+    for c in S:
+        if not np.array_equal(gcov[c], cov[c]):
+            raise SystemExit("PARITY FAILURE: 50-bp coverage of %s differs from the CPU restatement" % c)
+    # ---- GC bins (C port of the per-character loop) and the masked medians of determine_ploidy (numpy, as the reference)
+    from tiddit_amd import tiddit_gc
+    t0 = time.perf_counter()
+    seqs = {}
+    with open(fa, "rb") as f:                                   # (plain FASTA read; the reference goes through pysam.FastaFile)
+        name = None
+        for block in f.read().split(b">")[1:]:
+            head, _, body = block.partition(b"\n")
+            name = head.split()[0].decode()
+            if name in inS:
+                seqs[name] = np.frombuffer(body.replace(b"\n", b""), dtype=np.uint8)
+    gc_cpu = {c: oracle.binned_gc(seqs[c], 50, 0.5) for c in S}
+    T1["GC bins"] = time.perf_counter() - t0
+    gc_gpu = tiddit_gc.main(fa, S, 1, 50, 0.5)
+    if any(not np.array_equal(np.asarray(gc_gpu[c]), gc_cpu[c]) for c in S):
+        raise SystemExit("PARITY FAILURE: GC bins differ from the CPU port")
+    t0 = time.perf_counter()
+    med_cpu = [float(np.median(cov[c][(cov[c] > 0) & (gc_cpu[c][:len(cov[c])] != -1)])) for c in S]
+    T1["ploidy (masked medians)"] = time.perf_counter() - t0
+    from tiddit_amd import tiddit_coverage_analysis as tca
+    med_gpu, _ = tca.masked_medians([(gcov[c], gc_gpu[c]) for c in S])
+    if [float(x) for x in med_gpu] != med_cpu:
+        raise SystemExit("PARITY FAILURE: masked coverage medians differ from numpy.median")
+    # ---- clustering of the contig pairs inside the run
+    tmp = out + "_cpu"
+    shutil.rmtree(tmp + "_tiddit", ignore_errors=True)
+    os.makedirs(tmp + "_tiddit")
+    open(tmp + "_tiddit/discordants_WGS.tab", "w").write(disc)
+    open(tmp + "_tiddit/splits_WGS.tab", "w").write(split)
+    eps = int(lib["avg_insert_size"] / 2.0) or 50
+    cargs = (S, length, ["WGS"], lib["mp"], eps, 3, max_ins, 10000, True, 3)
+    t0 = time.perf_counter()
+    want = cluster_oracle.main(tmp, *cargs)
+    T1["clustering"] = time.perf_counter() - t0
+    got = tiddit_cluster.main(out, *cargs)
+    if cluster_oracle.canonical(got) != cluster_oracle.canonical(want):
+        raise SystemExit("PARITY FAILURE: candidates differ from the CPU restatement")
+    one = sum(T1.values())
+    allc = one - T1["signal extraction + coverage"] + t_sig_all
+    scale = lambda T, sig: T["library statistics"] + (sig + T["GC bins"] + T["ploidy (masked medians)"] + T["clustering"]) / frac
+    what = "the whole file" if frac > 0.999 else "library statistics on the file's sampled prefix; the other stages on the last %d contigs (%s .. %s: %.1f %% of the genome, %d records)" % (
+        len(S), S[0], S[-1], 100 * frac, n_rec)
+    return {"records_in_cpu_sample": int(n_rec),
+            "cpu_baseline": {"value": one, "unit": "s", "cores": 1, "kind": "port", "stage_seconds": {k: round(v, 3) for k, v in T1.items()},
+                             "sample_fraction_of_genome": frac, "whole_file_estimate_s": scale(T1, T1["signal extraction + coverage"]),
+                             "sample": what + "; the same stages as the GPU run: statistics (zlib inflate of the prefix + the sampling loop + numpy), signal extraction + "
+                                              "50-bp coverage (zlib inflate, C record walk + tiddit_signal.worker chain, Python rows), GC (C port), masked medians (numpy), "
+                                              "clustering (C DBSCAN restatement + Python regroup)"},
+            "cpu_baseline_all_cores": {"value": allc, "unit": "s", "cores": min(ncores, len(tids)), "host_cores": ncores, "cpu_model": cpu_model(), "kind": "port",
+                                       "signal_extraction_s": t_sig_all, "whole_file_estimate_s": scale(T1, t_sig_all),
+                                       "sample": "the same sample; signal extraction as one process per contig (the reference's own fan-out, tiddit_signal.pyx:259), the "
+                                                 "other stages as in the one-core leg (sequential in the reference too)"},
+            "speedup_vs_1_core_estimate": scale(T1, T1["signal extraction + coverage"]) / gpu_wall,
+            "parity_checked": "library statistics; for %s: signal tables (rows of contig pairs inside the sample), clip FASTA, 50-bp coverage, GC bins, masked medians and the "
+                              "candidates dictionary equal the CPU restatement (one core == all cores)" % ("every contig" if frac > 0.999 else "the sampled contigs")}
 
 
 if __name__ == "__main__":

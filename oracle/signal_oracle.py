@@ -349,8 +349,17 @@ def signal_main_file(path, min_q, max_ins, sample_id, min_contig, min_anchor_len
     max_ins = int(max_ins)                 # `int max_ins` (:230)
     header, sq, raw = inflate_bam(path)
     f = oracle.bam_walk(raw)
-    tid = f["tid"]
     chromosomes = [c["SN"] for c in sq if c["LN"] >= min_contig]
+    res, clip_texts = _workers_over_fields(sq, raw, f, chromosomes, min_q, max_ins, min_anchor_len, min_clip_len, want_clips)
+    cov, disc, split = _merge_and_format(header, chromosomes, res)
+    return cov, disc, split, "".join(clip_texts[c] for c in chromosomes), clip_texts, len(f["tid"])
+
+
+def _workers_over_fields(sq, raw, f, chromosomes, min_q, max_ins, min_anchor_len, min_clip_len, want_clips=True):
+    """tiddit_signal.worker (:147-228) for every contig of `chromosomes` over the decoded fields `f` of the inflated records `raw`
+    -> ([(chromosome, discordant rows, split rows, coverage)], {chromosome: clip FASTA text})"""
+    import numpy as np
+    tid = f["tid"]
     names = [c["SN"] for c in sq]
     res, clip_texts = [], {}
     # samfile.fetch(chromosome): the contig's records, in file order (a coordinate-sorted file keeps them together; an
@@ -391,5 +400,256 @@ def signal_main_file(path, min_q, max_ins, sample_id, min_contig, min_anchor_len
                 d.append([chrA, chrB, read.query_name, read.reference_start + 1, read.reference_end + 1, read.is_reverse, read_chromosome])
         clip_texts[chromosome] = "".join("".join(c) for c in clips)
         res.append((chromosome, d, sp, cov))
+    return res, clip_texts
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A BOUNDED SAMPLE of a large coordinate-sorted BAM without an index: the records of a run of contigs, found by a binary search
+# over the BGZF blocks (each block inflates on its own; a record start inside it is recognised by its fields and confirmed by the
+# chain of block_size hops that follows).  bench.py times the restatement on such a sample when the whole file would take minutes
+# (a 3-Gb genome: 54 GB of BAM, ~9 minutes on one core), and compares the product's outputs for those contigs with it.
+
+def read_header(path):
+    """-> (header dict, sq list): inflates only the blocks that hold the header"""
+    raw = b""
+    with open(path, "rb") as f:
+        while True:
+            head = f.read(18)
+            if len(head) < 18:
+                break
+            xlen, bsize = struct.unpack_from("<H", head, 10)[0], struct.unpack_from("<H", head, 16)[0]
+            rest = f.read(bsize + 1 - 18)
+            cdata = (head + rest)[12 + xlen:bsize + 1 - 8]
+            raw += zlib.decompress(cdata, -15) if cdata else b""
+            if len(raw) >= 12:
+                l_text = struct.unpack_from("<i", raw, 4)[0]
+                if len(raw) >= 12 + l_text:
+                    n_ref = struct.unpack_from("<i", raw, 8 + l_text)[0]
+                    o, ok = 12 + l_text, True
+                    for _ in range(n_ref):
+                        if len(raw) < o + 4:
+                            ok = False
+                            break
+                        ln = struct.unpack_from("<i", raw, o)[0]
+                        o += 8 + ln
+                    if ok and len(raw) >= o:
+                        break
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text].split(b"\x00")[0].decode()
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    sq = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", raw, o)[0]
+        sq.append({"SN": raw[o + 4:o + 4 + ln - 1].decode(), "LN": struct.unpack_from("<i", raw, o + 4 + ln)[0]})
+        o += 8 + ln
+    header = {"SQ": sq}
+    for line in text.split("\n"):
+        if line.startswith("@RG"):
+            header.setdefault("RG", []).append(dict(f.split(":", 1) for f in line.split("\t")[1:] if ":" in f))
+    return header, sq
+
+
+def block_offsets(path):
+    """file offsets of every BGZF block (header hops over a memory map; nothing is inflated)"""
+    import mmap
+    import numpy as np
+    offs = []
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        o, n = 0, len(mm)
+        while o + 18 <= n:
+            offs.append(o)
+            o += struct.unpack_from("<H", mm, o + 16)[0] + 1
+        mm.close()
+    return np.array(offs + [o], dtype=np.int64)
+
+
+def _inflate_blocks(mm, offs, b0, b1):
+    parts = []
+    for b in range(b0, b1):
+        o, e = int(offs[b]), int(offs[b + 1])
+        xlen = struct.unpack_from("<H", mm, o + 10)[0]
+        cdata = mm[o + 12 + xlen:e - 8]
+        if cdata:
+            parts.append(zlib.decompress(cdata, -15))
+    return b"".join(parts)
+
+
+def _record_at(buf, o, sq):
+    """does a plausible BAM record start at buf[o]?  (SAM/BAM spec v1 §4.2 field ranges against the header)"""
+    if o + 36 > len(buf):
+        return False
+    bs, tid, pos = struct.unpack_from("<iii", buf, o)
+    l_name, n_cig = buf[o + 12], struct.unpack_from("<H", buf, o + 16)[0]
+    l_seq, mtid, mpos = struct.unpack_from("<iii", buf, o + 20)
+    if bs < 32 + l_name or bs > (1 << 24) or l_name < 2 or l_seq < 0 or not (-1 <= tid < len(sq)) or not (-1 <= mtid < len(sq)):
+        return False
+    if tid >= 0 and not (-1 <= pos <= sq[tid]["LN"]):
+        return False
+    if mtid >= 0 and not (-1 <= mpos <= sq[mtid]["LN"]):
+        return False
+    return 32 + l_name + 4 * n_cig + (l_seq + 1) // 2 + l_seq <= bs
+
+
+def sync_block(mm, offs, b, sq, span=4, chain=16):
+    """-> (offset of the first record that starts in block b, relative to the block's first inflated byte; its tid; the inflated
+    bytes of blocks b .. b+span).  A candidate offset counts when `chain` records follow it hop by hop, all plausible."""
+    nb = len(offs) - 1
+    buf = _inflate_blocks(mm, offs, b, min(nb, b + span))
+    first_len = len(_inflate_blocks(mm, offs, b, b + 1))
+    for o in range(0, first_len):
+        if not _record_at(buf, o, sq):
+            continue
+        p, ok, k = o, True, 0
+        while k < chain and p + 36 <= len(buf):
+            if not _record_at(buf, p, sq):
+                ok = False
+                break
+            p += 4 + struct.unpack_from("<i", buf, p)[0]
+            k += 1
+        if ok and (k == chain or p >= len(buf) - 36):
+            return o, struct.unpack_from("<i", buf, o + 4)[0], buf
+    return None, None, buf
+
+
+def contig_block(mm, offs, sq, tid, first_data_block):
+    """the last block whose first record belongs to a contig before `tid` (the first record of `tid` starts in it or right behind it)"""
+    n_ref = len(sq)
+    key = lambda t: n_ref if t < 0 else t                 # the unplaced tail sorts last
+    lo, hi = first_data_block, len(offs) - 1              # invariant: key(first record of block lo) < tid  (or lo is the first data block)
+    while hi - lo > 1:
+        mid = (lo + hi) // 2
+        o, t, _ = sync_block(mm, offs, mid, sq)
+        probe = mid
+        while o is None and probe + 1 < hi:              # a block without a record start (one long record): look further right
+            probe += 1
+            o, t, _ = sync_block(mm, offs, probe, sq)
+        if o is None or key(t) >= tid:
+            hi = mid
+        else:
+            lo = mid
+    return lo
+
+
+def inflate_contigs(path, sq, tid_first, tid_last, offs=None):
+    """-> uint8 array of the inflated records of contigs tid_first .. tid_last (starts at a record; may carry a few records of the
+    neighbouring contigs at either end — the per-contig workers select by tid)"""
+    import mmap
+    import numpy as np
+    offs = block_offsets(path) if offs is None else offs
+    with open(path, "rb") as f:
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+        # the first block that holds records: the header ends somewhere inside block h
+        first_data = 0
+        b0 = contig_block(mm, offs, sq, tid_first, first_data) if tid_first > 0 else 0
+        b1 = contig_block(mm, offs, sq, tid_last + 1, b0) + 2 if tid_last + 1 < len(sq) else len(offs) - 1
+        b1 = min(b1 + 2, len(offs) - 1)
+        if b0 == 0:                                        # from the header on: skip it
+            buf = _inflate_blocks(mm, offs, 0, b1)
+            l_text = struct.unpack_from("<i", buf, 4)[0]
+            o = 12 + l_text
+            for _ in range(struct.unpack_from("<i", buf, 8 + l_text)[0]):
+                o += 8 + struct.unpack_from("<i", buf, o)[0]
+        else:
+            o, _, _ = sync_block(mm, offs, b0, sq)
+            while o is None:
+                b0 += 1
+                o, _, _ = sync_block(mm, offs, b0, sq)
+            buf = _inflate_blocks(mm, offs, b0, b1)
+        mm.close()
+    return np.frombuffer(buf, dtype=np.uint8)[o:]
+
+
+def _contig_job(args):
+    path, sq, t, min_q, max_ins, min_anchor_len, min_clip_len, offs = args
+    raw = inflate_contigs(path, sq, t, t, offs)
+    f = oracle.bam_walk(raw)
+    res, clips = _workers_over_fields(sq, raw, f, [sq[t]["SN"]], min_q, max_ins, min_anchor_len, min_clip_len)
+    return res[0], clips[sq[t]["SN"]], int((f["tid"] == t).sum())
+
+
+def signal_main_sample(path, tids, min_q, max_ins, min_anchor_len, min_clip_len, processes=1):
+    """tiddit_signal.main restricted to the contigs `tids` (a run of consecutive contig ids) of a large coordinate-sorted BAM:
+    -> (coverage dict, discordants.tab text, splits.tab text, per-contig clip texts, records of those contigs).  Rows whose two contigs
+    both lie in the run are exactly the full run's rows for those contig pairs (a discordant row needs both reads; split rows with the
+    other contig outside the run are incomplete and must be dropped by the caller).
+    processes > 1: one worker process per contig (the reference's own fan-out, tiddit_signal.pyx:259)."""
+    max_ins = int(max_ins)
+    header, sq = read_header(path)
+    offs = block_offsets(path)
+    chromosomes = [sq[t]["SN"] for t in tids]
+    jobs = [(path, sq, t, min_q, max_ins, min_anchor_len, min_clip_len, offs) for t in tids]
+    if processes > 1:
+        import multiprocessing
+        with multiprocessing.get_context("fork").Pool(min(processes, len(jobs))) as pool:
+            out = pool.map(_contig_job, jobs)
+    else:
+        out = [_contig_job(j) for j in jobs]
+    res = [o[0] for o in out]
+    clip_texts = {c: o[1] for c, o in zip(chromosomes, out)}
     cov, disc, split = _merge_and_format(header, chromosomes, res)
-    return cov, disc, split, "".join(clip_texts[c] for c in chromosomes), clip_texts, len(tid)
+    return cov, disc, split, clip_texts, sum(o[2] for o in out)
+
+
+def statistics_prefix(path, min_mapq, max_ins_len, n_reads):
+    """tiddit_stats.statistics (tiddit_stats.py:5-78) on the first `n_reads` placed alignments of a coordinate-sorted BAM: only the
+    blocks that hold them are inflated (zlib), the sampling loop (:17-47) is evaluated on the decoded columns, and the figures come
+    from the same numpy calls (:52-56).  -> library dict (no printing).  Pinned by the `library` entry of tests/golden/sv_e2e*.json,
+    which the reference's own tiddit_stats.py produced."""
+    import mmap
+    import numpy as np
+    header, sq = read_header(path)
+    offs = block_offsets(path)
+    lens, ins = [], []
+    innie = outtie = 0
+    sampled = 0
+    done = False
+    with open(path, "rb") as fh:
+        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        b, carry, first = 0, b"", True
+        step = 2048                                                  # blocks per piece (~130 MB inflated)
+        while b < len(offs) - 1 and not done:
+            b1 = min(len(offs) - 1, b + step)
+            buf = carry + _inflate_blocks(mm, offs, b, b1)
+            b = b1
+            o = 0
+            if first:
+                l_text = struct.unpack_from("<i", buf, 4)[0]
+                o = 12 + l_text
+                for _ in range(struct.unpack_from("<i", buf, 8 + l_text)[0]):
+                    o += 8 + struct.unpack_from("<i", buf, o)[0]
+                first = False
+            raw = np.frombuffer(buf, dtype=np.uint8)[o:]
+            f = oracle.bam_walk(raw)
+            k = len(f["tid"])
+            used = int(f["rec_off"][k - 1]) + 4 + int(raw[int(f["rec_off"][k - 1]):int(f["rec_off"][k - 1]) + 4].view("<i4")[0]) if k else 0
+            carry = bytes(raw[used:])
+            placed = f["tid"] >= 0                                   # samfile.fetch() leaves the unplaced tail out (:17)
+            idx = sampled + np.cumsum(placed)
+            in_len = placed & (idx <= n_reads + 1)                   # read_length.append comes before the n_sampled test (:19-23)
+            lens.append(f["l_seq"][in_len].astype(np.int64))
+            act = placed & (idx <= n_reads)
+            fl = f["flag"].astype(np.int64)
+            rev, mrev = (fl & 0x10) != 0, (fl & 0x20) != 0
+            ok = act & ((fl & 0x8) == 0) & (rev != mrev) & (f["mate_tid"] == f["tid"]) & (f["tlen"].astype(np.int64) <= max_ins_len) \
+                & (f["mate_pos"] >= f["pos"]) & ((fl & 0xd00) == 0) & (f["mapq"].astype(np.int64) >= min_mapq)      # :25-38
+            ins.append(f["tlen"][ok].astype(np.int64))
+            outtie += int((ok & rev & ~mrev).sum())
+            innie += int((ok & ~(rev & ~mrev)).sum())
+            sampled = int(idx[-1]) if k else sampled
+            done = sampled > n_reads
+        mm.close()
+    read_length = np.concatenate(lens) if lens else np.zeros(0, np.int64)
+    insert_size = np.concatenate(ins) if ins else np.zeros(0, np.int64)
+    library = {"avg_read_length": np.average(read_length)}
+    if len(insert_size):
+        library["avg_insert_size"] = np.average(insert_size)
+        library["std_insert_size"] = np.std(insert_size)
+        library["percentile_insert_size"] = np.percentile(insert_size, 99.9)
+    else:
+        library["avg_insert_size"] = library["std_insert_size"] = library["percentile_insert_size"] = 0
+    library["mp"] = not (innie > outtie)
+    return library

@@ -108,3 +108,49 @@ def test_product_statistics_equal_the_reference(small, monkeypatch):
         lib = tiddit_stats.statistics(bam, fa, fx["params"]["min_q"], 100000, n_reads)
         for k, v in fx["library"].items():
             assert lib[k] == v, (k, lib[k], v)
+
+
+def test_bounded_contig_sample_equals_the_full_restatement(small):
+    """signal_oracle.signal_main_sample — a run of contigs located by a binary search over the BGZF blocks, no index, nothing else
+    inflated (what bench.py times on a 3-Gb BAM instead of the whole file) — gives, for those contigs, exactly what the full
+    restatement gives: coverage, clip FASTA, and the rows of both tables whose contigs all lie in the run; one process and several"""
+    fx, bam, fa, contigs, d = small
+    P = fx["params"]
+    max_ins = fx["library"]["percentile_insert_size"]
+    cov, disc, split, clips, each, n = signal_oracle.signal_main_file(bam, P["min_q"], max_ins, "WGS", P["min_contig"], P["min_anchor_len"], P["min_clip_len"])
+    header, sq = signal_oracle.read_header(bam)
+    assert [c["SN"] for c in sq] == [c for c, _ in contigs]
+    offs = signal_oracle.block_offsets(bam)
+    assert offs[0] == 0 and offs[-1] == os.path.getsize(bam) - 28 + 28       # hops end exactly at the end of the file
+    big = [t for t, (c, ln) in enumerate(contigs) if ln >= P["min_contig"]]
+    for tids, procs in ((big[-5:], 1), (big[-5:], 3), (big[3:9], 2), (big[:2], 1)):
+        names = {contigs[t][0] for t in tids}
+        scov, sdisc, ssplit, sclips, nrec = signal_oracle.signal_main_sample(bam, tids, P["min_q"], max_ins, P["min_anchor_len"], P["min_clip_len"], procs)
+        for t in tids:
+            c = contigs[t][0]
+            assert np.array_equal(scov[c], cov[c]), c
+            assert sclips[c] == each[c], c
+        keep = lambda text: "".join(l + "\n" for l in text.splitlines() if l.split("\t")[1] in names and l.split("\t")[2] in names)
+        # (a split row needs one read only: the sample also has rows whose second contig lies outside the run — not comparable, dropped)
+        assert sdisc == keep(disc) and keep(ssplit) == keep(split), (tids, procs)
+        assert nrec > 0
+    assert len(keep(disc)) > 0
+
+
+def test_statistics_prefix_restatement_is_pinned(small):
+    """oracle/signal_oracle.statistics_prefix (the CPU leg's library statistics: inflates only the sampled prefix of the file) equals
+    the `library` dictionary the reference's own tiddit_stats.py produced for this file, at the fixture's cut-off and at smaller ones"""
+    fx, bam, fa, contigs, d = small
+    P = fx["params"]
+    lib = signal_oracle.statistics_prefix(bam, P["min_q"], 100000, P["n_reads_stats"])
+    for k, v in fx["library"].items():
+        assert lib[k] == v, (k, lib[k], v)
+    from tiddit_amd import tiddit_stats                     # (host path of the product: the same numbers for other cut-offs)
+    os.environ["TIDDIT_HOST_INGEST"] = "1"
+    try:
+        for n in (1, 1000, 77777):
+            a = signal_oracle.statistics_prefix(bam, P["min_q"], 100000, n)
+            b = tiddit_stats.statistics(bam, fa, P["min_q"], 100000, n)
+            assert a == {k: b[k] for k in a}, n
+    finally:
+        del os.environ["TIDDIT_HOST_INGEST"]
