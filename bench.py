@@ -958,7 +958,7 @@ def sv_e2e(args, ctx, with_oracle, rank=0, world=1, local_rank=0, barrier=lambda
     import shutil
     from tiddit_amd import __main__ as cli, synth_bam
     mb = args.sv_mb
-    d = "/tmp/tiddit_bench_sv_%d" % mb
+    d = os.path.join(os.environ.get("TIDDIT_BENCH_TMP", "/tmp"), "tiddit_bench_sv_%d" % mb)
     bam, fa = os.path.join(d, "WGS.bam"), os.path.join(d, "ref.fa")
     contigs = synth_bam.wgs_contigs(mb)
     t_gen = None
@@ -1019,7 +1019,7 @@ def sv_e2e_cpu_legs(mb, bam, fa, out, contigs, gpu_wall, full_mb=300):
         for t in reversed(big):
             tids.insert(0, t)
             acc += contigs[t][1]
-            if acc >= 0.04 * total:
+            if acc >= 0.04 * total and len(tids) >= 6:            # (several contigs, so that the all-cores leg has something to fan out)
                 break
     frac = sum(contigs[t][1] for t in tids) / total
     S = [names[t] for t in tids]
