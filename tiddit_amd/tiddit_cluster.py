@@ -72,7 +72,26 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
             from . import tiddit_signal
             cached = tiddit_signal.written_tables(disc_path, split_path)      # this process wrote these very files: their rows are still here
         if cached is not None:
-            disc_iter = ([r[0], r[1], r[2]] + [str(v) for v in r[3]] for r in cached[0])     # the columns `line.split("\t")` would give
+            # the rows as tiddit_signal wrote them, still as numbers and booleans: the same records as the text loop below builds, without the
+            # str() / int() round trip (positions stay ints — every later use converts with int() anyway; orientations become the text's words)
+            side = _MP_SIDE if is_mp else _PE_SIDE
+            default = (4, 6) if is_mp else (3, 7)
+            for frag, chrA, chrB, o in cached[0]:
+                lenA, lenB = contig_length[chrA], contig_length[chrB]
+                if lenA < min_contig or lenB < min_contig:
+                    continue
+                recs = bucket(chrA, chrB)
+                oa, ob = ("True" if o[2] else "False"), ("True" if o[5] else "False")
+                a, b = side.get((oa, ob), default)
+                posA, posB = o[a - 3], o[b - 3]
+                if posA > lenA:
+                    posA = lenA
+                    if posB > lenB:
+                        posA = lenB                 # QUIRK (:67-70), as below
+                recs.append([frag, sample, "D", posA, oa, posB, ob, i, o[0], o[1], o[3], o[4]])
+                positions[chrA][chrB].append([posA, posB, i])
+                i += 1
+            disc_iter = ()
         else:
             disc_iter = (line.rstrip().split("\t") for line in open(disc_path))
         for c in disc_iter:
@@ -93,7 +112,16 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
             files.append(("A", "{}_tiddit/contigs_{}.tab"))
         for kind, pattern in files:
             if kind == "S" and cached is not None:
-                rows_iter = ([r[0], r[1], r[2]] + [str(v) for v in r[3]] for r in cached[1])
+                for frag, chrA, chrB, o in cached[1]:
+                    lenA, lenB = contig_length[chrA], contig_length[chrB]
+                    if lenA < min_contig or lenB < min_contig:
+                        continue
+                    recs = bucket(chrA, chrB)
+                    posA, posB = min(o[0], lenA), min(o[2], lenB)
+                    recs.append([frag, sample, kind, posA, ("True" if o[1] else "False"), posB, ("True" if o[3] else "False"), i, o[4], o[5], o[6], o[7]])
+                    positions[chrA][chrB].append([posA, posB, i])
+                    i += 1
+                continue
             else:
                 rows_iter = (line.rstrip().split("\t") for line in open(pattern.format(prefix, sample)))
             for c in rows_iter:
