@@ -276,6 +276,11 @@ int tdt_region_counts_device(tdt_ctx *ctx, const int32_t *d_start, const int32_t
  * `name \t 1+i*bin \t (i+1)*bin+1 \t value \n` (last row ends at contig_len), kind 1 = wig values, one per line.
  * Values are written exactly like Python's `"{}".format(numpy.float64)`.  Two-call protocol: out == NULL returns the
  * size in *out_len; then call again with a buffer of at least that many bytes. */
+/* The numeric half of tiddit_signal.SA_analysis (tiddit_signal.pyx:11-145) for the selected records `which` (those carrying an SA tag):
+ * out[k] = {int32 status (0: SA mapQ below min_q, 1: valid, 2: unusual tag — run the literal code), read_start, read_end, split_pos,
+ * sa_split (before the swap), seg_start, seg_end, uint32 chr_off, chr_len (the SA contig name inside raw), uint8 is_reverse, sa_minus,
+ * 2 pad} — 40 bytes.  The contig-name order and the swap (:118-140) are string decisions left to the caller.  Host function. */
+int tdt_split_fields(const void *meta, const uint32_t *raw_end, const uint8_t *raw, size_t raw_len, const uint32_t *which, size_t m, int min_q, void *out);
 int tdt_format_coverage(const double *values, size_t n, const char *name, int64_t bin_size, int64_t contig_len, int kind, char *out,
                         size_t out_cap, size_t *out_len);
 

@@ -78,6 +78,7 @@ SYMBOLS = {
     "tdt_signal_scan": (_i, [_P, _P, _sz, _P, _i, _i, _i64, _i, _i, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "tdt_signal_scan_result": (_i, [_P, _P, _P, _P]),
     "tdt_format_clips": (_i, [_P, _P, _P, _P, _sz, ctypes.c_char_p, _P, _sz, ctypes.POINTER(_sz)]),
+    "tdt_split_fields": (_i, [_P, _P, _P, _sz, _P, _sz, _i, _P]),
     "tdt_masked_medians": (_i, [_P, _P, _P, _P, _i, _P, _P, _P]),
     "tdt_segment_means": (_i, [_P, _P, _P, _i64, _P, _P, _P, _sz, _P, _P]),
     "tdt_segment_means_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _P]),

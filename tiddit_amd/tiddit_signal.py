@@ -129,6 +129,8 @@ class _ReadProxy:
 
 _META = numpy.dtype([("idx", "<u4"), ("tid", "<i4"), ("pos", "<i4"), ("end", "<i4"), ("mate_tid", "<i4"), ("sa_rel", "<i4"),
                      ("flag", "<u2"), ("action", "u1"), ("pad", "u1")])
+_SPLIT = numpy.dtype([("status", "<i4"), ("read_start", "<i4"), ("read_end", "<i4"), ("split_pos", "<i4"), ("sa_split", "<i4"), ("seg_start", "<i4"),
+                      ("seg_end", "<i4"), ("chr_off", "<u4"), ("chr_len", "<u4"), ("is_reverse", "u1"), ("sa_minus", "u1"), ("pad", "<u2")])
 _FIELD_ORDER = ("tid", "pos", "end", "mapq", "flag", "mate_tid", "mate_pos", "tlen", "l_seq", "cigar_first", "cigar_last", "rec_off", "sa_off", "raw")
 
 
@@ -159,6 +161,39 @@ class SelectedReads:
         buf = numpy.empty(need.value, dtype=numpy.uint8)
         _native.check(lib.tdt_format_clips(*args, _native.ptr(buf), need.value, ctypes.byref(need)))
         return buf[:need.value].tobytes().decode()
+
+
+def split_rows_native(sel, which4, names, min_q, splits, lib=None):
+    """split-read rows (SA_analysis, :31-145) of the selected reads `which4` appended to splits[contig]: the numeric half in C
+    (``tdt_split_fields``) for well-formed tags; contig names, their string order and the swap (:118-140) here; unusual tags go
+    through the literal :func:`SA_analysis` (and raise what it raises)."""
+    if not len(which4):
+        return
+    lib = lib or sel.ctx.lib
+    so = numpy.empty(len(which4), dtype=_SPLIT)
+    _native.check(lib.tdt_split_fields(_native.ptr(sel.meta), _native.ptr(sel.raw_end), _native.ptr(sel.raw), len(sel.raw),
+                                       _native.ptr(numpy.ascontiguousarray(which4, dtype=numpy.uint32)), len(which4), int(min_q), _native.ptr(so)))
+    rb = sel.raw_bytes
+    cols = zip(which4.tolist(), so["status"].tolist(), so["read_start"].tolist(), so["read_end"].tolist(), so["split_pos"].tolist(),
+               so["sa_split"].tolist(), so["seg_start"].tolist(), so["seg_end"].tolist(), so["chr_off"].tolist(), so["chr_len"].tolist(),
+               so["is_reverse"].tolist(), so["sa_minus"].tolist(), sel.tid[which4].tolist(), sel.rec_off[which4].tolist())
+    for k, status, rs, re_, sp, ssp, gs, ge, co, cl, rev, sam, t_, o_ in cols:
+        if status == 0:
+            continue
+        chrom = names[t_]
+        if status != 1:                                   # an unusual tag: the literal code (and its exceptions)
+            split = SA_analysis(_ReadProxy(sel, k), min_q, "SA", chrom)
+            if split:
+                splits[chrom].append(split)
+            continue
+        sa_chr = rb[co:co + cl].decode()
+        qname = rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode()
+        if sa_chr < chrom:                                # string order, like the reference (:118)
+            splits[chrom].append([sa_chr, chrom, qname, ssp, bool(rev), sp, bool(sam), gs, ge, rs, re_])
+        elif sa_chr == chrom and ssp < sp:
+            splits[chrom].append([chrom, sa_chr, qname, ssp, bool(rev), sp, bool(sam), gs, ge, rs, re_])
+        else:
+            splits[chrom].append([chrom, sa_chr, qname, sp, bool(rev), ssp, bool(sam), rs, re_, gs, ge])
 
 
 def _device_scan(batch, contig_ok, min_q, max_ins, min_anchor_len, min_clip_len, ctx=None):
@@ -253,11 +288,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                 clips[chrom].append([sel.clip_fasta(clip_k[lo:hi], chrom), ""])
         t5 = time.time()
         T["clip rows"] += t5 - t4
-        for k in numpy.flatnonzero(act & 4):
-            chrom = names[stid[k]]
-            split = SA_analysis(_ReadProxy(sel, k), min_q, "SA", chrom)
-            if split:
-                splits[chrom].append(split)
+        split_rows_native(sel, numpy.flatnonzero(act & 4), names, min_q, splits)
         t6 = time.time()
         T["split rows"] += t6 - t5
         which = numpy.flatnonzero(act & 8)
