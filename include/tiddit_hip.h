@@ -243,6 +243,21 @@ int tdt_format_clips(const void *meta, const uint32_t *raw_end, const uint8_t *r
 int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t *gc, const int64_t *seg_off, int nseg, double *lower,
                        double *upper, int64_t *count);
 
+/* ---- library statistics on the device (tiddit_stats.statistics, tiddit_stats.py:5-78) ------------------------- *
+ * tdt_stats_push_device takes the decoded field arrays of one ingest batch (device pointers) and applies the sampling loop (:17-47):
+ * placed reads are numbered across batches, the cut-off after n_reads is honoured to the read, the insert sizes of the passing
+ * pairs are appended in order to a device list; *done = the sample is complete.  tdt_stats_counts: sampled, sum and count of the
+ * read lengths, innie, outtie, number and sum of the insert sizes (+ 2 per-batch figures).  tdt_stats_moments: numpy's
+ * mean((x - mean)^2) of the list (numpy.std = its square root; numpy's summation order reproduced) and the two order statistics
+ * k0 <= k1 that numpy.percentile interpolates between (radix select).  Everything is bit-identical to the numpy calls (:52-56). */
+typedef struct tdt_stats tdt_stats;
+int tdt_stats_create(tdt_ctx *ctx, int64_t n_reads, int min_mapq, int64_t max_ins_len, tdt_stats **out);
+int tdt_stats_destroy(tdt_stats *s);
+int tdt_stats_push_device(tdt_stats *s, const int32_t *d_tid, const int32_t *d_pos, const int32_t *d_mate_tid, const int32_t *d_mate_pos,
+                          const int32_t *d_tlen, const int32_t *d_l_seq, const uint16_t *d_flag, const uint8_t *d_mapq, size_t n, int *done);
+int tdt_stats_counts(tdt_stats *s, int64_t *counts9);
+int tdt_stats_moments(tdt_stats *s, double mean, int64_t k0, int64_t k1, double *mean_sqdev, int32_t *order0, int32_t *order1);
+
 /* ---- region means of the coverage bins per SV candidate --------------------------------------------- *
  * Replaces the per-candidate numpy.average calls of tiddit_variant.define_variant (tiddit_variant.pyx:265-283: avg_a / avg_b over
  * the 50-bp bins [start/50, end/50]; :307-315: covM over the bins between the breakpoints with gc != -1).  cov / gc are the

@@ -154,3 +154,32 @@ def test_sv_on_n_ranks_is_byte_identical(run, tmp_path, world):
     # every rank clustered a share of the signals (one device call each), none of them all of it
     shares = [sum(v) for v in res.values()]
     assert all(len(v) == 1 for v in res.values()) and max(shares) < sum(shares)
+
+
+def test_library_statistics_on_the_device_equal_the_host_loop(run):
+    """tiddit_stats.statistics with the sampling loop, the cut-off and numpy's mean / std / 99.9th percentile on the device
+    (csrc/tdt_stats.hip) == the read-by-read C loop + numpy on the host, for cut-offs inside a batch, at a batch edge, of one read and
+    beyond the file, with one batch and with many (the counters carry over); the fixture's cut-off is also the reference's own dictionary"""
+    from tiddit_amd import bamio, tiddit_stats
+    fx, bam, fa, contigs, out = run
+    if fx["params"]["total_mb"] > 30:
+        pytest.skip("the smaller files cover it")
+    P = fx["params"]
+    for chunk in (None, 3 << 20):
+        for n in (1, 2, 1000, 77777, P["n_reads_stats"], 10**9):
+            res = []
+            for host in ("1", "0"):
+                os.environ["TIDDIT_STATS_HOST"] = host
+                if chunk:
+                    os.environ["TIDDIT_INGEST_CHUNK"] = str(chunk)
+                try:
+                    res.append(tiddit_stats.statistics(bam, fa, P["min_q"], 100000, n))
+                finally:
+                    os.environ.pop("TIDDIT_STATS_HOST", None)
+                    os.environ.pop("TIDDIT_INGEST_CHUNK", None)
+                    bamio.set_carry(None)
+            assert res[0] == res[1], (chunk, n, res)
+            assert all(type(res[0][k]) is type(res[1][k]) for k in res[0]), (chunk, n)
+            if n == P["n_reads_stats"]:
+                for k, v in fx["library"].items():
+                    assert res[1][k] == v, (k, res[1][k], v)

@@ -104,6 +104,11 @@ SYMBOLS = {
     "tdt_ingest_edges": (_i, [_P, _P, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "tdt_copy_to_host": (_i, [_P, _P, _P, _sz]),
+    "tdt_stats_create": (_i, [_P, _i64, _i, _i64, _PP]),
+    "tdt_stats_destroy": (_i, [_P]),
+    "tdt_stats_push_device": (_i, [_P] * 9 + [_sz, ctypes.POINTER(_i)]),
+    "tdt_stats_counts": (_i, [_P, _P]),
+    "tdt_stats_moments": (_i, [_P, _dbl, _i64, _i64, ctypes.POINTER(_dbl), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "tdt_stats_scan": (_i, [_P] * 8 + [_sz, _i64, _i, _i64, _P, _P, ctypes.POINTER(_sz)]),
     "tdt_bam_decode": (_i, [_P, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz)] + [_P] * 13),
 }

@@ -723,7 +723,7 @@ def open_bam(path, ctx=None):
     import os
     if os.environ.get("TIDDIT_HOST_INGEST") == "1":
         return BamReader(path)
-    return DeviceBamReader(path, ctx=ctx)
+    return DeviceBamReader(path, ctx=ctx, chunk=int(os.environ.get("TIDDIT_INGEST_CHUNK", str(448 << 20))))
 
 
 # ------------------------------------------------------------------------------------ writer

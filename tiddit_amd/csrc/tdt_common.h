@@ -31,7 +31,7 @@ struct tdt_buf {
     size_t cap = 0;
 };
 
-enum { TDT_NSCRATCH = 24, TDT_NPINNED = 4 };
+enum { TDT_NSCRATCH = 28, TDT_NPINNED = 4 };
 
 struct tdt_ctx {
     int device = 0;

@@ -155,6 +155,69 @@ __global__ __launch_bounds__(64) void seg_means(const double *__restrict__ cov, 
     if (lane == 0) mean[q] = n ? total / (double)n : __longlong_as_double(0x7ff8000000000000ll);   // numpy.average([]) is nan
 }
 
+// numpy.add.reduce of a contiguous float64 array of any length: the chunk sums (numpy's pairwise sum of each 8192-element buffer) are
+// independent — one wavefront each — and a single thread then adds them in sequence, which is the order numpy folds them in.
+__global__ __launch_bounds__(64) void np_chunk_sums(const double *__restrict__ a, long long n, double *__restrict__ csums) {
+    __shared__ MnLeaf leaves[MN_MAXLEAVES];
+    __shared__ double lsum[MN_MAXLEAVES];
+    __shared__ int s_nleaf;
+    const int lane = threadIdx.x;
+    const long long o = (long long)blockIdx.x * MN_CHUNK;
+    if (o >= n) return;
+    const int len = (int)(n - o < MN_CHUNK ? n - o : MN_CHUNK);
+    const double *c = a + o;
+    double csum = 0.0;
+    if (len < 8) {
+        if (lane == 0)
+            for (int i = 0; i < len; i++) csum += c[i];
+    } else {
+        if (lane == 0) s_nleaf = mn_leaves(len, leaves);
+        __syncthreads();
+        const int nl = s_nleaf;
+        const int grp = lane >> 3, j = lane & 7;
+        for (int l0 = 0; l0 < nl; l0 += 8) {
+            const int l = l0 + grp;
+            double r = 0.0;
+            int s = 0, m = 0;
+            if (l < nl) {
+                s = leaves[l].start;
+                m = leaves[l].len;
+                r = c[s + j];
+                for (int i = 8; i < m - (m % 8); i += 8) r += c[s + i + j];
+            }
+            r = r + __shfl_xor(r, 1);
+            r = r + __shfl_xor(r, 2);
+            r = r + __shfl_xor(r, 4);
+            if (l < nl && j == 0) {
+                for (int i = m - (m % 8); i < m; i++) r += c[s + i];
+                lsum[l] = r;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int next = 0;
+            csum = mn_fold(len, lsum, next);
+        }
+    }
+    if (lane == 0) csums[blockIdx.x] = csum;
+}
+
+__global__ void np_fold_chunks(const double *__restrict__ csums, long long nchunks, double *__restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    double t = 0.0;
+    for (long long i = 0; i < nchunks; i++) t += csums[i];
+    *out = t;
+}
+
+// *d_out (device) = numpy.add.reduce(d_a[0:n]) bit for bit; d_csums: scratch of ceil(n / 8192) doubles.  (C++ linkage: tdt_stats.hip)
+int tdt_np_sum_device(tdt_ctx *ctx, const double *d_a, size_t n, double *d_csums, double *d_out) {
+    const long long nch = (long long)((n + MN_CHUNK - 1) / MN_CHUNK);
+    if (nch) hipLaunchKernelGGL(np_chunk_sums, dim3((unsigned)nch), dim3(64), 0, ctx->stream, d_a, (long long)n, d_csums);
+    hipLaunchKernelGGL(np_fold_chunks, dim3(1), dim3(1), 0, ctx->stream, (const double *)d_csums, nch, d_out);
+    TDT_CHECK_LAUNCH();
+    return TDT_OK;
+}
+
 static int means_launch(tdt_ctx *ctx, const double *d_cov, const int8_t *d_gc, const int64_t *seg_lo, const int64_t *seg_hi,
                         const uint8_t *masked, size_t nq, double *d_mean, int64_t *d_count) {
     hipStream_t st = ctx->stream;

@@ -13,16 +13,40 @@ from . import _native
 from .bamio import open_bam
 
 
+def _device_figures(lib, h, state):
+    """counters and the three numpy figures of the insert-size list from the device (csrc/tdt_stats.hip); None without insert sizes"""
+    cnt = numpy.zeros(9, dtype=numpy.int64)
+    _native.check(lib.tdt_stats_counts(h, _native.ptr(cnt)))
+    state[:5] = cnt[:5]
+    n_ins = int(cnt[5])
+    if not n_ins:
+        return None
+    mean = numpy.float64(int(cnt[6])) / n_ins                       # numpy.average of ints: an exact float64 sum / n
+    q = numpy.true_divide(99.9, 100)                                # numpy.percentile's own arithmetic (method "linear")
+    vi = (n_ins - 1) * q
+    k0 = int(numpy.floor(vi))
+    k1 = min(k0 + 1, n_ins - 1)
+    msd, o0, o1 = ctypes.c_double(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    _native.check(lib.tdt_stats_moments(h, float(mean), k0, k1, ctypes.byref(msd), ctypes.byref(o0), ctypes.byref(o1)))
+    a, b, g = numpy.int32(o0.value), numpy.int32(o1.value), vi - k0
+    diff = numpy.subtract(b, a)
+    pct = numpy.add(a, diff * g)                                    # numpy's _lerp(a, b, t)
+    if g >= 0.5:
+        pct = numpy.subtract(b, diff * (1 - g))
+    return mean, numpy.sqrt(numpy.float64(msd.value)), numpy.float64(pct)
+
+
 def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
-    library = {}
-    t = time.time()
     import os
     from . import bamio
+    library = {}
+    t = time.time()
     bamio.set_carry(None)
     reader = open_bam(bam_file_name)
     # `tiddit --sv` scans the same file for signals next (tiddit_signal.main): the sampled batches stay in HBM with their coverage records
     # written for the 50-bp histogram, and that pass starts from them instead of reading and inflating this part of the file again
-    carry = isinstance(reader, bamio.DeviceBamReader) and os.environ.get("TIDDIT_NO_CARRY") != "1"
+    on_device = isinstance(reader, bamio.DeviceBamReader)
+    carry = on_device and os.environ.get("TIDDIT_NO_CARRY") != "1"
     kept, hist = [], None
     if carry:
         from . import tiddit_coverage
@@ -32,46 +56,65 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     lib = _native.load()
     state = numpy.zeros(6, dtype=numpy.int64)
     chunks = []
-
-    def scan(cols, n):
-        # the sampling loop of the reference (:17-47), read by read, in C (csrc/tdt_bam.hip: tdt_stats_scan); `state` carries over
-        out = numpy.empty(n, dtype=numpy.int32)
-        k = ctypes.c_size_t(0)
-        _native.check(lib.tdt_stats_scan(*[_native.ptr(c) for c in cols], n, int(n_reads), int(min_mapq), int(max_ins_len), _native.ptr(state),
-                                         _native.ptr(out), ctypes.byref(k)))
-        chunks.append(out[:k.value].copy())
-
-    # one worker runs the loop of batch k (ctypes drops the GIL) while the device inflates and decodes batch k + 1; batches are
-    # scanned in order, and the pass stops one batch after the loop has seen its n_reads-th read
-    pending = None
+    figures = None
     batches = reader.batches()
-    with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
-        for b in batches:
-            if carry:
-                kept.append(b)
-            cols = [numpy.ascontiguousarray(getattr(b, k)) for k in ("tid", "pos", "mate_tid", "mate_pos", "tlen", "l_seq", "flag", "mapq")]
+    if on_device and os.environ.get("TIDDIT_STATS_HOST") != "1":
+        # the sampling loop (:17-47), its cut-off and the three numpy figures (:52-56) on the device: the decoded fields of every batch
+        # are in HBM already, and nothing but a handful of counters comes back
+        h = ctypes.c_void_p()
+        _native.check(lib.tdt_stats_create(reader.ctx.handle, int(n_reads), int(min_mapq), int(max_ins_len), ctypes.byref(h)))
+        try:
+            done = ctypes.c_int(0)
+            for b in batches:
+                if carry:
+                    kept.append(b)
+                d = b.dev
+                _native.check(lib.tdt_stats_push_device(h, d["tid"], d["pos"], d["mate_tid"], d["mate_pos"], d["tlen"], d["l_seq"], d["flag"], d["mapq"],
+                                                        len(b), ctypes.byref(done)))
+                if done.value:
+                    break
+            figures = _device_figures(lib, h, state)
+        finally:
+            lib.tdt_stats_destroy(h)
+    else:
+        def scan(cols, n):
+            # the sampling loop of the reference (:17-47), read by read, in C (csrc/tdt_bam.hip: tdt_stats_scan); `state` carries over
+            out = numpy.empty(n, dtype=numpy.int32)
+            k = ctypes.c_size_t(0)
+            _native.check(lib.tdt_stats_scan(*[_native.ptr(c) for c in cols], n, int(n_reads), int(min_mapq), int(max_ins_len), _native.ptr(state),
+                                             _native.ptr(out), ctypes.byref(k)))
+            chunks.append(out[:k.value].copy())
+
+        # one worker runs the loop of batch k (ctypes drops the GIL) while batch k + 1 is inflated and decoded; batches are scanned in
+        # order, and the pass stops one batch after the loop has seen its n_reads-th read
+        pending = None
+        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+            for b in batches:
+                if carry:
+                    kept.append(b)
+                cols = [numpy.ascontiguousarray(getattr(b, k)) for k in ("tid", "pos", "mate_tid", "mate_pos", "tlen", "l_seq", "flag", "mapq")]
+                if pending is not None:
+                    pending.result()
+                    if state[5]:
+                        pending = None
+                        break
+                pending = pool.submit(scan, cols, len(b))
             if pending is not None:
                 pending.result()
-                if state[5]:
-                    pending = None
-                    break
-            pending = pool.submit(scan, cols, len(b))
-        if pending is not None:
-            pending.result()
+        insert_size = numpy.concatenate(chunks) if chunks else numpy.zeros(0, dtype=numpy.int32)
+        if len(insert_size):
+            figures = (numpy.average(insert_size), numpy.std(insert_size), numpy.percentile(insert_size, 99.9))
     if carry:
         reader.retain = False
         bamio.set_carry(bamio.ScanCarry(bam_file_name, reader, batches, kept, hist))
     else:
         reader.close()
-    insert_size = numpy.concatenate(chunks) if chunks else numpy.zeros(0, dtype=numpy.int32)
     is_innie, is_outtie = int(state[3]), int(state[4])
     # numpy.average of the read lengths: an exact integer sum over an exact count
     avg_read_length = (float(state[1]) / float(state[2])) if state[2] else float(numpy.average(numpy.zeros(0)))
     library["avg_read_length"] = avg_read_length
-    if len(insert_size):
-        library["avg_insert_size"] = numpy.average(insert_size)
-        library["std_insert_size"] = numpy.std(insert_size)
-        library["percentile_insert_size"] = numpy.percentile(insert_size, 99.9)
+    if figures is not None:
+        library["avg_insert_size"], library["std_insert_size"], library["percentile_insert_size"] = figures
     else:
         library["avg_insert_size"] = 0
         library["std_insert_size"] = 0
