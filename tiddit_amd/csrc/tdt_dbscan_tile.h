@@ -22,7 +22,9 @@
 #pragma once
 #include <type_traits>
 
+#ifndef DT_THREADS
 #define DT_THREADS 256
+#endif
 #define DT_WAVES (DT_THREADS / 64)
 #ifndef DT_NW
 #define DT_NW 24                            // staged words per tile
@@ -37,7 +39,7 @@
 #define DT_CODE_LITERAL (1ull << 60)        // the low word IS the id (caller-supplied x labels)
 #define DT_MINUS1 0xbff0000000000000ull     // bits of -1.0
 #define DT_GRP 64                           // tiles per group of the two-level count sums (one-bucket path)
-#define DT_GRPMAX 20000                     // groups: 2^31 points / (DT_GRP * smallest tile)
+#define DT_GRPMAX (0x7fffffff / (DT_GRP * DT_T) + 2)   // groups of tiles a call can have (n < 2^31)
 
 #ifdef DT_PROF
 // variant builds only (tools/dt_prof.sh): shader-clock cycles per phase of dbt_tile as seen by thread 0, per workgroup
