@@ -239,7 +239,31 @@ def run_sv(args, version):
         t = time.time()
         write_candidates(prefix + ".candidates.tab", contigs, sv_clusters)
         T["candidates table"] = time.time() - t
-        print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
+        # Variant typing / filtering / the VCF (tiddit_variant.pyx, tiddit_vcf_header.py) are outside this build's scope.  When the
+        # reference package itself is importable (it needs pysam) the candidates are handed to it, as the reference's driver does
+        # (__main__.py:193-207), so that a full installation still ends with {prefix}.vcf.
+        handed = False
+        try:
+            import tiddit.tiddit_variant as tiddit_variant
+            import tiddit.tiddit_vcf_header as tiddit_vcf_header
+        except Exception:
+            tiddit_variant = None
+        if tiddit_variant is not None:
+            t = time.time()
+            vcf_header = tiddit_vcf_header.main(bam_header, library, sample_id, version)
+            variants = tiddit_variant.main(args.bam, sv_clusters, args, library, min_mapq, samples, coverage_data, contig_number, max_ins_len,
+                                           gc_dictionary)
+            with open(prefix + ".vcf", "w") as f:
+                f.write(vcf_header + "\n")
+                for chrom in contigs:
+                    if chrom not in variants:
+                        continue
+                    for variant in sorted(variants[chrom], key=lambda x: x[0]):
+                        f.write("\t".join(variant[1]) + "\n")
+            T["variant typing (reference package)"] = time.time() - t
+            handed = True
+        if not handed:
+            print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
     if world > 1:
         dist.barrier()                                                   # every output file exists when any rank returns
 

@@ -46,6 +46,9 @@ struct tdt_ctx {
     unsigned tile_calls = 0;             // clustering: parity selects one of two group-sum arrays
     int tile_groups_max = 0;             // ... and how many of their entries have ever been used
     void *tile_flags_zeroed = nullptr;   // clustering: the status block that has been zeroed once (its users re-zero it themselves)
+    // tdt_signal_scan -> tdt_signal_scan_result: what the last scan of THIS context selected (pointers into its scratch slots)
+    size_t scan_n_sel = 0, scan_raw_bytes = 0;
+    void *scan_meta = nullptr, *scan_size = nullptr, *scan_bytes = nullptr;
 };
 
 int tdt_scratch(tdt_ctx *ctx, int slot, size_t bytes, void **out);

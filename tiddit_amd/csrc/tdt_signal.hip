@@ -263,13 +263,7 @@ __global__ __launch_bounds__(64) void sig_gather_bytes(const unsigned *__restric
     for (unsigned b = threadIdx.x; b < end - beg; b += 64) out[beg + b] = src[b];
 }
 
-struct tdt_scan_state {
-    size_t n_sel = 0, raw_bytes = 0;
-    ScanMeta *d_meta = nullptr;
-    unsigned *d_size = nullptr;
-    uint8_t *d_bytes = nullptr;
-};
-static thread_local tdt_scan_state g_scan;
+// (the result of a scan belongs to the context it ran on: tdt_signal_scan_result fetches it from there, from any thread)
 
 extern "C" int tdt_signal_scan(tdt_ctx *ctx, const void *const *d_arrays14, size_t n_, const uint8_t *contig_ok, int n_contigs, int min_q,
                                int64_t max_ins, int min_anchor_len, int min_clip_len, size_t *n_sel, size_t *raw_bytes) {
@@ -279,7 +273,8 @@ extern "C" int tdt_signal_scan(tdt_ctx *ctx, const void *const *d_arrays14, size
     }
     *n_sel = 0;
     *raw_bytes = 0;
-    g_scan = tdt_scan_state();
+    ctx->scan_n_sel = ctx->scan_raw_bytes = 0;
+    ctx->scan_meta = ctx->scan_size = ctx->scan_bytes = nullptr;
     if (n_ == 0) return TDT_OK;
     if (n_ >= 0x7fffffffull) {
         tdt_set_error("tdt_signal_scan: n too large");
@@ -351,28 +346,28 @@ extern "C" int tdt_signal_scan(tdt_ctx *ctx, const void *const *d_arrays14, size
     if (rc) return rc;
     hipLaunchKernelGGL(sig_gather_bytes, dim3(m), dim3(64), 0, st, (const unsigned *)d_idx, m, d_rec_off, (const unsigned *)d_size, d_raw, (uint8_t *)scr3);
     TDT_CHECK_LAUNCH();
-    g_scan.n_sel = (size_t)m;
-    g_scan.raw_bytes = total;
-    g_scan.d_meta = d_meta;
-    g_scan.d_size = d_size;
-    g_scan.d_bytes = (uint8_t *)scr3;
+    ctx->scan_n_sel = (size_t)m;
+    ctx->scan_raw_bytes = total;
+    ctx->scan_meta = d_meta;
+    ctx->scan_size = d_size;
+    ctx->scan_bytes = scr3;
     *n_sel = (size_t)m;
     *raw_bytes = total;
     return TDT_OK;
 }
 
 extern "C" int tdt_signal_scan_result(tdt_ctx *ctx, void *meta24, uint32_t *raw_end, uint8_t *raw) {
-    if (!ctx || (g_scan.n_sel && (!meta24 || !raw_end || !raw))) {
+    if (!ctx || (ctx->scan_n_sel && (!meta24 || !raw_end || !raw))) {
         tdt_set_error("tdt_signal_scan_result: bad argument");
         return TDT_E_ARG;
     }
-    if (!g_scan.n_sel) return TDT_OK;
+    if (!ctx->scan_n_sel) return TDT_OK;
     TDT_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     static_assert(sizeof(ScanMeta) == 28, "ScanMeta layout");
-    TDT_HIP(hipMemcpyAsync(meta24, g_scan.d_meta, g_scan.n_sel * sizeof(ScanMeta), hipMemcpyDeviceToHost, st));
-    TDT_HIP(hipMemcpyAsync(raw_end, g_scan.d_size, g_scan.n_sel * 4, hipMemcpyDeviceToHost, st));
-    TDT_HIP(hipMemcpyAsync(raw, g_scan.d_bytes, g_scan.raw_bytes, hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipMemcpyAsync(meta24, ctx->scan_meta, ctx->scan_n_sel * sizeof(ScanMeta), hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipMemcpyAsync(raw_end, ctx->scan_size, ctx->scan_n_sel * 4, hipMemcpyDeviceToHost, st));
+    TDT_HIP(hipMemcpyAsync(raw, ctx->scan_bytes, ctx->scan_raw_bytes, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipStreamSynchronize(st));
     return TDT_OK;
 }

@@ -6,6 +6,7 @@ Same entry points as the reference — ``create_coverage`` (:10-21), ``update_co
 Bins are bit-identical to the reference's float64 arrays (see csrc/tdt_coverage.hip).
 """
 import ctypes
+import threading
 import math
 
 import numpy
@@ -225,23 +226,32 @@ def update_coverage_batch(ref_start, ref_end, mapq, flag, min_q, bin_size, cover
     """
     LN = _contig_length(coverage_data, bin_size, end_bin_size)
     key = (LN, int(bin_size))
-    h = _HIST_CACHE.get(key)          # one histogram object per (contig length, bin size): a per-read loop reuses it
-    if h is None:
-        if len(_HIST_CACHE) >= 8:
-            _HIST_CACHE.pop(next(iter(_HIST_CACHE))).close()
-        h = _HIST_CACHE[key] = CoverageHistogram([("c", LN)], bin_size)
-    try:
-        h.reset()
-        h.push(0, ref_start, ref_end, mapq, flag, min_q)
-        coverage_data += h.finish(0)
-    except Exception:
-        _HIST_CACHE.pop(key, None)
-        h.close()
-        raise
+    with _HIST_LOCK:                  # the cached histogram is shared state: reset / push / finish of two callers must not interleave
+        h = _HIST_CACHE.get(key)      # one histogram object per (contig length, bin size): a per-read loop reuses it
+        if h is None:
+            if len(_HIST_CACHE) >= 8:
+                _HIST_CACHE.pop(next(iter(_HIST_CACHE))).close()
+            h = _HIST_CACHE[key] = CoverageHistogram([("c", LN)], bin_size)
+        try:
+            h.reset()
+            h.push(0, ref_start, ref_end, mapq, flag, min_q)
+            coverage_data += h.finish(0)
+        except Exception:
+            _HIST_CACHE.pop(key, None)
+            h.close()
+            raise
     return coverage_data
 
 
+def clear_histogram_cache():
+    """release the device histograms `update_coverage[_batch]` keeps between calls"""
+    with _HIST_LOCK:
+        while _HIST_CACHE:
+            _HIST_CACHE.popitem()[1].close()
+
+
 _HIST_CACHE = {}
+_HIST_LOCK = threading.RLock()
 
 
 def update_coverage(ref_start, ref_end, bin_size, coverage_data, end_bin_size):
