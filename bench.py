@@ -78,7 +78,7 @@ def profiled_traffic(kernel):
     try:
         import hashlib
         prof = json.load(open(tp))
-        src = {"cov_": ("tdt_coverage.hip", "tdt_common.h"), "dbt_": ("tdt_dbscan_tile.h",), "gc_": ("tdt_gc.hip",)}
+        src = {"cov_": ("tdt_coverage.hip", "tdt_cov_record.h"), "dbt_": ("tdt_dbscan_tile.h",), "gc_": ("tdt_gc.hip",)}
         for pre, files in src.items():                       # ... or when the kernel's source changed since the profile was taken
             if kernel.startswith(pre):
                 for f in files:

@@ -533,7 +533,7 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         TDT_CHECK_LAUNCH();
         if (nb == 1) {
             ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
-            hipLaunchKernelGGL(dbt_finish1, dim3(ntt), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
+            hipLaunchKernelGGL(dbt_finish1, dim3((ntt + DT_FTPB - 1) / DT_FTPB), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
                                (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, 0ll, 0, t_flags, hw, seq);
         } else {
             hipLaunchKernelGGL(dbt_scan, dim3(1), dim3(1024), 0, st, t_aggR, t_aggE, ntt, (const int *)d_boff, nb, n, (const unsigned *)t_brun,
@@ -813,7 +813,7 @@ extern "C" int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const ui
     hw[1] = 0;
     hipLaunchKernelGGL((dbt_tile<true, false, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
     ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
-    hipLaunchKernelGGL(dbt_finish1, dim3(ntt), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR, (const unsigned *)t_aggE,
+    hipLaunchKernelGGL(dbt_finish1, dim3((ntt + DT_FTPB - 1) / DT_FTPB), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR, (const unsigned *)t_aggE,
                        ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, (long long)cluster_id, 1,
                        t_flags, hw, seq);
     TDT_CHECK_LAUNCH();

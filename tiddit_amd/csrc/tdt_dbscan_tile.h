@@ -625,17 +625,21 @@ __global__ __launch_bounds__(256) void dbt_finish(unsigned long long *__restrict
 // one bucket: no scan launch — every workgroup sums the counts it needs itself: whole groups of DT_GRP tiles from the group sums
 // the tile kernel accumulated, single tiles inside its own group.  `grp_next` is the group array of the NEXT call (the two
 // alternate): workgroup 0 clears it.
+#ifndef DT_FTPB
+#define DT_FTPB 4                            // tiles per workgroup of dbt_finish1: one prefix prologue serves them all
+#endif
 __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restrict__ lab, int n, const unsigned *__restrict__ aggR,
                                                    const unsigned *__restrict__ aggE, int nt, const unsigned *__restrict__ grp,
                                                    unsigned *__restrict__ grp_next, int ng_clear, long long *__restrict__ last_id,
                                                    long long id_base, int use_id_base,
                                                    unsigned *__restrict__ flags, volatile unsigned *host, unsigned seq) {
     __shared__ unsigned red[4][6];
+    __shared__ unsigned pR[DT_FTPB + 1], pE[DT_FTPB + 1];      // [j]: runs / extra sub-runs in front of tile (tile0 - 1 + j)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x * DT_FTPB;         // the first of this workgroup's tiles
     dt_signal_host(flags, host, seq);
     const int ng = (nt + DT_GRP - 1) / DT_GRP;
-    if (tile == 0)
+    if (blockIdx.x == 0)
         for (int i = tid; i < ng_clear; i += 256) {
             grp_next[i] = 0;
             grp_next[DT_GRPMAX + i] = 0;
@@ -666,14 +670,30 @@ __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restric
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 6; k++) v[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-    const unsigned preR[2] = {v[0], v[0] + v[1]}, preE[2] = {v[3], v[3] + v[4]};     // [0]: the previous tile's, [1]: this tile's
+    if (tid == 0) {                                // exclusive prefixes of tile-1, tile, tile+1, ...: a short serial chain
+        unsigned r = v[0], e = v[3];
+        pR[0] = r;
+        pE[0] = e;
+        r += v[1];
+        e += v[4];
+        for (int j = 1; j <= DT_FTPB; j++) {
+            pR[j] = r;
+            pE[j] = e;
+            const int t = tile + j - 1;
+            if (t < nt) {
+                r += aggR[t];
+                e += aggE[t];
+            }
+        }
+    }
+    __syncthreads();
     const long long R1 = use_id_base ? id_base : (long long)v[2] - 1;     // ids of the extra sub-runs continue from here (:112-122)
-    if (tile == 0 && tid == 0 && last_id) last_id[0] = R1 + (long long)v[5];
-    const int i0 = tile * DT_T;
+    if (blockIdx.x == 0 && tid == 0 && last_id) last_id[0] = R1 + (long long)v[5];
+    const long long i0 = (long long)tile * DT_T;
+    const long long i1 = i0 + (long long)DT_FTPB * DT_T < (long long)n ? i0 + (long long)DT_FTPB * DT_T : (long long)n;
     const bool al = (((size_t)lab) & 15) == 0;
-    for (int o = tid * 2; o < DT_T; o += 512) {
-        const int i = i0 + o;
-        if (i >= n) break;
+    for (long long i = i0 + tid * 2; i < i1; i += 512) {
+        const int tl = (int)((i - i0) / DT_T);     // DT_T is even: a pair never straddles two tiles
         ull w[2];
         const bool two = al && i + 2 <= n;
         if (two) {
@@ -688,10 +708,10 @@ __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restric
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             if (w[k] >> 63) continue;                                  // -1.0 stays
-            const int sel = 1 - (int)((w[k] >> 62) & 1ull);
+            const int j = tl + 1 - (int)((w[k] >> 62) & 1ull);         // the owner tile's prefix (the point's own tile, or the one before it)
             const unsigned c = (unsigned)w[k];
             const double id = (w[k] & DT_CODE_LITERAL) ? (double)(int)c
-                              : (w[k] & DT_CODE_EXTRA) ? (double)(R1 + (long long)(preE[sel] + c)) : (double)(preR[sel] + c);
+                              : (w[k] & DT_CODE_EXTRA) ? (double)(R1 + (long long)(pE[j] + c)) : (double)(pR[j] + c);
             w[k] = (ull)__double_as_longlong(id);
             any = true;
         }
