@@ -177,3 +177,41 @@ def test_signal_worker_has_the_reference_shape(sv_bam, tmp_path):
         name, rows, srows, bins, path = tiddit_signal.worker(chrom, bam, fa, prefix, 5, 600, "SYN", 50, True, 30, 20)
         assert name == chrom and rows == data[chrom] and srows == splits[chrom] and np.array_equal(bins, cov[chrom])
         assert open(path).read() == "".join("".join(c) for c in clips[chrom])
+
+
+def test_bench_runs_every_section_on_two_ranks_sharing_the_gpu(tmp_path):
+    """`bench.py --gpus 2` (the driver's multi-GPU invocation, torch.distributed.run, one process per rank) with TIDDIT_BENCH_SHARE_GPU=1:
+    both ranks on the box's one GPU, exchange over gloo — every section takes its N-rank path (contigs / bases split, the shared bucket
+    list with its all-gather, ONE BAM as byte-range shards with the exact all-reduce, `tiddit --sv` as one job on two ranks) and rank 0
+    prints ONE JSON line with the contract's keys; the N-rank sv_e2e candidates equal the one-rank run's"""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    small = ["--steps", "2", "--warmup", "1", "--contigs", "4", "--contig-len", "8000000", "--dbscan-n", "300000", "--gc-len", "50000000",
+             "--sv-mb", "3", "--ingest-mb", "1", "--no-next", "--no-cpu-baseline"]
+    env = dict(os.environ, TIDDIT_BENCH_SHARE_GPU="1", TIDDIT_BENCH_TMP=str(tmp_path))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2"] + small, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "bins/s"
+    for k in ("metric", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    for section in ("coverage_sv", "dbscan_shared", "gc", "ingest", "sv_e2e"):
+        assert section in d, section
+    assert "2 byte-range shards" in d["ingest"]["config"]["workload"] and "ONE job on 2 ranks" in d["sv_e2e"]["config"]["workload"]
+    one = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + small + ["--no-gc", "--no-ingest", "--no-dbscan", "--no-cov-sv"],
+                         env=dict(os.environ, TIDDIT_BENCH_TMP=str(tmp_path)), capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert d1["sv_e2e"]["candidates"] == d["sv_e2e"]["candidates"] > 0
+    a = open(os.path.join(str(tmp_path), "tiddit_bench_sv_3", "run1.candidates.tab")).read()
+    b = open(os.path.join(str(tmp_path), "tiddit_bench_sv_3", "run2.candidates.tab")).read()
+    assert a == b
