@@ -215,3 +215,56 @@ def test_bench_runs_every_section_on_two_ranks_sharing_the_gpu(tmp_path):
     a = open(os.path.join(str(tmp_path), "tiddit_bench_sv_3", "run1.candidates.tab")).read()
     b = open(os.path.join(str(tmp_path), "tiddit_bench_sv_3", "run2.candidates.tab")).read()
     assert a == b
+
+
+def test_signal_main_on_a_file_that_is_not_in_contig_order(sv_bam, tmp_path):
+    """the rows are merged into the (chrA, chrB, fragment) dictionaries while the file is scanned — legal only while the records come in
+    the header's contig order; here the records of the first contig are moved behind all others: the early merge must switch itself
+    off and the tables must still equal the literal restatement (which visits the contigs in header order, tiddit_signal.pyx:259-284)"""
+    import struct
+    from tiddit_amd import bamio, tiddit_signal
+    bam, fa, info, d = sv_bam
+    raw = b"".join(bamio.bgzf_blocks(open(bam, "rb")))
+    rd = bamio.BamReader(bam)
+    skip = rd.header_bytes
+    rd.close()
+    first, rest, o = [], [], skip
+    while o + 4 <= len(raw):
+        n = 4 + struct.unpack_from("<I", raw, o)[0]
+        (first if struct.unpack_from("<i", raw, o + 4)[0] == 0 else rest).append(raw[o:o + n])
+        o += n
+    assert first and rest
+    shuffled = raw[:skip] + b"".join(rest) + b"".join(first)
+    path = str(tmp_path / "moved.bam")
+    with open(path, "wb") as f:
+        for k in range(0, len(shuffled), 0xff00):
+            f.write(bamio._bgzf_block(shuffled[k:k + 0xff00], 1))
+        f.write(bamio._BGZF_EOF)
+    hdr, reads = signal_oracle.parse_bam(path)
+    prefix = str(tmp_path / "m")
+    os.makedirs(prefix + "_tiddit/clips")
+    cov = tiddit_signal.main(path, fa, prefix, 5, 600, "SYN", 1, 1000, False, 60, 25)
+    assert "tables" not in tiddit_signal.PREMERGED                       # (consumed or never offered)
+    wcov, wdisc, wsplit, wclips, wclip_each = signal_oracle.signal_main(hdr, reads, 5, 600, "SYN", 1000, 60, 25)
+    assert open(prefix + "_tiddit/discordants_SYN.tab").read() == wdisc and wdisc.count("\n") > 20
+    assert open(prefix + "_tiddit/splits_SYN.tab").read() == wsplit
+    assert open(prefix + "_tiddit/clips_SYN.fa").read() == wclips
+    for c in wcov:
+        assert np.array_equal(cov[c], wcov[c]), c
+    # and on the sorted file the early merge is what main() used
+    seen = {}
+    real = tiddit_signal._merge_and_write
+
+    def spy(header, chromosomes, res_data, res_splits, *a, **k):
+        seen["offered"] = "tables" in tiddit_signal.PREMERGED and tiddit_signal.PREMERGED["tables"][2] is res_data
+        return real(header, chromosomes, res_data, res_splits, *a, **k)
+    tiddit_signal._merge_and_write = spy
+    try:
+        p2 = str(tmp_path / "s")
+        os.makedirs(p2 + "_tiddit/clips")
+        tiddit_signal.main(bam, fa, p2, 5, 600, "SYN", 1, 1000, False, 60, 25)
+        assert seen["offered"]
+        tiddit_signal.main(path, fa, p2, 5, 600, "SYN", 1, 1000, False, 60, 25)
+        assert not seen["offered"]
+    finally:
+        tiddit_signal._merge_and_write = real

@@ -24,7 +24,7 @@ import ctypes
 
 from .hostutil import quiet_gc
 from . import _native, tiddit_coverage
-from .bamio import DeviceBatch, RecordView, open_bam
+from .bamio import DeviceBamReader, DeviceBatch, RecordView, open_bam
 
 _SA_OPS = {"M": 0, "S": 4, "H": 5, "D": 2, "I": 1}   # :23 — any other CIGAR letter raises KeyError, like the reference
 
@@ -275,6 +275,41 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     T.clear()
     T.update({"ingest (inflate + decode, device)": 0.0, "coverage push": 0.0, "field copies + predicates (host)": 0.0, "clip rows": 0.0,
               "split rows": 0.0, "discordant select + rows": 0.0})
+    # The merge of tiddit_signal.main (:262-284) walks the contigs in order and, inside a contig, the rows in file order.  On a
+    # coordinate-sorted file whose contig order is the header's that IS the file order, so the rows of a batch can be merged into the
+    # (chrA, chrB, fragment) dictionaries as soon as they exist — on the worker thread, behind the device ingest of the next batch —
+    # and main() finds the dictionaries ready.  A row out of contig order switches the early merge off; main() then merges the
+    # per-contig lists as before.
+    all_contigs = list(names)
+    rank_of = {}
+    for t, ok in enumerate(big):
+        if ok:
+            rank_of[names[t]] = len(rank_of)
+    early = {"ok": shard is None, "last_d": -1, "last_s": -1,
+             "data": {a: {b: {} for b in all_contigs} for a in rank_of}, "splits": {a: {b: {} for b in all_contigs} for a in rank_of}}
+
+    def merge_early(chrom, rows, which):
+        r = rank_of.get(chrom)
+        if r is None or not early["ok"]:
+            return
+        if r < early["last_" + which]:
+            early["ok"] = False
+            return
+        early["last_" + which] = r
+        if which == "d":
+            tab = early["data"]
+            for signal in rows:
+                a = tab.get(signal[0])
+                if a is not None:
+                    a[signal[1]].setdefault(signal[2], []).append(signal[3:])
+        else:
+            tab = early["splits"]
+            for signal in rows:
+                a = tab.get(signal[0])
+                if a is not None:
+                    f = a[signal[1]].setdefault(signal[2], [])
+                    f += signal[3:]
+
     def rows_of(sel):
         """clip / split / discordant rows of one batch's selected reads (host copies only: runs on the worker thread while the device
         ingests the next batch — the main thread waits inside the library without the GIL)"""
@@ -288,18 +323,36 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                 clips[chrom].append([sel.clip_fasta(clip_k[lo:hi], chrom), ""])
         t5 = time.time()
         T["clip rows"] += t5 - t4
-        split_rows_native(sel, numpy.flatnonzero(act & 4), names, min_q, splits)
+        which4 = numpy.flatnonzero(act & 4)
+        tids4 = stid[which4]
+        runs4 = [] if not len(which4) else [int(t) for t in tids4[numpy.concatenate([[0], numpy.flatnonzero(numpy.diff(tids4)) + 1])]]
+        before = {t: len(splits[names[t]]) for t in set(runs4)}
+        split_rows_native(sel, which4, names, min_q, splits)
+        if early["ok"]:
+            if len(set(runs4)) != len(runs4):
+                early["ok"] = False                              # a contig twice in one batch: not coordinate sorted
+            for t in runs4:
+                merge_early(names[t], splits[names[t]][before[t]:], "s")
         t6 = time.time()
         T["split rows"] += t6 - t5
         which = numpy.flatnonzero(act & 8)
         rb = sel.raw_bytes
         cols = zip(stid[which].tolist(), sel.mate_tid[which].tolist(), sel.pos[which].tolist(), sel.end[which].tolist(),
                    sel.flag[which].tolist(), sel.rec_off[which].tolist())
+        cur_t, cur_rows = None, None
         for t_, m_, p_, e_, f_, o_ in cols:
             chrom, mate = names[t_], names[m_]
             chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
             qname = rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode()          # block_size, 32 fixed bytes, then l_read_name bytes (NUL included)
-            data[chrom].append([chrA, chrB, qname, p_ + 1, e_ + 1, bool(f_ & 0x10), chrom])
+            row = [chrA, chrB, qname, p_ + 1, e_ + 1, bool(f_ & 0x10), chrom]
+            data[chrom].append(row)
+            if t_ != cur_t:
+                if cur_rows:
+                    merge_early(names[cur_t], cur_rows, "d")
+                cur_t, cur_rows = t_, []
+            cur_rows.append(row)
+        if cur_rows:
+            merge_early(names[cur_t], cur_rows, "d")
         T["discordant select + rows"] += time.time() - t6
 
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
@@ -399,6 +452,9 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                 o = hist.offset(i)
                 coverage[n] = allbins[o:o + hist.nbins(i)[0]].copy()
     hist.close()
+    PREMERGED.clear()
+    if early["ok"] and isinstance(reader, DeviceBamReader):
+        PREMERGED["tables"] = (early["data"], early["splits"], data, splits)      # (keyed to the very lists main() hands to the merge)
     return header, chromosomes, coverage, data, splits, clips
 
 
@@ -406,6 +462,7 @@ _SCAN_CACHE = {}
 STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 SCAN_SECONDS = {}           # ... and of the last scan_signals() pass, by what the host waited for
 LAST_SEAM = {}              # seam offsets of the last sharded scan_signals() pass (dist.check_seams)
+PREMERGED = {}              # the (chrA, chrB, fragment) dictionaries the last scan_signals() merged while it scanned (see rows_of)
 WRITTEN_TABLES = {}         # (discordants path, splits path) -> stamps + the rows the last main() wrote there (tiddit_cluster reads them back)
 
 
@@ -432,18 +489,23 @@ def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bi
 def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id):
     """the merge loop and the three writers of tiddit_signal.main (:246-332) over per-contig row lists in file order"""
     all_contigs = [c["SN"] for c in header["SQ"]]
-    data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
-    splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
+    pre = PREMERGED.pop("tables", None)
+    if pre is not None and pre[2] is res_data and pre[3] is res_splits and list(pre[0]) == list(chromosomes):
+        data, splits = pre[0], pre[1]                                        # merged while the file was scanned (scan_signals)
+    else:
+        pre = None
+        data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
+        splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
     os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
     clip_fasta = []
     with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "w") as all_clips:      # (written last in the reference; same bytes)
         for chrom in chromosomes:                                            # results in contig order (:262-284)
             print("Collecting signals on contig: {}".format(chrom))
-            for signal in res_data[chrom]:
+            for signal in (res_data[chrom] if pre is None else ()):
                 if signal[0] not in data:
                     continue
                 data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
-            for signal in res_splits[chrom]:
+            for signal in (res_splits[chrom] if pre is None else ()):
                 if signal[0] not in splits:
                     continue
                 splits[signal[0]][signal[1]].setdefault(signal[2], [])
