@@ -256,7 +256,6 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     elif shard is None:
         reader = open_bam(bam_file_name)
     else:
-        from .bamio import DeviceBamReader
         reader = DeviceBamReader(bam_file_name, shard=shard, chunk=int(os.environ.get("TIDDIT_INGEST_CHUNK", str(448 << 20))))
     header = reader.header
     names, lengths = reader.references, reader.lengths
