@@ -285,7 +285,8 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         if ok:
             rank_of[names[t]] = len(rank_of)
     early = {"ok": shard is None, "last_d": -1, "last_s": -1,
-             "data": {a: {b: {} for b in all_contigs} for a in rank_of}, "splits": {a: {b: {} for b in all_contigs} for a in rank_of}}
+             "data": {a: {b: {} for b in all_contigs} for a in rank_of}, "splits": {a: {b: {} for b in all_contigs} for a in rank_of},
+             "dlines": {}, "slines": {}}       # (chrA, chrB, fragment) -> the row as main() writes it, formatted as soon as it is complete
 
     def merge_early(chrom, rows, which):
         r = rank_of.get(chrom)
@@ -296,18 +297,32 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             return
         early["last_" + which] = r
         if which == "d":
-            tab = early["data"]
+            tab, lines = early["data"], early["dlines"]
             for signal in rows:
-                a = tab.get(signal[0])
+                chrA = signal[0]
+                a = tab.get(chrA)
                 if a is not None:
-                    a[signal[1]].setdefault(signal[2], []).append(signal[3:])
+                    chrB = signal[1]
+                    reads = a[chrB].setdefault(signal[2], [])
+                    reads.append(signal[3:])
+                    if len(reads) == 2:                          # the row of :298-318 is complete with the fragment's second read
+                        first, second = reads
+                        if chrA == chrB:
+                            if second[-1] < first[-1]:
+                                first, second = second, first
+                        elif first[-1] != chrA:
+                            first, second = second, first
+                        out = first[0:-1] + second[0:-1]
+                        lines[(chrA, chrB, signal[2])] = ("{}\t{}\t{}\t{}\n".format(signal[2], chrA, chrB, "\t".join(map(str, out))), out)
         else:
-            tab = early["splits"]
+            tab, lines = early["splits"], early["slines"]
             for signal in rows:
-                a = tab.get(signal[0])
+                chrA = signal[0]
+                a = tab.get(chrA)
                 if a is not None:
                     f = a[signal[1]].setdefault(signal[2], [])
                     f += signal[3:]
+                    lines[(chrA, signal[1], signal[2])] = "{}\t{}\t{}\t{}\n".format(signal[2], chrA, signal[1], "\t".join(map(str, f)))
 
     def rows_of(sel):
         """clip / split / discordant rows of one batch's selected reads (host copies only: runs on the worker thread while the device
@@ -453,7 +468,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     hist.close()
     PREMERGED.clear()
     if early["ok"] and isinstance(reader, DeviceBamReader):
-        PREMERGED["tables"] = (early["data"], early["splits"], data, splits)      # (keyed to the very lists main() hands to the merge)
+        PREMERGED["tables"] = (early["data"], early["splits"], data, splits, early["dlines"], early["slines"])   # (keyed to the very lists main() merges)
     return header, chromosomes, coverage, data, splits, clips
 
 
@@ -523,6 +538,13 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
     with open(disc_path, "w") as f:      # :298-318
         for chrA in data:
             for chrB in data[chrA]:
+                if pre is not None:                     # the rows were formatted when their second read arrived: same order, same text
+                    dl, frags = pre[4], data[chrA][chrB]
+                    if frags:
+                        got = [dl[(chrA, chrB, fragment)] for fragment, reads in frags.items() if len(reads) >= 2]
+                        f.write("".join(g[0] for g in got))
+                        disc_rows.extend((fragment, chrA, chrB, dl[(chrA, chrB, fragment)][1]) for fragment, reads in frags.items() if len(reads) >= 2)
+                    continue
                 for fragment, reads in data[chrA][chrB].items():
                     if len(reads) < 2:
                         continue
@@ -538,6 +560,12 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
     with open(split_path, "w") as f:           # :320-326
         for chrA in splits:
             for chrB in splits[chrA]:
+                if pre is not None:
+                    sl, frags = pre[5], splits[chrA][chrB]
+                    if frags:
+                        f.write("".join(sl[(chrA, chrB, fragment)] for fragment in frags))
+                        split_rows.extend((fragment, chrA, chrB, fields) for fragment, fields in frags.items())
+                    continue
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
                     split_rows.append((fragment, chrA, chrB, fields))
