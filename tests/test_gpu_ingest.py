@@ -190,7 +190,7 @@ def test_signal_scan_device_ingest_equals_host_ingest(bams, monkeypatch):
         monkeypatch.setenv("TIDDIT_HOST_INGEST", mode)
         res[mode] = tiddit_signal.scan_signals(bams[0], 5, 600, 10000, 30, 20)
     h, d = res["1"], res["0"]
-    text = lambda clips: {c: "".join("".join(e) for e in v) for c, v in clips.items()}     # (entries are only ever written joined)
+    text = lambda clips: {c: b"".join(tiddit_signal._clip_bytes(e) for e in v) for c, v in clips.items()}     # (entries are only ever written joined)
     assert h[1] == d[1] and h[3] == d[3] and h[4] == d[4] and text(h[5]) == text(d[5])
     assert sum(len(v) for v in d[3].values()) > 0 and sum(len(v) for v in d[4].values()) > 0 and sum(len(v) for v in text(d[5]).values()) > 0
     for c in h[2]:

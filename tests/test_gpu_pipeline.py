@@ -176,7 +176,7 @@ def test_signal_worker_has_the_reference_shape(sv_bam, tmp_path):
     for chrom in chroms[:3]:
         name, rows, srows, bins, path = tiddit_signal.worker(chrom, bam, fa, prefix, 5, 600, "SYN", 50, True, 30, 20)
         assert name == chrom and rows == data[chrom] and srows == splits[chrom] and np.array_equal(bins, cov[chrom])
-        assert open(path).read() == "".join("".join(c) for c in clips[chrom])
+        assert open(path, "rb").read() == b"".join(tiddit_signal._clip_bytes(c) for c in clips[chrom])
 
 
 def test_bench_runs_every_section_on_two_ranks_sharing_the_gpu(tmp_path):

@@ -152,7 +152,7 @@ class SelectedReads:
         return RecordView(self, k)
 
     def clip_fasta(self, which, contig):
-        """``>name|contig|pos+1\\nSEQ\\n`` of the selected records `which`, as one string (tdt_format_clips)"""
+        """``>name|contig|pos+1\\nSEQ\\n`` of the selected records `which`, as one bytes object (tdt_format_clips)"""
         which = numpy.ascontiguousarray(which, dtype=numpy.uint32)
         lib = self.ctx.lib
         need = ctypes.c_size_t(0)
@@ -160,7 +160,12 @@ class SelectedReads:
         _native.check(lib.tdt_format_clips(*args, None, 0, ctypes.byref(need)))
         buf = numpy.empty(need.value, dtype=numpy.uint8)
         _native.check(lib.tdt_format_clips(*args, _native.ptr(buf), need.value, ctypes.byref(need)))
-        return buf[:need.value].tobytes().decode()
+        return buf[:need.value].tobytes()
+
+
+def _clip_bytes(clip):
+    """the bytes of one clip entry: [header, sequence] strings of the host path, or [bytes, ""] of a whole batch formatted in C"""
+    return clip[0] if isinstance(clip[0], bytes) else "".join(clip).encode()
 
 
 def split_rows_native(sel, which4, names, min_q, splits, lib=None):
@@ -286,7 +291,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             rank_of[names[t]] = len(rank_of)
     early = {"ok": shard is None, "last_d": -1, "last_s": -1,
              "data": {a: {b: {} for b in all_contigs} for a in rank_of}, "splits": {a: {b: {} for b in all_contigs} for a in rank_of},
-             "dlines": {}, "slines": {}}       # (chrA, chrB, fragment) -> the row as main() writes it, formatted as soon as it is complete
+             "slines": {a: {b: {} for b in all_contigs} for a in rank_of}}   # fragment -> the split row as main() writes it
 
     def merge_early(chrom, rows, which):
         r = rank_of.get(chrom)
@@ -297,7 +302,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             return
         early["last_" + which] = r
         if which == "d":
-            tab, lines = early["data"], early["dlines"]
+            tab = early["data"]
             for signal in rows:
                 chrA = signal[0]
                 a = tab.get(chrA)
@@ -305,15 +310,16 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                     chrB = signal[1]
                     reads = a[chrB].setdefault(signal[2], [])
                     reads.append(signal[3:])
-                    if len(reads) == 2:                          # the row of :298-318 is complete with the fragment's second read
-                        first, second = reads
+                    if len(reads) == 2:                          # the row of :298-318 is complete with the fragment's second read:
+                        first, second = reads                    # reads[2] = (fragment, chrA, chrB, fields), reads[3] = its text
                         if chrA == chrB:
                             if second[-1] < first[-1]:
                                 first, second = second, first
                         elif first[-1] != chrA:
                             first, second = second, first
                         out = first[0:-1] + second[0:-1]
-                        lines[(chrA, chrB, signal[2])] = ("{}\t{}\t{}\t{}\n".format(signal[2], chrA, chrB, "\t".join(map(str, out))), out)
+                        reads.append((signal[2], chrA, chrB, out))
+                        reads.append("{}\t{}\t{}\t{}\n".format(signal[2], chrA, chrB, "\t".join(map(str, out))))
         else:
             tab, lines = early["splits"], early["slines"]
             for signal in rows:
@@ -322,7 +328,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                 if a is not None:
                     f = a[signal[1]].setdefault(signal[2], [])
                     f += signal[3:]
-                    lines[(chrA, signal[1], signal[2])] = "{}\t{}\t{}\t{}\n".format(signal[2], chrA, signal[1], "\t".join(map(str, f)))
+                    lines[chrA][signal[1]][signal[2]] = "{}\t{}\t{}\t{}\n".format(signal[2], chrA, signal[1], "\t".join(map(str, f)))
 
     def rows_of(sel):
         """clip / split / discordant rows of one batch's selected reads (host copies only: runs on the worker thread while the device
@@ -468,7 +474,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     hist.close()
     PREMERGED.clear()
     if early["ok"] and isinstance(reader, DeviceBamReader):
-        PREMERGED["tables"] = (early["data"], early["splits"], data, splits, early["dlines"], early["slines"])   # (keyed to the very lists main() merges)
+        PREMERGED["tables"] = (early["data"], early["splits"], data, splits, early["slines"])   # (keyed to the very lists main() merges)
     return header, chromosomes, coverage, data, splits, clips
 
 
@@ -494,9 +500,9 @@ def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bi
     print("Collecting signals on contig: {}".format(chromosome))
     os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
     path = "{}_tiddit/clips/{}.fa".format(prefix, chromosome)
-    with open(path, "w") as f:
+    with open(path, "wb") as f:
         for clip in clips[chromosome]:
-            f.write("".join(clip))
+            f.write(_clip_bytes(clip))
     return (chromosome, data[chromosome], splits[chromosome], coverage[chromosome], path)
 
 
@@ -512,7 +518,7 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
         splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
     os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
     clip_fasta = []
-    with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "w") as all_clips:      # (written last in the reference; same bytes)
+    with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "wb") as all_clips:      # (written last in the reference; same bytes)
         for chrom in chromosomes:                                            # results in contig order (:262-284)
             print("Collecting signals on contig: {}".format(chrom))
             for signal in (res_data[chrom] if pre is None else ()):
@@ -525,9 +531,9 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                 splits[signal[0]][signal[1]].setdefault(signal[2], [])
                 splits[signal[0]][signal[1]][signal[2]] += signal[3:]
             path = "{}_tiddit/clips/{}.fa".format(prefix, chrom)
-            with open(path, "w") as f:
+            with open(path, "wb") as f:
                 for clip in res_clips[chrom]:
-                    text = "".join(clip)
+                    text = _clip_bytes(clip)
                     f.write(text)
                     all_clips.write(text)                # clips_{sample}.fa is the per-contig files one after the other (:328-332)
             clip_fasta.append(path)
@@ -539,11 +545,11 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
         for chrA in data:
             for chrB in data[chrA]:
                 if pre is not None:                     # the rows were formatted when their second read arrived: same order, same text
-                    dl, frags = pre[4], data[chrA][chrB]
+                    frags = data[chrA][chrB]
                     if frags:
-                        got = [dl[(chrA, chrB, fragment)] for fragment, reads in frags.items() if len(reads) >= 2]
-                        f.write("".join(g[0] for g in got))
-                        disc_rows.extend((fragment, chrA, chrB, dl[(chrA, chrB, fragment)][1]) for fragment, reads in frags.items() if len(reads) >= 2)
+                        rows = [reads[2] for reads in frags.values() if len(reads) > 2]
+                        f.write("".join([reads[3] for reads in frags.values() if len(reads) > 2]))
+                        disc_rows += rows
                     continue
                 for fragment, reads in data[chrA][chrB].items():
                     if len(reads) < 2:
@@ -561,10 +567,10 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
         for chrA in splits:
             for chrB in splits[chrA]:
                 if pre is not None:
-                    sl, frags = pre[5], splits[chrA][chrB]
+                    frags = splits[chrA][chrB]
                     if frags:
-                        f.write("".join(sl[(chrA, chrB, fragment)] for fragment in frags))
-                        split_rows.extend((fragment, chrA, chrB, fields) for fragment, fields in frags.items())
+                        f.write("".join(pre[4][chrA][chrB].values()))
+                        split_rows += [(fragment, chrA, chrB, fields) for fragment, fields in frags.items()]
                     continue
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
@@ -640,7 +646,7 @@ def _main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads
     STAGE_SECONDS["scan (ingest, coverage, predicates, rows; this rank's shard)"] = time.time() - t
     STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
     t1 = time.time()
-    mine = {c: (res_data[c], res_splits[c], ["".join(x) for x in res_clips[c]]) for c in chromosomes
+    mine = {c: (res_data[c], res_splits[c], [_clip_bytes(x) for x in res_clips[c]]) for c in chromosomes
             if res_data[c] or res_splits[c] or res_clips[c]}
     parts = tdist.gather_bytes(pickle.dumps(mine, protocol=4), 0, group)
     STAGE_SECONDS["row gather"] = time.time() - t1
