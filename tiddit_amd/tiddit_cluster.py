@@ -57,13 +57,18 @@ STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 
 def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly):
     """Parse discordants_/splits_/contigs_{sample}.tab in the reference's order (:46-137).
-    -> signals[chrA][chrB] = list of records, positions[chrA][chrB] = list of [posA, posB, i]."""
+    -> signals[chrA][chrB] = list of records, positions[chrA][chrB] = flat list posA, posB, i, posA, posB, i, ... (one array
+    conversion per bucket later, not one per row)."""
     signals, positions = {}, {}
+    pos_of = {}                  # id(record list of a bucket) -> its flat position list
     i = 0
 
     def bucket(chrA, chrB):
-        positions.setdefault(chrA, {}).setdefault(chrB, [])
-        return signals.setdefault(chrA, {}).setdefault(chrB, [])
+        recs = signals.setdefault(chrA, {}).get(chrB)
+        if recs is None:
+            recs = signals[chrA][chrB] = []
+            pos_of[id(recs)] = positions.setdefault(chrA, {}).setdefault(chrB, [])
+        return recs
 
     for sample in samples:
         disc_path, split_path = "{}_tiddit/discordants_{}.tab".format(prefix, sample), "{}_tiddit/splits_{}.tab".format(prefix, sample)
@@ -89,7 +94,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
                     if posB > lenB:
                         posA = lenB                 # QUIRK (:67-70), as below
                 recs.append([frag, sample, "D", posA, oa, posB, ob, i, o[0], o[1], o[3], o[4]])
-                positions[chrA][chrB].append([posA, posB, i])
+                pos_of[id(recs)].extend((posA, posB, i))
                 i += 1
             disc_iter = ()
         else:
@@ -105,7 +110,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
                 if int(posB) > contig_length[chrB]:
                     posA = contig_length[chrB]      # QUIRK (:67-70): posB is never clipped, posA takes chrB's length
             recs.append([c[0], sample, "D", posA, c[5], posB, c[8], i, int(c[3]), int(c[4]), int(c[6]), int(c[7])])
-            positions[chrA][chrB].append([int(posA), int(posB), i])
+            pos_of[id(recs)].extend((int(posA), int(posB), i))
             i += 1
         files = [("S", "{}_tiddit/splits_{}.tab")]
         if not skip_assembly:
@@ -119,7 +124,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
                     recs = bucket(chrA, chrB)
                     posA, posB = min(o[0], lenA), min(o[2], lenB)
                     recs.append([frag, sample, kind, posA, ("True" if o[1] else "False"), posB, ("True" if o[3] else "False"), i, o[4], o[5], o[6], o[7]])
-                    positions[chrA][chrB].append([posA, posB, i])
+                    pos_of[id(recs)].extend((posA, posB, i))
                     i += 1
                 continue
             else:
@@ -135,7 +140,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
                 if int(posB) > contig_length[chrB]:
                     posB = contig_length[chrB]
                 recs.append([c[0], sample, kind, posA, c[4], posB, c[6], i, int(c[7]), int(c[8]), int(c[9]), int(c[10])])
-                positions[chrA][chrB].append([int(posA), int(posB), i])
+                pos_of[id(recs)].extend((int(posA), int(posB), i))
                 i += 1
     return signals, positions
 
@@ -338,7 +343,7 @@ def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_in
     t0 = time.time()
 
     order = [(a, b) for a in chromosomes if a in positions for b in chromosomes if b in positions[a]]
-    bucket_arrays = [numpy.array(positions[a][b], dtype=numpy.int64) for a, b in order]
+    bucket_arrays = [numpy.array(positions[a][b], dtype=numpy.int64).reshape(-1, 3) for a, b in order]
     try:
         import torch.distributed as _dist
         sharded = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
@@ -363,9 +368,7 @@ def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_in
         recs = signals[chrA][chrB]
         n_sig = len(recs)
         n_ctg_clusters = 0
-        for j in range(n_sig):         # signal-index order == file order inside the bucket (:160)
-            rec = recs[j]
-            cid = int(lab[j])
+        for rec, cid in zip(recs, lab.astype(numpy.int64).tolist()):         # signal-index order == file order inside the bucket (:160)
             if cid == -1:
                 lone_contig = chrA == chrB and rec[2] == "A" and (int(rec[5]) - int(rec[3])) < max_ins_len * 2
                 if not lone_contig:

@@ -609,6 +609,10 @@ def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_co
     _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id)
     print("total", time.time() - t)
     STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
+    t1 = time.time()
+    del res_data, res_splits, res_clips
+    STAGE_SECONDS["free the row lists"] = time.time() - t1
+    STAGE_SECONDS["_end"] = time.time()
     return coverage_data
 
 
@@ -677,4 +681,6 @@ def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_con
     """``tiddit_signal.main`` (tiddit_signal.pyx:230-334): signals of every contig -> discordants_/splits_ .tab, clips_ .fa; returns the
     50-bp coverage dictionary.  (The collector is off while the row tables are built: hostutil.quiet_gc.)"""
     with quiet_gc():
-        return _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len)
+        coverage_data = _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len)
+    STAGE_SECONDS["collector back on"] = time.time() - STAGE_SECONDS.pop("_end")
+    return coverage_data
