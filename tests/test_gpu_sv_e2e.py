@@ -55,6 +55,14 @@ def test_candidates_whole_dictionary(run):
                                fx["library"]["percentile_insert_size"], P["min_contig"], True, P["min_reads"])
     assert cluster_oracle.summary(cand) == fx["candidates"]
     assert h(cluster_oracle.canonical(cand)) == fx["candidates_sha256"]
+    # ... through either way in: the rows the signal stage of this process left behind (the CLI's own path), and the .tab text
+    from tiddit_amd import tiddit_signal
+    had = tiddit_signal.written_tables(out + "_tiddit/discordants_WGS.tab", out + "_tiddit/splits_WGS.tab") is not None
+    tiddit_signal.WRITTEN_TABLES.clear()
+    text = tiddit_cluster.main(out, names, dict(contigs), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"],
+                               fx["library"]["percentile_insert_size"], P["min_contig"], True, P["min_reads"])
+    assert h(cluster_oracle.canonical(text)) == fx["candidates_sha256"]
+    assert had or os.environ.get("TIDDIT_HOST_INGEST") == "1", "the signal stage's rows were not there for tiddit_cluster.main"
     # what the CLI wrote is the same table
     rows = [l.rstrip("\n").split("\t") for l in open(out + ".candidates.tab") if not l.startswith("#")]
     want = [[r[0], str(r[3]), r[1], str(r[4]), str(r[2])] + [str(x) for x in r[5:]] for r in fx["candidates"]]

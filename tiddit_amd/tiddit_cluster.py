@@ -81,21 +81,28 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
             # str() / int() round trip (positions stay ints — every later use converts with int() anyway; orientations become the text's words)
             side = _MP_SIDE if is_mp else _PE_SIDE
             default = (4, 6) if is_mp else (3, 7)
-            for frag, chrA, chrB, o in cached[0]:
+            words = ("False", "True")
+            pick = []                                   # [revA * 2 + revB] -> (word A, word B, index of posA in the fields, ... of posB)
+            for ra in (0, 1):
+                for rb in (0, 1):
+                    ia, ib = side.get((words[ra], words[rb]), default)
+                    pick.append((words[ra], words[rb], ia - 3, ib - 3))
+            for chrA, chrB, rows in cached[0]:          # the rows of one contig pair, in file order
                 lenA, lenB = contig_length[chrA], contig_length[chrB]
                 if lenA < min_contig or lenB < min_contig:
                     continue
                 recs = bucket(chrA, chrB)
-                oa, ob = ("True" if o[2] else "False"), ("True" if o[5] else "False")
-                a, b = side.get((oa, ob), default)
-                posA, posB = o[a - 3], o[b - 3]
-                if posA > lenA:
-                    posA = lenA
-                    if posB > lenB:
-                        posA = lenB                 # QUIRK (:67-70), as below
-                recs.append([frag, sample, "D", posA, oa, posB, ob, i, o[0], o[1], o[3], o[4]])
-                pos_of[id(recs)].extend((posA, posB, i))
-                i += 1
+                add, pos = recs.append, pos_of[id(recs)].extend
+                for frag, _, _, o in rows:
+                    oa, ob, ia, ib = pick[o[2] * 2 + o[5]]
+                    posA, posB = o[ia], o[ib]
+                    if posA > lenA:
+                        posA = lenA
+                        if posB > lenB:
+                            posA = lenB                 # QUIRK (:67-70), as below
+                    add([frag, sample, "D", posA, oa, posB, ob, i, o[0], o[1], o[3], o[4]])
+                    pos((posA, posB, i))
+                    i += 1
             disc_iter = ()
         else:
             disc_iter = (line.rstrip().split("\t") for line in open(disc_path))
@@ -117,15 +124,17 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
             files.append(("A", "{}_tiddit/contigs_{}.tab"))
         for kind, pattern in files:
             if kind == "S" and cached is not None:
-                for frag, chrA, chrB, o in cached[1]:
+                for chrA, chrB, rows in cached[1]:
                     lenA, lenB = contig_length[chrA], contig_length[chrB]
                     if lenA < min_contig or lenB < min_contig:
                         continue
                     recs = bucket(chrA, chrB)
-                    posA, posB = min(o[0], lenA), min(o[2], lenB)
-                    recs.append([frag, sample, kind, posA, ("True" if o[1] else "False"), posB, ("True" if o[3] else "False"), i, o[4], o[5], o[6], o[7]])
-                    pos_of[id(recs)].extend((posA, posB, i))
-                    i += 1
+                    add, pos = recs.append, pos_of[id(recs)].extend
+                    for frag, o in rows.items():
+                        posA, posB = min(o[0], lenA), min(o[2], lenB)
+                        add([frag, sample, kind, posA, ("True" if o[1] else "False"), posB, ("True" if o[3] else "False"), i, o[4], o[5], o[6], o[7]])
+                        pos((posA, posB, i))
+                        i += 1
                 continue
             else:
                 rows_iter = (line.rstrip().split("\t") for line in open(pattern.format(prefix, sample)))

@@ -539,7 +539,9 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
             clip_fasta.append(path)
     print("Writing signals to file")
 
-    disc_rows, split_rows = [], []        # the rows as written: tiddit_cluster in the same process takes them from here (no text re-parse)
+    # the rows as written, per contig pair in file order: tiddit_cluster in the same process takes them from here (no text re-parse).
+    # disc_rows: (chrA, chrB, [(fragment, chrA, chrB, fields), ...]); split_rows: (chrA, chrB, {fragment: fields})
+    disc_rows, split_rows = [], []
     disc_path, split_path = "{}_tiddit/discordants_{}.tab".format(prefix, sample_id), "{}_tiddit/splits_{}.tab".format(prefix, sample_id)
     with open(disc_path, "w") as f:      # :298-318
         for chrA in data:
@@ -549,8 +551,9 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                     if frags:
                         rows = [reads[2] for reads in frags.values() if len(reads) > 2]
                         f.write("".join([reads[3] for reads in frags.values() if len(reads) > 2]))
-                        disc_rows += rows
+                        disc_rows.append((chrA, chrB, rows))
                     continue
+                rows = []
                 for fragment, reads in data[chrA][chrB].items():
                     if len(reads) < 2:
                         continue
@@ -562,7 +565,9 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                         first, second = second, first
                     out = first[0:-1] + second[0:-1]
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, out))))
-                    disc_rows.append((fragment, chrA, chrB, out))
+                    rows.append((fragment, chrA, chrB, out))
+                if rows:
+                    disc_rows.append((chrA, chrB, rows))
     with open(split_path, "w") as f:           # :320-326
         for chrA in splits:
             for chrB in splits[chrA]:
@@ -570,11 +575,12 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                     frags = splits[chrA][chrB]
                     if frags:
                         f.write("".join(pre[4][chrA][chrB].values()))
-                        split_rows += [(fragment, chrA, chrB, fields) for fragment, fields in frags.items()]
+                        split_rows.append((chrA, chrB, frags))
                     continue
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
-                    split_rows.append((fragment, chrA, chrB, fields))
+                if splits[chrA][chrB]:
+                    split_rows.append((chrA, chrB, splits[chrA][chrB]))
     WRITTEN_TABLES.clear()
     WRITTEN_TABLES[(os.path.abspath(disc_path), os.path.abspath(split_path))] = (_file_stamp(disc_path), _file_stamp(split_path), disc_rows, split_rows)
 
@@ -586,7 +592,8 @@ def _file_stamp(path):
 
 def written_tables(disc_path, split_path):
     """the (discordant, split) rows of the last `main` of THIS process if the two files on disk are still the ones it wrote
-    (size, mtime, inode) — else None, and the caller parses the text.  Rows: (fragment, chrA, chrB, fields as written, not yet str)."""
+    (size, mtime, inode) — else None, and the caller parses the text.  Per contig pair in file order: discordants
+    (chrA, chrB, [(fragment, chrA, chrB, fields as written, not yet str), ...]), splits (chrA, chrB, {fragment: fields})."""
     ent = WRITTEN_TABLES.get((os.path.abspath(disc_path), os.path.abspath(split_path)))
     if ent is None:
         return None
