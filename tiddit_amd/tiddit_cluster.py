@@ -89,7 +89,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
                     pick.append((words[ra], words[rb], ia - 3, ib - 3))
             for chrA, chrB, rows in cached[0]:          # the rows of one contig pair, in file order
                 lenA, lenB = contig_length[chrA], contig_length[chrB]
-                if lenA < min_contig or lenB < min_contig:
+                if lenA < min_contig or lenB < min_contig or not rows:
                     continue
                 recs = bucket(chrA, chrB)
                 add, pos = recs.append, pos_of[id(recs)].extend
@@ -126,7 +126,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
             if kind == "S" and cached is not None:
                 for chrA, chrB, rows in cached[1]:
                     lenA, lenB = contig_length[chrA], contig_length[chrB]
-                    if lenA < min_contig or lenB < min_contig:
+                    if lenA < min_contig or lenB < min_contig or not rows:
                         continue
                     recs = bucket(chrA, chrB)
                     add, pos = recs.append, pos_of[id(recs)].extend

@@ -551,7 +551,8 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                     if frags:
                         rows = [reads[2] for reads in frags.values() if len(reads) > 2]
                         f.write("".join([reads[3] for reads in frags.values() if len(reads) > 2]))
-                        disc_rows.append((chrA, chrB, rows))
+                        if rows:
+                            disc_rows.append((chrA, chrB, rows))
                     continue
                 rows = []
                 for fragment, reads in data[chrA][chrB].items():
