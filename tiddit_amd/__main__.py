@@ -200,6 +200,25 @@ def run_sv(args, version):
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
     T["library statistics"] = time.time() - t
 
+    # The GC / N-mask bins depend on the reference FASTA alone (the reference computes them after the signals, __main__.py:166):
+    # a second host thread with its own library context (own streams and scratch) reads the FASTA and runs the GC kernel while the
+    # BAM is scanned — the scan waits on the inflate kernel, the GC pass on the page cache and PCIe.  TIDDIT_GC_OVERLAP=0: in sequence.
+    gc_job = None
+    if rank == 0 and os.environ.get("TIDDIT_GC_OVERLAP", "1") != "0":
+        import threading
+        from . import _native
+        gc_job = {"t0": time.time()}
+
+        def gc_thread():
+            try:
+                ctx = _native.Context(_native.default_context().device)
+                fasta = FastaFile(args.ref)
+                gc_job["result"] = {c: tiddit_gc.binned_gc(fasta, c, 50, 0.5, ctx=ctx)[1] for c in chromosomes}
+            except BaseException as e:           # re-raised on the main thread
+                gc_job["error"] = e
+            gc_job["seconds"] = time.time() - gc_job["t0"]
+        gc_job["thread"] = threading.Thread(target=gc_thread, name="tiddit-gc")
+        gc_job["thread"].start()
     t = time.time()
     with stage("tiddit: signal extraction + coverage"):
         signal_main = tiddit_signal.main_sharded if world > 1 else tiddit_signal.main
@@ -213,8 +232,16 @@ def run_sv(args, version):
     if rank == 0:
         t = time.time()
         with stage("tiddit: GC bins"):
-            gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
+            if gc_job is None:
+                gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
+            else:
+                gc_job["thread"].join()
+                if "error" in gc_job:
+                    raise gc_job["error"]
+                gc_dictionary = gc_job["result"]
         T["GC bins"] = time.time() - t
+        if gc_job is not None:
+            T["  GC bins, on their own thread beside the scan"] = gc_job["seconds"]
         t = time.time()
         with stage("tiddit: ploidy"):
             library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,
