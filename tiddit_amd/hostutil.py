@@ -11,19 +11,29 @@ def quiet_gc():
     stage left alive (the rows the next stage reads) moves to the permanent generation, or the first allocation after ``gc.enable()``
     starts a full collection over all of it (0.25 s at 240 M reads, 0.8 s at 600 M).  Frozen objects are still freed by their
     reference counts; :func:`thaw` hands them back to the collector (a long-lived host that wants cycles among them found)."""
+    global _FROZEN
     was = gc.isenabled()
     gc.disable()
+    if _FROZEN:                  # what the previous stage froze goes back to the collector's lists: at most one stage's leftovers are
+        gc.unfreeze()            # ever exempt from collection (nothing walks them while the collector is off)
+        _FROZEN = False
     try:
         yield
     finally:
         if was:
             gc.freeze()
+            _FROZEN = True
             gc.enable()
+
+
+_FROZEN = False
 
 
 def thaw():
     """undo the ``gc.freeze()`` of :func:`quiet_gc`"""
+    global _FROZEN
     gc.unfreeze()
+    _FROZEN = False
 
 
 class PinnedPool:

@@ -245,8 +245,9 @@ def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
 def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None):
     """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
     split rows, clip FASTA entries).  The discordant and split rows are what ``worker`` returns (:228); the clip entries
-    are ``[text, ""]`` pairs whose joined text is the contig's clip FASTA in file order (one entry per read with the host
-    ingest, one per contig run of a batch with the device ingest — ``"".join`` is what every consumer does, :223-226).
+    are pairs whose joined content is the contig's clip FASTA in file order: ``[header, sequence + "\n"]`` strings, one per read,
+    with the host ingest; ``[bytes, ""]``, one per contig run of a batch, already formatted by ``tdt_format_clips``, with the
+    device ingest.  ``_clip_bytes(entry)`` gives the bytes of either — joining is what every consumer does (:223-226).
 
     shard = (rank, world): only the records that start in this rank's byte range of the file (bamio.DeviceBamReader); the
     seam offsets are left in ``LAST_SEAM`` for dist.check_seams.  reduce_bins(hist) -> float64 array of ALL the histogram's
