@@ -984,10 +984,13 @@ def sv_e2e(args, ctx, with_oracle, rank=0, world=1, local_rank=0, barrier=lambda
         barrier()                                                   # the job is done when its slowest rank is
         walls.append(time.perf_counter() - t0)
         stages = dict(cli.STAGE_SECONDS)
+        if rep == 0:
+            first_stages = stages
     if rank != 0:
         return None
     res = {"metric": "tiddit --sv --skip_assembly end to end (BAM file -> candidates table), wall seconds", "wall_s": walls[-1],
            "first_pass_wall_s": walls[0], "stage_seconds": {k: round(v, 4) for k, v in stages.items()},
+           "first_pass_stage_seconds": {k: round(v, 4) for k, v in first_stages.items()},      # (a fresh process: allocations, first touches)
            "config": {"workload": "BASELINE configs[3]: %d-Mb genome (24 chromosomes + chrM + 2 scaffolds), 30x 150-bp pairs, planted DEL/DUP/INV/BND at 3 per Mb; "
                                   "%.0f MB BAM (zlib level 1, reads cut from the reference), file in the page cache%s" % (mb, os.path.getsize(bam) / 1e6,
                                   "" if world == 1 else "; ONE job on %d ranks: byte-range shards of the file, rows gathered on rank 0, buckets packed / cut over the ranks" % world)},
