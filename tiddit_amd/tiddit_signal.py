@@ -242,6 +242,65 @@ def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
     return out[:cnt.value]
 
 
+class EarlyTables:
+    """The (chrA, chrB, fragment) dictionaries of tiddit_signal.main (:246-284), filled WHILE the file is scanned.
+
+    main() walks the contigs in header order and, inside a contig, its rows in file order.  On a coordinate-sorted file whose contig
+    order is the header's that IS the order in which ``scan_signals`` produces rows, so a batch's rows can be merged as soon as they
+    exist — on the worker thread, behind the device ingest of the next batch — and main() finds the dictionaries ready.  A row out
+    of contig order switches the early merge off (``ok`` False); main() then merges the per-contig lists as before.
+
+    ``data[chrA][chrB][fragment]`` = the fragment's reads (each ``row[3:]``) as in the reference, and — once the second read has
+    arrived, i.e. the row of :298-318 is complete — two more entries: ``(fragment, chrA, chrB, fields as written)`` and the text line.
+    ``splits[chrA][chrB][fragment]`` = the concatenated fields (:282); ``slines[..]`` = the line as main() writes it."""
+
+    def __init__(self, all_contigs, kept_contigs, enabled=True):
+        self.ok = bool(enabled)
+        self.rank_of = {c: i for i, c in enumerate(kept_contigs)}          # chromosomes of main(): the contigs of at least min_contig, in header order
+        self.last = {"d": -1, "s": -1}
+        self.data = {a: {b: {} for b in all_contigs} for a in self.rank_of}
+        self.splits = {a: {b: {} for b in all_contigs} for a in self.rank_of}
+        self.slines = {a: {b: {} for b in all_contigs} for a in self.rank_of}
+
+    def add(self, chrom, rows, which):
+        """rows of contig `chrom` (file order), which = "d" (discordant rows of worker, :214-221) or "s" (split rows)"""
+        r = self.rank_of.get(chrom)
+        if r is None or not self.ok:
+            return
+        if r < self.last[which]:
+            self.ok = False
+            return
+        self.last[which] = r
+        if which == "d":
+            tab = self.data
+            for signal in rows:
+                chrA = signal[0]
+                a = tab.get(chrA)
+                if a is not None:
+                    chrB = signal[1]
+                    reads = a[chrB].setdefault(signal[2], [])
+                    reads.append(signal[3:])
+                    if len(reads) == 2:
+                        first, second = reads
+                        if chrA == chrB:
+                            if second[-1] < first[-1]:           # QUIRK (:307): compares the two read_chr strings, always equal
+                                first, second = second, first
+                        elif first[-1] != chrA:
+                            first, second = second, first
+                        out = first[0:-1] + second[0:-1]
+                        reads.append((signal[2], chrA, chrB, out))
+                        reads.append("{}\t{}\t{}\t{}\n".format(signal[2], chrA, chrB, "\t".join(map(str, out))))
+        else:
+            tab, lines = self.splits, self.slines
+            for signal in rows:
+                chrA = signal[0]
+                a = tab.get(chrA)
+                if a is not None:
+                    f = a[signal[1]].setdefault(signal[2], [])
+                    f += signal[3:]
+                    lines[chrA][signal[1]][signal[2]] = "{}\t{}\t{}\t{}\n".format(signal[2], chrA, signal[1], "\t".join(map(str, f)))
+
+
 def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None):
     """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
     split rows, clip FASTA entries).  The discordant and split rows are what ``worker`` returns (:228); the clip entries
@@ -280,56 +339,9 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
     T.clear()
     T.update({"ingest (inflate + decode, device)": 0.0, "coverage push": 0.0, "field copies + predicates (host)": 0.0, "clip rows": 0.0,
               "split rows": 0.0, "discordant select + rows": 0.0})
-    # The merge of tiddit_signal.main (:262-284) walks the contigs in order and, inside a contig, the rows in file order.  On a
-    # coordinate-sorted file whose contig order is the header's that IS the file order, so the rows of a batch can be merged into the
-    # (chrA, chrB, fragment) dictionaries as soon as they exist — on the worker thread, behind the device ingest of the next batch —
-    # and main() finds the dictionaries ready.  A row out of contig order switches the early merge off; main() then merges the
-    # per-contig lists as before.
-    all_contigs = list(names)
-    rank_of = {}
-    for t, ok in enumerate(big):
-        if ok:
-            rank_of[names[t]] = len(rank_of)
-    early = {"ok": shard is None, "last_d": -1, "last_s": -1,
-             "data": {a: {b: {} for b in all_contigs} for a in rank_of}, "splits": {a: {b: {} for b in all_contigs} for a in rank_of},
-             "slines": {a: {b: {} for b in all_contigs} for a in rank_of}}   # fragment -> the split row as main() writes it
-
-    def merge_early(chrom, rows, which):
-        r = rank_of.get(chrom)
-        if r is None or not early["ok"]:
-            return
-        if r < early["last_" + which]:
-            early["ok"] = False
-            return
-        early["last_" + which] = r
-        if which == "d":
-            tab = early["data"]
-            for signal in rows:
-                chrA = signal[0]
-                a = tab.get(chrA)
-                if a is not None:
-                    chrB = signal[1]
-                    reads = a[chrB].setdefault(signal[2], [])
-                    reads.append(signal[3:])
-                    if len(reads) == 2:                          # the row of :298-318 is complete with the fragment's second read:
-                        first, second = reads                    # reads[2] = (fragment, chrA, chrB, fields), reads[3] = its text
-                        if chrA == chrB:
-                            if second[-1] < first[-1]:
-                                first, second = second, first
-                        elif first[-1] != chrA:
-                            first, second = second, first
-                        out = first[0:-1] + second[0:-1]
-                        reads.append((signal[2], chrA, chrB, out))
-                        reads.append("{}\t{}\t{}\t{}\n".format(signal[2], chrA, chrB, "\t".join(map(str, out))))
-        else:
-            tab, lines = early["splits"], early["slines"]
-            for signal in rows:
-                chrA = signal[0]
-                a = tab.get(chrA)
-                if a is not None:
-                    f = a[signal[1]].setdefault(signal[2], [])
-                    f += signal[3:]
-                    lines[chrA][signal[1]][signal[2]] = "{}\t{}\t{}\t{}\n".format(signal[2], chrA, signal[1], "\t".join(map(str, f)))
+    # the per-fragment merge of main() runs while the file is scanned (EarlyTables)
+    early = EarlyTables(list(names), [names[t] for t, ok in enumerate(big) if ok], enabled=shard is None)
+    merge_early = early.add
 
     def rows_of(sel):
         """clip / split / discordant rows of one batch's selected reads (host copies only: runs on the worker thread while the device
@@ -349,9 +361,9 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         runs4 = [] if not len(which4) else [int(t) for t in tids4[numpy.concatenate([[0], numpy.flatnonzero(numpy.diff(tids4)) + 1])]]
         before = {t: len(splits[names[t]]) for t in set(runs4)}
         split_rows_native(sel, which4, names, min_q, splits)
-        if early["ok"]:
+        if early.ok:
             if len(set(runs4)) != len(runs4):
-                early["ok"] = False                              # a contig twice in one batch: not coordinate sorted
+                early.ok = False                                 # a contig twice in one batch: not coordinate sorted
             for t in runs4:
                 merge_early(names[t], splits[names[t]][before[t]:], "s")
         t6 = time.time()
@@ -474,8 +486,8 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                 coverage[n] = allbins[o:o + hist.nbins(i)[0]].copy()
     hist.close()
     PREMERGED.clear()
-    if early["ok"] and isinstance(reader, DeviceBamReader):
-        PREMERGED["tables"] = (early["data"], early["splits"], data, splits, early["slines"])   # (keyed to the very lists main() merges)
+    if early.ok and isinstance(reader, DeviceBamReader):
+        PREMERGED["tables"] = (early.data, early.splits, data, splits, early.slines)   # (keyed to the very lists main() merges)
     return header, chromosomes, coverage, data, splits, clips
 
 
