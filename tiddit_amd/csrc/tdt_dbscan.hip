@@ -484,9 +484,11 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         unsigned *t_flags = (unsigned *)ts;
         unsigned *t_grp0 = (unsigned *)((char *)ts + sz_flags);
         unsigned *t_grp1 = (unsigned *)((char *)ts + sz_flags + sz_grp);
-        rc = tdt_scratch(ctx, 21, 4 * sz_b + 2 * sz_agg, &tb);
+        const size_t sz_code = db_align((size_t)n * 2 + 16);
+        rc = tdt_scratch(ctx, 21, 4 * sz_b + 2 * sz_agg + sz_code, &tb);
         if (rc) return rc;
         char *q = (char *)tb;
+        unsigned short *t_code = (unsigned short *)q; q += sz_code;
         unsigned *t_brun = (unsigned *)q; q += sz_b;
         unsigned *t_bext = (unsigned *)q; q += sz_b;
         unsigned *t_aggR = (unsigned *)q; q += sz_agg;
@@ -511,7 +513,7 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         TP.eps32 = eps > 0xffffffffull ? 0xffffffffu : (unsigned)eps;
         TP.wide = eps > 0xffffffffull;
         TP.m = m;
-        TP.lab = (unsigned long long *)d_labels;
+        TP.code = t_code;
         TP.aggR = t_aggR;
         TP.aggE = t_aggE;
         TP.brun = t_brun;
@@ -534,12 +536,13 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         TDT_CHECK_LAUNCH();
         if (nb == 1) {
             ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
-            hipLaunchKernelGGL(dbt_finish1, dim3((ntt + DT_FTPB - 1) / DT_FTPB), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
-                               (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, 0ll, 0, t_flags, hw, seq);
+            hipLaunchKernelGGL(dbt_finish1, dim3((ntt + DT_FTPB - 1) / DT_FTPB), dim3(256), 0, st, (const unsigned short *)t_code, d_labels, n, (const int *)nullptr,
+                               (const unsigned *)t_aggR, (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max,
+                               (long long *)d_last_id, 0ll, 0, t_flags, hw, seq);
         } else {
             hipLaunchKernelGGL(dbt_scan, dim3(1), dim3(1024), 0, st, t_aggR, t_aggE, ntt, (const int *)d_boff, nb, n, (const unsigned *)t_brun,
                                (const unsigned *)t_bext, t_runbase, t_extbase, (long long *)d_last_id, mode, t_flags, hw, seq);
-            hipLaunchKernelGGL(dbt_finish, dim3((n + 511) / 512), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR,
+            hipLaunchKernelGGL(dbt_finish, dim3((n + 1023) / 1024), dim3(256), 0, st, (const unsigned short *)t_code, d_labels, n, (const unsigned *)t_aggR,
                                (const unsigned *)t_aggE, (const int *)d_boff, nb, (const unsigned *)t_runbase, (const unsigned *)t_extbase);
         }
         TDT_CHECK_LAUNCH();
@@ -779,8 +782,10 @@ extern "C" int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const ui
     void *ts = nullptr, *tb = nullptr;
     int rc = tdt_scratch(ctx, 20, sz_flags + 2 * sz_grp, &ts);
     if (rc) return rc;
-    rc = tdt_scratch(ctx, 21, 2 * sz_agg + 1024, &tb);
+    const size_t sz_code = db_align((size_t)n * 2 + 16);
+    rc = tdt_scratch(ctx, 21, 2 * sz_agg + 1024 + sz_code, &tb);
     if (rc) return rc;
+    unsigned short *t_code = (unsigned short *)((char *)tb + 2 * sz_agg + 1024);
     unsigned *t_flags = (unsigned *)ts;
     unsigned *t_grp0 = (unsigned *)((char *)ts + sz_flags), *t_grp1 = (unsigned *)((char *)ts + sz_flags + sz_grp);
     unsigned *t_aggR = (unsigned *)tb, *t_aggE = (unsigned *)((char *)tb + sz_agg);
@@ -798,7 +803,7 @@ extern "C" int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const ui
     TP.eps32 = eps > 0xffffffffull ? 0xffffffffu : (unsigned)eps;
     TP.wide = eps > 0xffffffffull;
     TP.m = m;
-    TP.lab = (unsigned long long *)d_labels;
+    TP.code = t_code;
     TP.aggR = t_aggR;
     TP.aggE = t_aggE;
     TP.brun = TP.bext = nullptr;
@@ -814,9 +819,9 @@ extern "C" int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const ui
     hw[1] = 0;
     hipLaunchKernelGGL((dbt_tile<true, false, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
     ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
-    hipLaunchKernelGGL(dbt_finish1, dim3((ntt + DT_FTPB - 1) / DT_FTPB), dim3(256), 0, st, (unsigned long long *)d_labels, n, (const unsigned *)t_aggR, (const unsigned *)t_aggE,
-                       ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max, (long long *)d_last_id, (long long)cluster_id, 1,
-                       t_flags, hw, seq);
+    hipLaunchKernelGGL(dbt_finish1, dim3((ntt + DT_FTPB - 1) / DT_FTPB), dim3(256), 0, st, (const unsigned short *)t_code, d_labels, n, (const int *)d_xlab,
+                       (const unsigned *)t_aggR, (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max,
+                       (long long *)d_last_id, (long long)cluster_id, 1, t_flags, hw, seq);
     TDT_CHECK_LAUNCH();
     bool seen = false;
     for (long spin = 0; spin < 4000000; spin++) {

@@ -9,8 +9,8 @@
 //   dbt_tile    a workgroup stages DT_NW words (1536 points) of x and y, OWNS the x-clusters that start in all but its last two words
 //               (a cluster may run on into the two halo words: it has at most DB_SMALL = 128 members) and computes for them
 //               the window masks p (DBSCAN.py:41-51), runs / labelled masks (:52-62), the stable y order of every cluster
-//               (:76-81), the y window masks (:90-99), sub-run starts and sub-run numbers (:101-110).  Every point gets its
-//               final -1.0 or an 8-byte CODE written into the label array: (kind, owner-tile flag, tile-local index).
+//               (:76-81), the y window masks (:90-99), sub-run starts and sub-run numbers (:101-110).  Every point gets a
+//               2-byte CODE in a side array: -1, or (kind, owner-tile flag, tile-local index).
 //               Per tile it leaves two counts: x-runs started, extra sub-runs.
 //               (The first workgroup of the NEXT launch stores the word that tells the host whether a cluster was too large for
 //               this path into pinned memory: no extra launch, no stream synchronisation, no per-workgroup fence.)
@@ -34,9 +34,13 @@
 #define DT_T (DT_OW * 64)                   // 1408 owned positions
 #define DT_WPW (DT_NW / DT_WAVES)           // words per wave
 #define DT_XS (DT_S + 64 + DBF_M_MAX + 8)   // x staged for [t0-64, t0+S+m+...)
-#define DT_CODE_PREV (1ull << 62)           // the position belongs to the NEXT tile's range: its owner is tile(position) - 1
-#define DT_CODE_EXTRA (1ull << 61)          // index counts extra sub-run starts (else: x-run index)
-#define DT_CODE_LITERAL (1ull << 60)        // the low word IS the id (caller-supplied x labels)
+// a point's 2-byte CODE between the tile kernel and the finish kernel (its own array: 2 B/point written and read once, the
+// float64 labels written once):
+#define DT_C_MINUS1 0xffffu                 // label -1.0
+#define DT_C_PREV 0x4000u                   // the position belongs to the NEXT tile's range: its owner is tile(position) - 1
+#define DT_C_EXTRA 0x2000u                  // index counts extra sub-run starts (else: x-run index)
+#define DT_C_LITERAL 0x1000u                // the id is the caller-supplied x label of the position
+#define DT_C_INDEX 0x0fffu                  // tile-local index (x-runs / extra starts of a tile: at most DT_S / 2)
 #define DT_MINUS1 0xbff0000000000000ull     // bits of -1.0
 #define DT_GRP 64                           // tiles per group of the two-level count sums (one-bucket path)
 #define DT_GRPMAX (0x7fffffff / (DT_GRP * DT_T) + 2)   // groups of tiles a call can have (n < 2^31)
@@ -58,7 +62,7 @@ struct DtParams {
     unsigned eps32;
     int wide;                 // eps > 2^32-1: every 32-bit distance qualifies
     int m;
-    unsigned long long *lab;  // n words: codes or -1.0
+    unsigned short *code;     // n codes (DT_C_*)
     unsigned *aggR, *aggE;    // per tile: x-runs started in the owned words, extra sub-run starts of the owned clusters
     unsigned *brun, *bext;    // per bucket whose first point lies in the tile: the two counts in front of that point
     unsigned *flags;          // [0] != 0: some x-cluster is too large for this path
@@ -315,12 +319,10 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // ---- lane = point: cluster ids and extents.  cid = index (1-based) of the point's cluster among the runs started in the
     // staged range; 1..n_owned are this tile's.  Packed per point for the later steps: cid << 1 | labelled.
     unsigned info[DT_WPW];
-    unsigned labv[LABELS ? DT_WPW : 1];
 #pragma unroll
     for (int s = 0; s < DT_WPW; s++) {
         const int W = wave * DT_WPW + s;
         const int q = 64 * W + lane;
-        if (LABELS) labv[s] = xs[q + 64];
         const ull st = dbf_uni(ST[W]), f = dbf_uni(FM[W]), tl = dbf_uni(TL[W]);
         const unsigned cid = runBase[W] + dbf_cnt_le(st, lane);
         const bool lab = (f >> lane) & 1ull;
@@ -332,8 +334,8 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (mine && q == DT_S - 1) atomicOr(P.flags, 1u);     // the cluster may run past the staged range: not this path's case
             const int g = t0 + q;
             if (g < n) {
-                if (mine) P.lab[g] = (q >= DT_T ? DT_CODE_PREV : 0ull) | (ull)(cid - 1);
-                else if (!lab && q < DT_T) P.lab[g] = DT_MINUS1;
+                if (mine) P.code[g] = (unsigned short)((q >= DT_T ? DT_C_PREV : 0u) | (cid - 1));
+                else if (!lab && q < DT_T) P.code[g] = (unsigned short)DT_C_MINUS1;
             }
         }
     }
@@ -486,15 +488,15 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         if (ext[s]) {
             const unsigned dq = ordl[q];                       // the point sorted to position q
             const int g = t0 + (int)dq;
-            ull code = DT_MINUS1;
+            unsigned code = DT_C_MINUS1;
             if ((FY[W] >> lane) & 1ull) {
-                const ull prevf = dq >= DT_T ? DT_CODE_PREV : 0ull;
-                if (sub[s] == 1) code = LABELS ? (DT_CODE_LITERAL | (ull)labv[s]) : (prevf | (ull)((info[s] >> 1) - 1u));   // sub-run 1 keeps the x id
-                else code = prevf | DT_CODE_EXTRA | (ull)(extBase[W] + dbf_cnt_le(EB[W], lane));  // k-th extra start of the bucket
+                const unsigned prevf = dq >= DT_T ? DT_C_PREV : 0u;
+                if (sub[s] == 1) code = LABELS ? DT_C_LITERAL : (prevf | ((info[s] >> 1) - 1u));   // sub-run 1 keeps the x id
+                else code = prevf | DT_C_EXTRA | (extBase[W] + dbf_cnt_le(EB[W], lane));           // k-th extra start of the bucket
             }
-            P.lab[g] = code;
+            P.code[g] = (unsigned short)code;
         } else if (!info[s] && q < DT_T && t0 + q < n && !((FM[W] >> lane) & 1ull)) {
-            P.lab[t0 + q] = DT_MINUS1;                          // not in any x-cluster
+            P.code[t0 + q] = (unsigned short)DT_C_MINUS1;       // not in any x-cluster
         }
     }
     DT_MARK(11);
@@ -573,53 +575,46 @@ __global__ __launch_bounds__(1024) void dbt_scan(unsigned *aggR, unsigned *aggE,
             last_id[b] = (long long)(runbase[b + 1] - runbase[b]) - 1 + (xonly ? 0ll : (long long)(extbase[b + 1] - extbase[b]));
 }
 
-__global__ __launch_bounds__(256) void dbt_finish(unsigned long long *__restrict__ lab, int n, const unsigned *__restrict__ preR,
-                                                  const unsigned *__restrict__ preE, const int *__restrict__ boff, int nb,
-                                                  const unsigned *__restrict__ runbase, const unsigned *__restrict__ extbase) {
-    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+__global__ __launch_bounds__(256) void dbt_finish(const unsigned short *__restrict__ code, double *__restrict__ lab, int n,
+                                                  const unsigned *__restrict__ preR, const unsigned *__restrict__ preE,
+                                                  const int *__restrict__ boff, int nb, const unsigned *__restrict__ runbase,
+                                                  const unsigned *__restrict__ extbase) {
+    // four points per thread: 8 bytes of codes in, 32 bytes of labels out (n and the arrays' alignment permitting)
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
-    ull w[2];
-    const bool two = i0 + 2 <= n && (((size_t)lab) & 15) == 0;
-    if (!two && i0 + 1 < n) {          // unaligned label array: element-wise
-        for (int k = 0; k < 2; k++) {
-            const int i = i0 + k;
-            const ull c = lab[i];
-            if (c >> 63) continue;
-            const int t = i / DT_T - (int)((c >> 62) & 1ull);
-            const int b = db_bucket(boff, nb, i);
-            const unsigned rb = runbase[b];
-            const double id = (c & DT_CODE_EXTRA) ? (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + (unsigned)c - extbase[b]))
-                                                  : (double)(preR[t] + (unsigned)c - rb);
-            lab[i] = (ull)__double_as_longlong(id);
-        }
-        return;
-    }
-    if (two) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lab + i0);
-        w[0] = v.x;
-        w[1] = v.y;
+    unsigned c[4];
+    const bool four = i0 + 4 <= n;
+    if (four) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(code + i0);
+        c[0] = v.x & 0xffffu;
+        c[1] = v.x >> 16;
+        c[2] = v.y & 0xffffu;
+        c[3] = v.y >> 16;
     } else {
-        w[0] = lab[i0];
-        w[1] = DT_MINUS1;
-    }
-    bool any = false;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        if (w[k] >> 63) continue;                                  // -1.0 stays
-        const int i = i0 + k;
-        const int t = i / DT_T - (int)((w[k] >> 62) & 1ull);
-        const unsigned v = (unsigned)w[k];
+        for (int k = 0; k < 4; k++) c[k] = i0 + k < n ? code[i0 + k] : DT_C_MINUS1;
+    }
+    double id[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        id[k] = -1.0;
+        if (c[k] == DT_C_MINUS1) continue;
+        const int i = (int)(i0 + k);
+        const int t = i / DT_T - (int)((c[k] & DT_C_PREV) != 0);
+        const unsigned v = c[k] & DT_C_INDEX;
         const int b = db_bucket(boff, nb, i);
         const unsigned rb = runbase[b];
-        double id;
-        if (w[k] & DT_CODE_EXTRA) id = (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + v - extbase[b]));
-        else id = (double)(preR[t] + v - rb);
-        w[k] = (ull)__double_as_longlong(id);
-        any = true;
+        if (c[k] & DT_C_EXTRA) id[k] = (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + v - extbase[b]));
+        else id[k] = (double)(preR[t] + v - rb);
     }
-    if (!any) return;
-    if (two) *reinterpret_cast<ulonglong2 *>(lab + i0) = make_ulonglong2(w[0], w[1]);
-    else lab[i0] = w[0];
+    if (four && (((size_t)lab) & 15) == 0) {
+        *reinterpret_cast<double2 *>(lab + i0) = make_double2(id[0], id[1]);
+        *reinterpret_cast<double2 *>(lab + i0 + 2) = make_double2(id[2], id[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (i0 + k < n) lab[i0 + k] = id[k];
+    }
 }
 
 // one bucket: no scan launch — every workgroup sums the counts it needs itself: whole groups of DT_GRP tiles from the group sums
@@ -628,13 +623,15 @@ __global__ __launch_bounds__(256) void dbt_finish(unsigned long long *__restrict
 #ifndef DT_FTPB
 #define DT_FTPB 4                            // tiles per workgroup of dbt_finish1: one prefix prologue serves them all
 #endif
-__global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restrict__ lab, int n, const unsigned *__restrict__ aggR,
+__global__ __launch_bounds__(256) void dbt_finish1(const unsigned short *__restrict__ code, double *__restrict__ lab, int n,
+                                                   const int *__restrict__ xlab, const unsigned *__restrict__ aggR,
                                                    const unsigned *__restrict__ aggE, int nt, const unsigned *__restrict__ grp,
                                                    unsigned *__restrict__ grp_next, int ng_clear, long long *__restrict__ last_id,
                                                    long long id_base, int use_id_base,
                                                    unsigned *__restrict__ flags, volatile unsigned *host, unsigned seq) {
     __shared__ unsigned red[4][6];
     __shared__ unsigned pR[DT_FTPB + 1], pE[DT_FTPB + 1];      // [j]: runs / extra sub-runs in front of tile (tile0 - 1 + j)
+    __shared__ unsigned ownR[DT_FTPB], ownE[DT_FTPB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x * DT_FTPB;         // the first of this workgroup's tiles
     dt_signal_host(flags, host, seq);
@@ -644,6 +641,24 @@ __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restric
             grp_next[i] = 0;
             grp_next[DT_GRPMAX + i] = 0;
         }
+    const long long i0 = (long long)tile * DT_T;
+    const long long i1 = i0 + (long long)DT_FTPB * DT_T < (long long)n ? i0 + (long long)DT_FTPB * DT_T : (long long)n;
+    // four points per thread and trip (DT_T is a multiple of 4: never two tiles); the codes of every trip are fetched up front,
+    // so their latency rides behind the prefix sums below
+    constexpr int NIT = (DT_FTPB * DT_T + 1023) / 1024;
+    uint2 cv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const long long i = i0 + tid * 4 + it * 1024;
+        cv[it] = make_uint2(0xffffffffu, 0xffffffffu);
+        if (i + 4 <= i1) cv[it] = *reinterpret_cast<const uint2 *>(code + i);
+        else if (i < i1) {
+            unsigned c[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) c[k] = i + k < n ? code[i + k] : DT_C_MINUS1;
+            cv[it] = make_uint2(c[0] | c[1] << 16, c[2] | c[3] << 16);
+        }
+    }
     // A: tiles < tile-1, B: tile-1, T: all
     const int gA = (tile - 1) / DT_GRP;            // group of tile-1 (tile 0: no tile before it)
     unsigned rA = 0, rB = 0, rT = 0, eA = 0, eB = 0, eT = 0;
@@ -660,6 +675,11 @@ __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restric
             if (i < tile - 1) { rA += r; eA += e; }
             else { rB = r; eB = e; }
         }
+    }
+    if (tid < DT_FTPB) {                           // this workgroup's own tiles: fetched beside the sums, not one after the other in the chain below
+        const int t = tile + tid;
+        ownR[tid] = t < nt ? aggR[t] : 0u;
+        ownE[tid] = t < nt ? aggE[t] : 0u;
     }
     unsigned v[6] = {rA, rB, rT, eA, eB, eT};
 #pragma unroll
@@ -679,47 +699,36 @@ __global__ __launch_bounds__(256) void dbt_finish1(unsigned long long *__restric
         for (int j = 1; j <= DT_FTPB; j++) {
             pR[j] = r;
             pE[j] = e;
-            const int t = tile + j - 1;
-            if (t < nt) {
-                r += aggR[t];
-                e += aggE[t];
-            }
+            r += ownR[j - 1];
+            e += ownE[j - 1];
         }
     }
     __syncthreads();
     const long long R1 = use_id_base ? id_base : (long long)v[2] - 1;     // ids of the extra sub-runs continue from here (:112-122)
     if (blockIdx.x == 0 && tid == 0 && last_id) last_id[0] = R1 + (long long)v[5];
-    const long long i0 = (long long)tile * DT_T;
-    const long long i1 = i0 + (long long)DT_FTPB * DT_T < (long long)n ? i0 + (long long)DT_FTPB * DT_T : (long long)n;
     const bool al = (((size_t)lab) & 15) == 0;
-    for (long long i = i0 + tid * 2; i < i1; i += 512) {
-        const int tl = (int)((i - i0) / DT_T);     // DT_T is even: a pair never straddles two tiles
-        ull w[2];
-        const bool two = al && i + 2 <= n;
-        if (two) {
-            const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(lab + i);
-            w[0] = q.x;
-            w[1] = q.y;
-        } else {
-            w[0] = lab[i];
-            w[1] = i + 1 < n ? lab[i + 1] : DT_MINUS1;
-        }
-        bool any = false;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (w[k] >> 63) continue;                                  // -1.0 stays
-            const int j = tl + 1 - (int)((w[k] >> 62) & 1ull);         // the owner tile's prefix (the point's own tile, or the one before it)
-            const unsigned c = (unsigned)w[k];
-            const double id = (w[k] & DT_CODE_LITERAL) ? (double)(int)c
-                              : (w[k] & DT_CODE_EXTRA) ? (double)(R1 + (long long)(pE[j] + c)) : (double)(pR[j] + c);
-            w[k] = (ull)__double_as_longlong(id);
-            any = true;
+    for (int it = 0; it < NIT; it++) {
+        const long long i = i0 + tid * 4 + it * 1024;
+        if (i >= i1) break;
+        const int tl = (int)((i - i0) / DT_T);
+        const unsigned c[4] = {cv[it].x & 0xffffu, cv[it].x >> 16, cv[it].y & 0xffffu, cv[it].y >> 16};
+        double id[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            id[k] = -1.0;
+            if (c[k] == DT_C_MINUS1) continue;
+            const int j = tl + 1 - (int)((c[k] & DT_C_PREV) != 0);     // the owner tile's prefix (the point's own tile, or the one before it)
+            const unsigned v = c[k] & DT_C_INDEX;
+            id[k] = (c[k] & DT_C_LITERAL) ? (double)xlab[i + k] : (c[k] & DT_C_EXTRA) ? (double)(R1 + (long long)(pE[j] + v)) : (double)(pR[j] + v);
         }
-        if (!any) continue;
-        if (two) *reinterpret_cast<ulonglong2 *>(lab + i) = make_ulonglong2(w[0], w[1]);
-        else {
-            lab[i] = w[0];
-            if (i + 1 < n) lab[i + 1] = w[1];
+        if (i + 4 <= n && al) {
+            *reinterpret_cast<double2 *>(lab + i) = make_double2(id[0], id[1]);
+            *reinterpret_cast<double2 *>(lab + i + 2) = make_double2(id[2], id[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i + k < n) lab[i + k] = id[k];
         }
     }
 }
