@@ -579,41 +579,39 @@ __global__ __launch_bounds__(256) void dbt_finish(const unsigned short *__restri
                                                   const unsigned *__restrict__ preR, const unsigned *__restrict__ preE,
                                                   const int *__restrict__ boff, int nb, const unsigned *__restrict__ runbase,
                                                   const unsigned *__restrict__ extbase) {
-    // four points per thread: 8 bytes of codes in, 32 bytes of labels out (n and the arrays' alignment permitting)
-    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i0 >= n) return;
-    unsigned c[4];
-    const bool four = i0 + 4 <= n;
-    if (four) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(code + i0);
-        c[0] = v.x & 0xffffu;
-        c[1] = v.x >> 16;
-        c[2] = v.y & 0xffffu;
-        c[3] = v.y >> 16;
-    } else {
+    // two pairs of points per thread, pair h of thread t at block*1024 + h*512 + 2t: a wave's store instruction writes one contiguous KB
+    const bool al = (((size_t)lab) & 15) == 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = i0 + k < n ? code[i0 + k] : DT_C_MINUS1;
-    }
-    double id[4];
+    for (int h = 0; h < 2; h++) {
+        const long long i0 = (long long)blockIdx.x * 1024 + h * 512 + threadIdx.x * 2;
+        if (i0 >= n) continue;
+        unsigned c[2];
+        if (i0 + 2 <= n) {
+            const unsigned v = *reinterpret_cast<const unsigned *>(code + i0);
+            c[0] = v & 0xffffu;
+            c[1] = v >> 16;
+        } else {
+            c[0] = code[i0];
+            c[1] = DT_C_MINUS1;
+        }
+        double id[2];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        id[k] = -1.0;
-        if (c[k] == DT_C_MINUS1) continue;
-        const int i = (int)(i0 + k);
-        const int t = i / DT_T - (int)((c[k] & DT_C_PREV) != 0);
-        const unsigned v = c[k] & DT_C_INDEX;
-        const int b = db_bucket(boff, nb, i);
-        const unsigned rb = runbase[b];
-        if (c[k] & DT_C_EXTRA) id[k] = (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + v - extbase[b]));
-        else id[k] = (double)(preR[t] + v - rb);
-    }
-    if (four && (((size_t)lab) & 15) == 0) {
-        *reinterpret_cast<double2 *>(lab + i0) = make_double2(id[0], id[1]);
-        *reinterpret_cast<double2 *>(lab + i0 + 2) = make_double2(id[2], id[3]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (i0 + k < n) lab[i0 + k] = id[k];
+        for (int k = 0; k < 2; k++) {
+            id[k] = -1.0;
+            if (c[k] == DT_C_MINUS1) continue;
+            const int i = (int)(i0 + k);
+            const int t = i / DT_T - (int)((c[k] & DT_C_PREV) != 0);
+            const unsigned v = c[k] & DT_C_INDEX;
+            const int b = db_bucket(boff, nb, i);
+            const unsigned rb = runbase[b];
+            if (c[k] & DT_C_EXTRA) id[k] = (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + v - extbase[b]));
+            else id[k] = (double)(preR[t] + v - rb);
+        }
+        if (i0 + 2 <= n && al) *reinterpret_cast<double2 *>(lab + i0) = make_double2(id[0], id[1]);
+        else {
+            lab[i0] = id[0];
+            if (i0 + 1 < n) lab[i0 + 1] = id[1];
+        }
     }
 }
 
@@ -643,22 +641,20 @@ __global__ __launch_bounds__(256) void dbt_finish1(const unsigned short *__restr
         }
     const long long i0 = (long long)tile * DT_T;
     const long long i1 = i0 + (long long)DT_FTPB * DT_T < (long long)n ? i0 + (long long)DT_FTPB * DT_T : (long long)n;
-    // four points per thread and trip (DT_T is a multiple of 4: never two tiles); the codes of every trip are fetched up front,
-    // so their latency rides behind the prefix sums below
+    // two pairs of points per thread and trip, pair h of thread t at trip*1024 + h*512 + 2t: a store instruction of a wave writes one
+    // contiguous KB of labels (DT_T is even: a pair never lies in two tiles).  The codes of every trip are fetched up front, so their
+    // latency rides behind the prefix sums below.
     constexpr int NIT = (DT_FTPB * DT_T + 1023) / 1024;
-    uint2 cv[NIT];
+    unsigned cv[NIT][2];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const long long i = i0 + tid * 4 + it * 1024;
-        cv[it] = make_uint2(0xffffffffu, 0xffffffffu);
-        if (i + 4 <= i1) cv[it] = *reinterpret_cast<const uint2 *>(code + i);
-        else if (i < i1) {
-            unsigned c[4];
+    for (int it = 0; it < NIT; it++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) c[k] = i + k < n ? code[i + k] : DT_C_MINUS1;
-            cv[it] = make_uint2(c[0] | c[1] << 16, c[2] | c[3] << 16);
+        for (int h = 0; h < 2; h++) {
+            const long long i = i0 + it * 1024 + h * 512 + tid * 2;
+            cv[it][h] = 0xffffffffu;
+            if (i + 2 <= i1) cv[it][h] = *reinterpret_cast<const unsigned *>(code + i);
+            else if (i < i1) cv[it][h] = (unsigned)code[i] | 0xffff0000u;
         }
-    }
     // A: tiles < tile-1, B: tile-1, T: all
     const int gA = (tile - 1) / DT_GRP;            // group of tile-1 (tile 0: no tile before it)
     unsigned rA = 0, rB = 0, rT = 0, eA = 0, eB = 0, eT = 0;
@@ -708,27 +704,26 @@ __global__ __launch_bounds__(256) void dbt_finish1(const unsigned short *__restr
     if (blockIdx.x == 0 && tid == 0 && last_id) last_id[0] = R1 + (long long)v[5];
     const bool al = (((size_t)lab) & 15) == 0;
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const long long i = i0 + tid * 4 + it * 1024;
-        if (i >= i1) break;
-        const int tl = (int)((i - i0) / DT_T);
-        const unsigned c[4] = {cv[it].x & 0xffffu, cv[it].x >> 16, cv[it].y & 0xffffu, cv[it].y >> 16};
-        double id[4];
+    for (int it = 0; it < NIT; it++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            id[k] = -1.0;
-            if (c[k] == DT_C_MINUS1) continue;
-            const int j = tl + 1 - (int)((c[k] & DT_C_PREV) != 0);     // the owner tile's prefix (the point's own tile, or the one before it)
-            const unsigned v = c[k] & DT_C_INDEX;
-            id[k] = (c[k] & DT_C_LITERAL) ? (double)xlab[i + k] : (c[k] & DT_C_EXTRA) ? (double)(R1 + (long long)(pE[j] + v)) : (double)(pR[j] + v);
-        }
-        if (i + 4 <= n && al) {
-            *reinterpret_cast<double2 *>(lab + i) = make_double2(id[0], id[1]);
-            *reinterpret_cast<double2 *>(lab + i + 2) = make_double2(id[2], id[3]);
-        } else {
+        for (int h = 0; h < 2; h++) {
+            const long long i = i0 + it * 1024 + h * 512 + tid * 2;
+            if (i >= i1) continue;
+            const int tl = (int)((i - i0) / DT_T);
+            const unsigned c[2] = {cv[it][h] & 0xffffu, cv[it][h] >> 16};
+            double id[2];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (i + k < n) lab[i + k] = id[k];
+            for (int k = 0; k < 2; k++) {
+                id[k] = -1.0;
+                if (c[k] == DT_C_MINUS1) continue;
+                const int j = tl + 1 - (int)((c[k] & DT_C_PREV) != 0);     // the owner tile's prefix (the point's own tile, or the one before it)
+                const unsigned v = c[k] & DT_C_INDEX;
+                id[k] = (c[k] & DT_C_LITERAL) ? (double)xlab[i + k] : (c[k] & DT_C_EXTRA) ? (double)(R1 + (long long)(pE[j] + v)) : (double)(pR[j] + v);
+            }
+            if (i + 2 <= n && al) *reinterpret_cast<double2 *>(lab + i) = make_double2(id[0], id[1]);
+            else {
+                lab[i] = id[0];
+                if (i + 1 < n) lab[i + 1] = id[1];
+            }
         }
-    }
 }
