@@ -202,12 +202,14 @@ def run_sv(args, version):
 
     # The GC / N-mask bins depend on the reference FASTA alone (the reference computes them after the signals, __main__.py:166):
     # a second host thread with its own library context (own streams and scratch) reads the FASTA and runs the GC kernel while the
-    # BAM is scanned — the scan waits on the inflate kernel, the GC pass on the page cache and PCIe.  TIDDIT_GC_OVERLAP=0: in sequence.
+    # main thread merges and writes the signal tables — pure Python, while the GC pass waits on the page cache, PCIe and the device.
+    # It starts when the BAM scan is over (tiddit_signal.AFTER_SCAN): beside the scan itself the two compete for the link and the
+    # scan of a 54-GB file lost 0.3 s to it.  TIDDIT_GC_OVERLAP=0: in sequence, on the main thread.
     gc_job = None
     if rank == 0 and os.environ.get("TIDDIT_GC_OVERLAP", "1") != "0":
         import threading
         from . import _native
-        gc_job = {"t0": time.time()}
+        gc_job = {}
 
         def gc_thread():
             try:
@@ -217,13 +219,22 @@ def run_sv(args, version):
             except BaseException as e:           # re-raised on the main thread
                 gc_job["error"] = e
             gc_job["seconds"] = time.time() - gc_job["t0"]
-        gc_job["thread"] = threading.Thread(target=gc_thread, name="tiddit-gc")
-        gc_job["thread"].start()
+
+        def start_gc():
+            if "thread" not in gc_job:
+                gc_job["t0"] = time.time()
+                gc_job["thread"] = threading.Thread(target=gc_thread, name="tiddit-gc")
+                gc_job["thread"].start()
+        tiddit_signal.AFTER_SCAN.append(start_gc)
     t = time.time()
     with stage("tiddit: signal extraction + coverage"):
         signal_main = tiddit_signal.main_sharded if world > 1 else tiddit_signal.main
-        coverage_data = signal_main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
-                                    False, args.min_anchor_len, args.min_clip_len)
+        try:
+            coverage_data = signal_main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
+                                        False, args.min_anchor_len, args.min_clip_len)
+        finally:
+            if gc_job is not None:
+                tiddit_signal.AFTER_SCAN.remove(start_gc)
     if rank == 0:
         print("extracted signals in:")
         print(t - time.time())
@@ -235,13 +246,14 @@ def run_sv(args, version):
             if gc_job is None:
                 gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
             else:
+                start_gc()                      # (already running unless the signal stage never reached the end of its scan)
                 gc_job["thread"].join()
                 if "error" in gc_job:
                     raise gc_job["error"]
                 gc_dictionary = gc_job["result"]
         T["GC bins"] = time.time() - t
         if gc_job is not None:
-            T["  GC bins, on their own thread beside the scan"] = gc_job["seconds"]
+            T["  GC bins, on their own thread beside merge + write"] = gc_job["seconds"]
         t = time.time()
         with stage("tiddit: ploidy"):
             library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,

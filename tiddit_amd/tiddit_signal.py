@@ -496,6 +496,7 @@ STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 SCAN_SECONDS = {}           # ... and of the last scan_signals() pass, by what the host waited for
 LAST_SEAM = {}              # seam offsets of the last sharded scan_signals() pass (dist.check_seams)
 PREMERGED = {}              # the (chrA, chrB, fragment) dictionaries the last scan_signals() merged while it scanned (see rows_of)
+AFTER_SCAN = []             # callables main() invokes once the file has been scanned, before the tables are merged and written (host-only work from there on)
 WRITTEN_TABLES = {}         # (discordants path, splits path) -> stamps + the rows the last main() wrote there (tiddit_cluster reads them back)
 
 
@@ -626,6 +627,8 @@ def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_co
     STAGE_SECONDS.clear()
     STAGE_SECONDS["scan (ingest, coverage, predicates, rows)"] = time.time() - t
     STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
+    for hook in list(AFTER_SCAN):
+        hook()
     t1 = time.time()
     _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id)
     print("total", time.time() - t)
@@ -670,6 +673,8 @@ def _main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads
     STAGE_SECONDS.clear()
     STAGE_SECONDS["scan (ingest, coverage, predicates, rows; this rank's shard)"] = time.time() - t
     STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
+    for hook in list(AFTER_SCAN):
+        hook()
     t1 = time.time()
     mine = {c: (res_data[c], res_splits[c], [_clip_bytes(x) for x in res_clips[c]]) for c in chromosomes
             if res_data[c] or res_splits[c] or res_clips[c]}
