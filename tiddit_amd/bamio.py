@@ -455,6 +455,10 @@ def take_carry(path, bin_size):
     return c
 
 
+_SPAN_POOLS = []                 # free list of hostutil.PinnedPool objects, each holding a reader's four span buffers
+_SPAN_POOLS_LOCK = __import__("threading").Lock()
+
+
 class DeviceBamReader:
     """BAM reader whose inflate, record finding and field decode run on the MI355X (``tdt_ingest_*``): the file's BGZF
     blocks are read into pinned host memory by a helper thread, pushed as they are, and come back as :class:`DeviceBatch`.
@@ -512,12 +516,19 @@ class DeviceBamReader:
         """(buffer, consumed) spans of whole BGZF blocks, read ahead by a helper thread into rotating pinned buffers"""
         import queue
         import threading
-        import torch
         lib = self.ctx.lib
         chunk = self.chunk
         b_lo, x_hi = self._b_lo, self._x_hi
         chunk = max(1 << 16, min(chunk, x_hi - b_lo))
-        bufs = [torch.empty(chunk + (2 << 20), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(4)]   # in use, prefetched, queued, being read
+        # four pinned span buffers (in use, prefetched, queued, being read) from a process-wide free list: handed back in Spans.close(),
+        # not whenever the collector gets to this closure — a reader opened right after another one used to find the previous
+        # reader's pinned blocks still alive and paid 5-55 ms for new ones (the spread of the bench's ingest line)
+        with _SPAN_POOLS_LOCK:
+            span_pool = _SPAN_POOLS.pop() if _SPAN_POOLS else None
+        if span_pool is None:
+            from .hostutil import PinnedPool
+            span_pool = PinnedPool()
+        bufs = [span_pool.take("span%d" % i, chunk + (2 << 20), np.uint8) for i in range(4)]
         q = queue.Queue(maxsize=1)
         stop = self._stop
 
@@ -587,6 +598,7 @@ class DeviceBamReader:
         class Spans:
             """blocking ``next()`` and non-blocking ``poll()`` over the reader thread's queue; None = end of range"""
             done = False
+            returned = False
 
             def _take(self, item):
                 if item is None:
@@ -614,6 +626,10 @@ class DeviceBamReader:
             def close(self):
                 stop.set()                                        # a consumer that stops early releases the reader thread
                 th.join()
+                if not self.returned:
+                    self.returned = True
+                    with _SPAN_POOLS_LOCK:
+                        _SPAN_POOLS.append(span_pool)
 
         return Spans()
 
