@@ -316,7 +316,9 @@ def main(argv=None):
     parser.add_argument("--cov", help="generate a coverage bed file", required=False, action="store_true")
     args, unknown = parser.parse_known_args()
     if args.sv:
-        run_sv(_sv_parser().parse_args(), version)
+        from .hostutil import quiet_gc
+        with quiet_gc(freeze=True):          # one job, one process: the collector stays off from the first stage to the last
+            run_sv(_sv_parser().parse_args(), version)
     elif args.cov:
         run_cov(_cov_parser().parse_args())
     else:

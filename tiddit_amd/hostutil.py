@@ -4,25 +4,28 @@ import gc
 
 
 @contextlib.contextmanager
-def quiet_gc():
+def quiet_gc(freeze=False):
     """The row tables of the signal / cluster stages are millions of small, acyclic lists and dicts; CPython's cyclic collector walks
     all of them again and again while they are built (a third of the host time of `tiddit --sv` on a 48 M-read BAM).  Reference
-    counting still frees everything; the collector is switched back on afterwards if it was on — after ``gc.freeze()``: what the
-    stage left alive (the rows the next stage reads) moves to the permanent generation, or the first allocation after ``gc.enable()``
-    starts a full collection over all of it (0.25 s at 240 M reads, 0.8 s at 600 M).  Frozen objects are still freed by their
-    reference counts; :func:`thaw` hands them back to the collector (a long-lived host that wants cycles among them found)."""
+    counting still frees everything; the collector is switched back on afterwards if it was on.
+
+    freeze=True (the command line, which owns its process): ``gc.freeze()`` first — what the job left alive moves to the permanent
+    generation, or the first allocation after ``gc.enable()`` starts a full collection over all of it (0.25 s at 240 M reads, 0.8 s
+    at 600 M).  Frozen objects are still freed by their reference counts; the next ``quiet_gc`` (or :func:`thaw`) hands them back to
+    the collector.  The library entry points (``tiddit_signal.main`` ...) do not freeze: a host's own objects are none of their business."""
     global _FROZEN
     was = gc.isenabled()
     gc.disable()
-    if _FROZEN:                  # what the previous stage froze goes back to the collector's lists: at most one stage's leftovers are
-        gc.unfreeze()            # ever exempt from collection (nothing walks them while the collector is off)
+    if _FROZEN:
+        gc.unfreeze()
         _FROZEN = False
     try:
         yield
     finally:
         if was:
-            gc.freeze()
-            _FROZEN = True
+            if freeze:
+                gc.freeze()
+                _FROZEN = True
             gc.enable()
 
 
@@ -30,7 +33,7 @@ _FROZEN = False
 
 
 def thaw():
-    """undo the ``gc.freeze()`` of :func:`quiet_gc`"""
+    """undo the ``gc.freeze()`` of ``quiet_gc(freeze=True)``"""
     global _FROZEN
     gc.unfreeze()
     _FROZEN = False
