@@ -305,7 +305,7 @@ def main():
                                "stream, %d-bp bins, q>=%d filter; contigs split over the %d rank(s)" % (C_all, L, C_all * L / 1e9, args.depth, z, args.min_q, world),
                    "reads": job_reads, "bins": job_bins, "reads_rank0": total_reads, "bins_rank0": total_bins, "launches_per_step": 3,
                    "layout": "8-byte BINNED records in HBM (first_bin << 2 | shape, filter byte, the two table indices of tiddit_coverage.pyx:53-63: "
-                             "csrc/tdt_common.h cov_bin_record) — what the ingest kernel writes when the reader is bound to this histogram "
+                             "csrc/tdt_cov_record.h cov_bin_record) — what the ingest kernel writes when the reader is bound to this histogram "
                              "(DeviceBamReader.bin_for): the division and the bin split are done once where the record is made.  "
                              "'packed_layout' times the same launch from the bin-size-agnostic packed records (start | span:24 mapq:6 flags), "
                              "'four_array_layout' from separate start/end/mapq/flag arrays (11 B/read), 'pack_*_ms' the one-off conversions from "
