@@ -123,3 +123,31 @@ def test_written_tables_are_forgotten_when_a_file_changes(tmp_path):
     assert tiddit_signal.written_tables(*paths) is None
     sig, pos = tiddit_cluster._read_signals(prefix, ["S"], dict(CONTIGS), False, MIN_CONTIG, True)
     assert any(r[0] == "extra" for r in sig["chr1"]["chr1"])
+
+
+def test_quiet_gc_leaves_the_collector_as_it_found_it_and_only_the_cli_freezes():
+    import gc
+    from tiddit_amd.hostutil import quiet_gc, thaw
+    assert gc.isenabled()
+    with quiet_gc():
+        assert not gc.isenabled()
+        with quiet_gc():                      # nested (tiddit_signal.main inside the command line's own): stays off, nothing frozen
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    assert gc.isenabled() and gc.get_freeze_count() == 0
+    with quiet_gc(freeze=True):
+        pass
+    assert gc.isenabled() and gc.get_freeze_count() > 0
+    with quiet_gc():                          # the next stage hands the frozen objects back
+        assert gc.get_freeze_count() == 0
+    with quiet_gc(freeze=True):
+        pass
+    thaw()
+    assert gc.get_freeze_count() == 0
+    gc.disable()
+    try:
+        with quiet_gc(freeze=True):           # a host that runs without the collector keeps running without it
+            pass
+        assert not gc.isenabled() and gc.get_freeze_count() == 0
+    finally:
+        gc.enable()
