@@ -151,44 +151,3 @@ def test_quiet_gc_leaves_the_collector_as_it_found_it_and_only_the_cli_freezes()
         assert not gc.isenabled() and gc.get_freeze_count() == 0
     finally:
         gc.enable()
-
-
-def test_discordant_reads_merged_from_columns_equal_the_merge_of_their_rows():
-    """EarlyTables.add_discordant_reads (what main()'s own scan uses: no per-contig row lists) == EarlyTables.add over worker()'s rows"""
-    rng = random.Random(3)
-    n = 4000
-    kept = [c for c, ln in CONTIGS if ln >= MIN_CONTIG]
-    tids = sorted(rng.randrange(len(NAMES)) for _ in range(n))
-    rb, offs = bytearray(), []
-    for _ in tids:
-        nm = ("frag%04d" % rng.randrange(n // 2)).encode() + b"\0"
-        rec = bytearray(36 + len(nm) + 10)
-        rec[12] = len(nm)
-        rec[36:36 + len(nm)] = nm
-        offs.append(len(rb))
-        rb += rec
-    rb = bytes(rb)
-    mates = [t if rng.random() < 0.7 else rng.randrange(len(NAMES)) for t in tids]
-    pos = [rng.randrange(10 ** 6) for _ in tids]
-    end = [p + 150 for p in pos]
-    flags = [rng.randrange(4096) for _ in tids]
-    a, b = tiddit_signal.EarlyTables(NAMES, kept), tiddit_signal.EarlyTables(NAMES, kept)
-    for lo in range(0, n, 700):                             # batch by batch
-        sl = slice(lo, lo + 700)
-        assert a.add_discordant_reads(NAMES, tids[sl], mates[sl], pos[sl], end[sl], flags[sl], offs[sl], rb)
-        cur, rows = None, []
-        for t_, m_, p_, e_, f_, o_ in zip(tids[sl], mates[sl], pos[sl], end[sl], flags[sl], offs[sl]):
-            chrom, mate = NAMES[t_], NAMES[m_]
-            chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
-            row = [chrA, chrB, rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode(), p_ + 1, e_ + 1, bool(f_ & 0x10), chrom]
-            if t_ != cur:
-                if rows:
-                    b.add(NAMES[cur], rows, "d")
-                cur, rows = t_, []
-            rows.append(row)
-        if rows:
-            b.add(NAMES[cur], rows, "d")
-    assert a.ok and b.ok and a.data == b.data
-    assert sum(len(v) for x in a.data.values() for v in x.values()) > 1000
-    # a contig out of header order: refused, and the tables stand down
-    assert not a.add_discordant_reads(NAMES, [0], [0], [5], [155], [0], offs[:1], rb) and not a.ok

@@ -301,54 +301,7 @@ class EarlyTables:
                     lines[chrA][signal[1]][signal[2]] = "{}\t{}\t{}\t{}\n".format(signal[2], chrA, signal[1], "\t".join(map(str, f)))
 
 
-    def add_discordant_reads(self, names, tids, mates, pos, end, flags, offs, rb):
-        """The discordant reads of one batch as columns (file order; `offs` = their records in the raw bytes `rb`): the same merge as
-        ``add(contig, rows, "d")`` run by run, without the detour over worker()'s row lists (:214-221) — what main() needs of a read
-        is its fragment's entry.  -> False, with ``ok`` switched off, when a contig arrives out of header order."""
-        data, rank_of, last = self.data, self.rank_of, self.last["d"]
-        if not self.ok:
-            return False
-        cur_t, chrom, kept = None, None, False
-        for t_, m_, p_, e_, f_, o_ in zip(tids, mates, pos, end, flags, offs):
-            if t_ != cur_t:
-                cur_t, chrom = t_, names[t_]
-                r = rank_of.get(chrom)
-                kept = r is not None                  # (a contig main() does not walk: its workers' rows are never merged)
-                if kept:
-                    if r < last:
-                        self.ok = False
-                        return False
-                    last = r
-            if not kept:
-                continue
-            mate = names[m_]
-            chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
-            a = data.get(chrA)
-            if a is None:
-                continue
-            qname = rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode()          # block_size, 32 fixed bytes, then l_read_name bytes (NUL included)
-            reads = a[chrB].setdefault(qname, [])
-            reads.append([p_ + 1, e_ + 1, bool(f_ & 0x10), chrom])
-            if len(reads) == 2:
-                first, second = reads
-                if chrA == chrB:
-                    if second[-1] < first[-1]:           # QUIRK (:307): compares the two read_chr strings, always equal
-                        first, second = second, first
-                elif first[-1] != chrA:
-                    first, second = second, first
-                out = first[0:-1] + second[0:-1]
-                reads.append((qname, chrA, chrB, out))
-                reads.append("{}\t{}\t{}\t{}\n".format(qname, chrA, chrB, "\t".join(map(str, out))))
-        self.last["d"] = last
-        return True
-
-
-class _NeedRows(Exception):
-    """scan_signals(keep_rows=False) met a file that is not in contig order: the caller scans again, keeping worker()'s rows"""
-
-
-def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None,
-                 keep_rows=True):
+def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None):
     """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
     split rows, clip FASTA entries).  The discordant and split rows are what ``worker`` returns (:228); the clip entries
     are pairs whose joined content is the contig's clip FASTA in file order: ``[header, sequence + "\n"]`` strings, one per read,
@@ -357,10 +310,7 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
 
     shard = (rank, world): only the records that start in this rank's byte range of the file (bamio.DeviceBamReader); the
     seam offsets are left in ``LAST_SEAM`` for dist.check_seams.  reduce_bins(hist) -> float64 array of ALL the histogram's
-    bins (the sharded caller all-reduces them there); default: this process's own bins.
-
-    keep_rows=False (main()'s own call): the discordant reads go straight into the merged tables (EarlyTables) and the per-contig
-    row lists stay empty — half the Python work per read; a file that is not in contig order raises ``_NeedRows``."""
+    bins (the sharded caller all-reduces them there); default: this process's own bins."""
     max_ins = int(max_ins)         # the reference's `int max_ins` argument truncates a float percentile (:147,:230; probed with Cython 3.2)
     carry = None
     if shard is None and os.environ.get("TIDDIT_HOST_INGEST") != "1":
@@ -420,12 +370,6 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         T["split rows"] += t6 - t5
         which = numpy.flatnonzero(act & 8)
         rb = sel.raw_bytes
-        if not keep_rows:
-            if not early.ok or not early.add_discordant_reads(names, stid[which].tolist(), sel.mate_tid[which].tolist(), sel.pos[which].tolist(),
-                                                              sel.end[which].tolist(), sel.flag[which].tolist(), sel.rec_off[which].tolist(), rb):
-                raise _NeedRows()
-            T["discordant select + rows"] += time.time() - t6
-            return
         cols = zip(stid[which].tolist(), sel.mate_tid[which].tolist(), sel.pos[which].tolist(), sel.end[which].tolist(),
                    sel.flag[which].tolist(), sel.rec_off[which].tolist())
         cur_t, cur_rows = None, None
@@ -525,14 +469,6 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             T["discordant select + rows"] += t0 - t6
         if pending is not None:
             pending.result()
-    except BaseException:
-        pool.shutdown(wait=True)
-        try:                                                  # the device buffers of an abandoned scan go back at once (a _NeedRows caller scans again)
-            reader.close()
-            hist.close()
-        except Exception:
-            pass
-        raise
     finally:
         pool.shutdown(wait=True)                              # (also on an error: no row thread outlives the scan)
     if shard is not None:
@@ -686,12 +622,8 @@ def written_tables(disc_path, split_path):
 
 def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
     t = time.time()
-    try:
-        header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
-            bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50, keep_rows=os.environ.get("TIDDIT_HOST_INGEST") == "1")
-    except _NeedRows:                    # not in contig order: the merge has to wait for the end of the scan, over worker()'s rows
-        header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
-            bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
+    header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
+        bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
     STAGE_SECONDS.clear()
     STAGE_SECONDS["scan (ingest, coverage, predicates, rows)"] = time.time() - t
     STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
