@@ -34,6 +34,7 @@ extern "C" {
 #define TDT_E_INEXACT (-4)  /* a bin left the exact-arithmetic domain (|acc| >= 2^53)              */
 #define TDT_E_NOMEM (-5)
 #define TDT_E_UNSUPPORTED (-6) /* input outside the device path's domain (e.g. coordinate span >= 2^32) */
+#define TDT_E_KEY (-7)      /* a name that is not in the table (reference: KeyError); tdt_last_error() = the name */
 
 typedef struct tdt_ctx tdt_ctx;
 typedef struct tdt_cov tdt_cov;
@@ -233,6 +234,42 @@ int tdt_signal_scan_result(tdt_ctx *ctx, void *meta, uint32_t *raw_end, uint8_t 
  * tdt_signal_scan_result) `>query_name|contig|pos+1\nSEQUENCE\n`, concatenated.  Two-call protocol like tdt_format_coverage. */
 int tdt_format_clips(const void *meta, const uint32_t *raw_end, const uint8_t *raw, const uint32_t *which, size_t m, const char *contig,
                      char *out, size_t out_cap, size_t *out_len);
+
+/* ---- signal tables (host, no Python in the per-row path) ------------------------------------------ *
+ * Replaces, for the discordant / split / clipped reads tdt_signal_scan selected:
+ *   - the merge loop of tiddit_signal.main (tiddit_signal.pyx:246-284: data[chrA][chrB][fragment], splits[..] +=) and its three
+ *     writers (:298-332: discordants_{sample}.tab, splits_{sample}.tab, the clip FASTA files),
+ *   - the signal table of tiddit_cluster.main (tiddit_cluster.pyx:47-105: find_discordant_pos :7-37, the clip QUIRK :67-70),
+ *   - the per-row half of its regrouping (:156-254): which signals make up which candidate, in the reference's insertion order.
+ * One table per job, used by one thread at a time.  names = the header's contig names, NUL-terminated, back to back, in header
+ * order; contigs >= min_contig are main()'s `chromosomes`.  Byte-identical output for coordinate-sorted AND unsorted input (see
+ * csrc/tdt_sigtab.hip).  TDT_E_KEY where the reference raises KeyError (a split row whose chrB is not in the header). */
+int tdt_sigtab_create(const char *names, const int64_t *lengths, int n_contigs, int64_t min_contig, void **out);
+void tdt_sigtab_destroy(void *t);
+/* the arrays of tdt_signal_scan_result, batch by batch in file order.  *stopped == n_sel: done; else the index of a split read whose
+ * SA tag tdt_split_fields does not take — hand its row over with tdt_sigtab_add_split_row (or drop it) and call again with
+ * resume = *stopped + 1. */
+int tdt_sigtab_add(void *t, const void *meta, const uint32_t *raw_end, const uint8_t *raw, size_t n_sel, size_t raw_len, int min_q, size_t resume,
+                   size_t *stopped);
+int tdt_sigtab_add_split_row(void *t, int tid, const char *chrA, const char *chrB, const char *qname, const int64_t *six, int is_reverse, int sa_minus);
+int tdt_sigtab_add_clips(void *t, int tid, const char *bytes, size_t len);
+int tdt_sigtab_clips(void *t, int tid, const char **ptr, size_t *len);      /* clips/{contig}.fa of one contig (valid until the table changes) */
+int tdt_sigtab_stats(void *t, int64_t *out8);
+/* the row log as one blob (N-rank job: rows travel to the owner rank of their chrA; owner == NULL: all rows) — two-call protocol */
+int tdt_sigtab_export(void *t, const int32_t *owner, int dest, void *out, size_t cap, size_t *need);
+int tdt_sigtab_import(void *t, const void *blob, size_t len);
+int tdt_sigtab_format(void *t, size_t *n_segments_disc, size_t *n_segments_split);
+/* kind 0 = discordants, 1 = splits; segments: 5 int64 per contig pair with rows (chrA id, chrB id, offset, length, rows) */
+int tdt_sigtab_text(void *t, int kind, const char **ptr, size_t *len, int64_t *segments);
+/* bytes per contig of one output — what 0: the rows of discordants_{sample}.tab with that chrA, 1: splits_{sample}.tab, 2: the contig's
+ * clip FASTA — and one such block written at `offset` of an open file: a file is its blocks in header order, so N ranks place theirs */
+int tdt_sigtab_sizes(void *t, int what, int64_t *out_per_contig);
+int tdt_sigtab_pwrite(void *t, int what, int contig, int fd, int64_t offset);
+int tdt_sigtab_cluster_table(void *t, int is_mp, int64_t min_contig, size_t *n_signals, int *n_buckets);
+int tdt_sigtab_cluster_columns(void *t, int32_t *posA, int32_t *posB, int64_t *bucket_off, int32_t *bucket_a, int32_t *bucket_b);
+int tdt_sigtab_regroup(void *t, const int32_t *labels, size_t *n_candidates, size_t *n_members, size_t *name_bytes);
+int tdt_sigtab_regroup_result(void *t, int32_t *cand4, int32_t *startA, int32_t *endA, int32_t *startB, int32_t *endB, int32_t *posA, int32_t *posB,
+                              uint8_t *oriA, uint8_t *oriB, char *names);
 
 /* ---- masked medians of the coverage bins -------------------------------------------------------- *
  * Replaces the per-bin Python loop + numpy.median of determine_ploidy (tiddit_coverage_analysis.pyx:14-27).

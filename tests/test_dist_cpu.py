@@ -352,3 +352,94 @@ def test_oversized_bucket_cut_gloo_world2_and_3():
         for p in procs:
             p.join(60)
         assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+# ---- `tiddit --sv` on N ranks behind the scan (tiddit_signal.share_and_write + tiddit_cluster.main_sharded): rows to the owner of
+# their chrA in ONE all-to-all, every owner formats / places its blocks and clusters / regroups its buckets; rank 0 only puts the
+# finished candidates together.  The two device steps are the host stand-ins of tests/sigtab_common.py.
+
+def _sv_tables_worker(rank, world, port, q, bam, fixture, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import json
+    import torch.distributed as dist
+    from oracle import cluster_oracle
+    from sigtab_common import fill_tables, oracle_labels
+    from tiddit_amd import bamio, tiddit_cluster, tiddit_signal
+    from tiddit_amd.sigtab import SignalTables
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = json.load(open(fixture))
+        P = fx["params"]
+        rd = bamio.BamReader(bam, batch_bytes=4 << 20)
+        batches = list(rd.batches())
+        rd.close()
+        mine = batches[len(batches) * rank // world:len(batches) * (rank + 1) // world]        # this rank's share of the file, in file order
+        big = [ln >= P["min_contig"] for ln in rd.lengths]
+        scanned = SignalTables(rd.references, rd.lengths, P["min_contig"])
+        max_ins = fx["library"]["percentile_insert_size"]
+        fill_tables(scanned, mine, rd.references, big, P["min_q"], max_ins, P["min_anchor_len"], P["min_clip_len"])
+        prefix = os.path.join(outdir, "n%d" % world)
+        chromosomes = [n for n, ok in zip(rd.references, big) if ok]
+        merged, owner = tiddit_signal.share_and_write(scanned, chromosomes, prefix, "WGS")
+        assert tiddit_signal.written_tables(prefix + "_tiddit/discordants_WGS.tab", prefix + "_tiddit/splits_WGS.tab") is merged
+        st = merged.stats()
+
+        class Pageable:
+            def take(self, name, n, dtype):
+                return np.zeros(n, dtype=dtype)
+        tiddit_cluster._POOL = Pageable()
+        tiddit_cluster.cluster_columns_device = oracle_labels
+        cand = tiddit_cluster.main_sharded(prefix, rd.references, dict(zip(rd.references, rd.lengths)), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"],
+                                           max_ins, P["min_contig"], True, P["min_reads"])
+        res = {"rows": st["discordant_rows"] + st["split_rows"], "stages": sorted(tiddit_cluster.STAGE_SECONDS)}
+        if rank == 0:
+            res["canonical"] = cluster_oracle.canonical(cand)
+            res["summary"] = cluster_oracle.summary(cand)
+        else:
+            assert cand is None
+        q.put((rank, res))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sv_signal_tables_on_n_ranks_gloo_world2_and_3(tmp_path):
+    """the fixture's 3-Mb WGS file dealt to 2 / 3 ranks: discordants / splits .tab, every clip FASTA and the candidates dictionary are
+    the single-process run's (= the fixture's checksums); every owner holds rows, none of them all"""
+    import hashlib
+    import json
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from sv_e2e_common import load_fixture, materialise
+    golden = os.path.join(REPO, "tests", "golden")
+    fx = load_fixture(golden, "sv_e2e_small.json")
+    bam, fa, contigs = materialise(fx, str(tmp_path), threads=4)
+    sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
+    for world in (2, 3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_sv_tables_worker, args=(r, world, port, q, bam, os.path.join(golden, "sv_e2e_small.json"), str(tmp_path))) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = dict(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(60)
+        assert all(isinstance(v, dict) for v in res.values()), res
+        prefix = str(tmp_path / ("n%d" % world))
+        assert sha(prefix + "_tiddit/discordants_WGS.tab") == fx["discordants_sha256"]
+        assert sha(prefix + "_tiddit/splits_WGS.tab") == fx["splits_sha256"]
+        assert sha(prefix + "_tiddit/clips_WGS.fa") == fx["clips_sha256"]
+        each = b"".join(open(prefix + "_tiddit/clips/%s.fa" % n, "rb").read() for n, ln in contigs if ln >= fx["params"]["min_contig"])
+        assert hashlib.sha256(each).hexdigest() == fx["clips_sha256"]
+        assert res[0]["summary"] == json.loads(json.dumps(fx["candidates"])) and hashlib.sha256(res[0]["canonical"].encode()).hexdigest() == fx["candidates_sha256"]
+        rows = [res[r]["rows"] for r in range(world)]
+        assert all(x > 0 for x in rows) and max(rows) < sum(rows)
+        assert all("candidates to rank 0" in res[r]["stages"] and "parse .tab" not in res[r]["stages"] for r in range(world))

@@ -58,10 +58,11 @@ def test_candidates_whole_dictionary(run):
     # ... through either way in: the rows the signal stage of this process left behind (the CLI's own path), and the .tab text
     from tiddit_amd import tiddit_signal
     had = tiddit_signal.written_tables(out + "_tiddit/discordants_WGS.tab", out + "_tiddit/splits_WGS.tab") is not None
-    tiddit_signal.WRITTEN_TABLES.clear()
+    assert ("signal table (native, into pinned columns)" in tiddit_cluster.STAGE_SECONDS) == had
+    tiddit_signal._forget_tables()
     text = tiddit_cluster.main(out, names, dict(contigs), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"],
                                fx["library"]["percentile_insert_size"], P["min_contig"], True, P["min_reads"])
-    assert h(cluster_oracle.canonical(text)) == fx["candidates_sha256"]
+    assert h(cluster_oracle.canonical(text)) == fx["candidates_sha256"] and "parse .tab" in tiddit_cluster.STAGE_SECONDS
     assert had or os.environ.get("TIDDIT_HOST_INGEST") == "1", "the signal stage's rows were not there for tiddit_cluster.main"
     # what the CLI wrote is the same table
     rows = [l.rstrip("\n").split("\t") for l in open(out + ".candidates.tab") if not l.startswith("#")]
@@ -117,12 +118,12 @@ def _sv_rank(rank, world, port, q, argv, min_cut):
         import torch.distributed as dist
         from tiddit_amd import __main__ as cli, tiddit_cluster
         seen = []
-        real = tiddit_cluster.cluster_buckets
+        real = tiddit_cluster.cluster_columns_device
 
-        def spy(buckets, *a, **k):
-            seen.append(sum(len(b) for b in buckets))
-            return real(buckets, *a, **k)
-        tiddit_cluster.cluster_buckets = spy
+        def spy(posA, *a, **k):
+            seen.append(len(posA))
+            return real(posA, *a, **k)
+        tiddit_cluster.cluster_columns_device = spy
         cli.main(argv)
         q.put((rank, seen))
         dist.destroy_process_group()
@@ -134,8 +135,9 @@ def _sv_rank(rank, world, port, q, argv, min_cut):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sv_on_n_ranks_is_byte_identical(run, tmp_path, world):
     """`tiddit --sv --skip_assembly` as 2 / 3 ranks on ONE file: byte-range shards of the BAM with checked seams, one exact all-reduce
-    of the 50-bp bins, rows gathered in file order, buckets (the large ones cut at posA gaps >= eps) clustered where the packing puts
-    them — discordants/splits .tab, every clip FASTA, .ploidies.tab and .candidates.tab equal the single-process run byte for byte"""
+    of the 50-bp bins, rows sent once to the owner rank of their chrA, every owner formatting / placing its blocks of the .tab files and
+    clustering / regrouping its own buckets — discordants/splits .tab, every clip FASTA, .ploidies.tab and .candidates.tab equal the
+    single-process run byte for byte"""
     import socket
     import torch.multiprocessing as mp
     fx, bam, fa, contigs, out = run

@@ -194,7 +194,7 @@ def run_sv(args, version):
     t = time.time()
     with stage("tiddit: library statistics"):
         if rank == 0:                                                    # the sample is a prefix of the file: one rank's job
-            library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s)
+            library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=world == 1)   # (N ranks scan byte-range shards: nobody would take a carry)
         if world > 1:
             library = tdist.broadcast_object(library if rank == 0 else None, 0)
     max_ins_len = args.i if args.i else library["percentile_insert_size"]

@@ -11,7 +11,7 @@ SO_PATH = os.environ.get("TIDDIT_HIP_LIB") or os.path.join(_HERE, "libtiddit_hip
 
 TDT_OK = 0
 ERRORS = {-1: "TDT_E_ARG", -2: "TDT_E_HIP", -3: "TDT_E_RANGE", -4: "TDT_E_INEXACT", -5: "TDT_E_NOMEM",
-          -6: "TDT_E_UNSUPPORTED"}
+          -6: "TDT_E_UNSUPPORTED", -7: "TDT_E_KEY"}
 
 _lib = None
 _lock = threading.Lock()
@@ -79,6 +79,23 @@ SYMBOLS = {
     "tdt_signal_scan_result": (_i, [_P, _P, _P, _P]),
     "tdt_format_clips": (_i, [_P, _P, _P, _P, _sz, ctypes.c_char_p, _P, _sz, ctypes.POINTER(_sz)]),
     "tdt_split_fields": (_i, [_P, _P, _P, _sz, _P, _sz, _i, _P]),
+    "tdt_sigtab_create": (_i, [ctypes.c_char_p, _P, _i, _i64, _PP]),
+    "tdt_sigtab_destroy": (None, [_P]),
+    "tdt_sigtab_add": (_i, [_P, _P, _P, _P, _sz, _sz, _i, _sz, ctypes.POINTER(_sz)]),
+    "tdt_sigtab_add_split_row": (_i, [_P, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _P, _i, _i]),
+    "tdt_sigtab_add_clips": (_i, [_P, _i, _P, _sz]),
+    "tdt_sigtab_clips": (_i, [_P, _i, _PP, ctypes.POINTER(_sz)]),
+    "tdt_sigtab_stats": (_i, [_P, _P]),
+    "tdt_sigtab_export": (_i, [_P, _P, _i, _P, _sz, ctypes.POINTER(_sz)]),
+    "tdt_sigtab_import": (_i, [_P, _P, _sz]),
+    "tdt_sigtab_format": (_i, [_P, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "tdt_sigtab_text": (_i, [_P, _i, _PP, ctypes.POINTER(_sz), _P]),
+    "tdt_sigtab_sizes": (_i, [_P, _i, _P]),
+    "tdt_sigtab_pwrite": (_i, [_P, _i, _i, _i, _i64]),
+    "tdt_sigtab_cluster_table": (_i, [_P, _i, _i64, ctypes.POINTER(_sz), ctypes.POINTER(_i)]),
+    "tdt_sigtab_cluster_columns": (_i, [_P, _P, _P, _P, _P, _P]),
+    "tdt_sigtab_regroup": (_i, [_P, _P, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "tdt_sigtab_regroup_result": (_i, [_P] * 11),
     "tdt_masked_medians": (_i, [_P, _P, _P, _P, _i, _P, _P, _P]),
     "tdt_segment_means": (_i, [_P, _P, _P, _i64, _P, _P, _P, _sz, _P, _P]),
     "tdt_segment_means_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _P]),

@@ -594,6 +594,7 @@ class DeviceBamReader:
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
+        self._span_thread = th                                    # close() joins it before the ingest handle goes (the thread prefetches through it)
 
         class Spans:
             """blocking ``next()`` and non-blocking ``poll()`` over the reader thread's queue; None = end of range"""
@@ -726,7 +727,13 @@ class DeviceBamReader:
             raise ValueError("truncated BAM record at end of file")
 
     def close(self):
+        """safe whatever the lifetime of a ``batches()`` generator: the reader thread (which calls tdt_ingest_prefetch on the handle and
+        reads the file) is stopped and joined before the handle is destroyed and the file closed"""
         self._stop.set()
+        th = getattr(self, "_span_thread", None)
+        if th is not None and th.is_alive() and th is not __import__("threading").current_thread():
+            th.join()
+        self._span_thread = None
         if self._h:
             self.ctx.lib.tdt_ingest_destroy(self._h)
             self._h = None

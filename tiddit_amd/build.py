@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libtiddit_hip.so")
-SOURCES = ["tdt_ctx.hip", "tdt_coverage.hip", "tdt_gc.hip", "tdt_dbscan.hip", "tdt_dbscan_yseg.hip", "tdt_sort.hip", "tdt_bam.hip", "tdt_format.hip", "tdt_bgzf.hip", "tdt_inflate.hip", "tdt_inflate2.hip", "tdt_ingest.hip", "tdt_signal.hip", "tdt_median.hip", "tdt_region.hip", "tdt_comm.hip", "tdt_means.hip", "tdt_stats.hip"]
+SOURCES = ["tdt_ctx.hip", "tdt_coverage.hip", "tdt_gc.hip", "tdt_dbscan.hip", "tdt_dbscan_yseg.hip", "tdt_sort.hip", "tdt_bam.hip", "tdt_format.hip", "tdt_bgzf.hip", "tdt_inflate.hip", "tdt_inflate2.hip", "tdt_ingest.hip", "tdt_signal.hip", "tdt_median.hip", "tdt_region.hip", "tdt_comm.hip", "tdt_means.hip", "tdt_stats.hip", "tdt_sigtab.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
 

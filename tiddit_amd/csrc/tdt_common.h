@@ -67,6 +67,17 @@ struct BzDesc {
     unsigned long long in_off, out_off;   // payload offset in the compressed buffer, block offset in the output
     unsigned in_len, isize, crc, pad;
 };
+// tdt_split_fields (tdt_format.hip) / the signal tables (tdt_sigtab.hip)
+struct TdtSplitOut {
+    int32_t status;        // 0: SA mapQ below min_q (no row, :40-41), 1: fields valid, 2: not handled here
+    int32_t read_start, read_end;      // reference_start + 1, reference_end + 1 of the read (:60-61)
+    int32_t split_pos, sa_split;       // before the swap (:62-116)
+    int32_t seg_start, seg_end;        // the SA segment's reference_start (the tag's POS, stored raw, :13) and reference_end
+    uint32_t chr_off, chr_len;         // the SA contig name inside raw
+    uint8_t is_reverse, sa_minus, pad[2];
+};
+void tdt_split_one(const uint8_t *meta, const uint32_t *raw_end, const uint8_t *raw, size_t raw_len, uint32_t r, int min_q, TdtSplitOut &o);
+
 int tdt_host_thread_count();
 int tdt_bz_hop(const uint8_t *p, size_t avail, size_t *bsize, size_t *pay_off, size_t *pay_len, uint32_t *isize);
 int tdt_bz_block_table(const uint8_t *comp, size_t len, std::vector<BzDesc> &blocks, size_t *produced);

@@ -300,14 +300,6 @@ extern "C" int tdt_format_clips(const void *meta_, const uint32_t *raw_end, cons
 // entry 0 of the tag `rname,pos,strand,CIGAR,mapQ[,NM]` with unsigned decimal pos / mapQ, strand + or -, and a CIGAR of decimal
 // lengths with the letters M S H D I (the only ones the reference's table knows, :23); anything else gets status 2 and the caller
 // runs the literal Python, which reproduces the reference's behaviour there (KeyError on other CIGAR letters, int() oddities).
-struct TdtSplitOut {
-    int32_t status;        // 0: SA mapQ below min_q (no row, :40-41), 1: fields valid, 2: not handled here
-    int32_t read_start, read_end;      // reference_start + 1, reference_end + 1 of the read (:60-61)
-    int32_t split_pos, sa_split;       // before the swap (:62-116)
-    int32_t seg_start, seg_end;        // the SA segment's reference_start (the tag's POS, stored raw, :13) and reference_end
-    uint32_t chr_off, chr_len;         // the SA contig name inside raw
-    uint8_t is_reverse, sa_minus, pad[2];
-};
 
 static bool sp_uint(const uint8_t *p, const uint8_t *e, long long *v) {
     if (p >= e || e - p > 9) return false;
@@ -320,6 +312,90 @@ static bool sp_uint(const uint8_t *p, const uint8_t *e, long long *v) {
     return true;
 }
 
+// one selected record r (see tdt_split_fields below)
+void tdt_split_one(const uint8_t *meta, const uint32_t *raw_end, const uint8_t *raw, size_t raw_len, uint32_t r, int min_q, TdtSplitOut &o) {
+    memset(&o, 0, sizeof(o));
+    o.status = 2;
+    const size_t rec0 = r ? raw_end[r - 1] : 0u, rec1 = raw_end[r];
+    int32_t pos, end, sa_rel;
+    uint16_t flag;
+    memcpy(&pos, meta + (size_t)r * 28 + 8, 4);
+    memcpy(&end, meta + (size_t)r * 28 + 12, 4);
+    memcpy(&sa_rel, meta + (size_t)r * 28 + 20, 4);
+    memcpy(&flag, meta + (size_t)r * 28 + 24, 2);
+    if (sa_rel < 0 || rec0 + (size_t)sa_rel >= rec1 || rec1 > raw_len) return;
+    const uint8_t *s = raw + rec0 + sa_rel, *lim = raw + rec1;
+    const uint8_t *e = s;
+    while (e < lim && *e && *e != ';') e++;               // entry 0 of the tag (:36-39 only ever look at it)
+    if (e >= lim) return;
+    const uint8_t *f[6];
+    int nf = 0;
+    f[nf++] = s;
+    for (const uint8_t *p = s; p < e && nf < 6; p++)
+        if (*p == ',') f[nf++] = p + 1;
+    if (nf < 5) return;
+    auto fend = [&](int i) { return i + 1 < nf ? f[i + 1] - 1 : e; };
+    // a sixth comma would make fend(5) wrong only for a field nobody reads (NM); fields 0..4 end at the next comma
+    long long sa_pos, sa_mapq;
+    if (!sp_uint(f[1], fend(1), &sa_pos) || !sp_uint(f[4], fend(4), &sa_mapq)) return;
+    if (fend(2) - f[2] != 1 || (f[2][0] != '+' && f[2][0] != '-')) return;
+    if (f[0] >= fend(0)) return;
+    bool ascii = true;
+    for (const uint8_t *p = f[0]; p < fend(0); p++) ascii = ascii && *p < 0x80;
+    if (!ascii) return;
+    // the SA CIGAR (:17-27): reference length (M, D), leading soft clip (hard clips skipped), well-formedness
+    long long ref = 0, lead = 0;
+    bool leading = true, ok = f[3] < fend(3);
+    for (const uint8_t *p = f[3]; ok && p < fend(3);) {
+        const uint8_t *q = p;
+        while (q < fend(3) && *q >= '0' && *q <= '9') q++;
+        long long len;
+        if (q == p || q >= fend(3) || !sp_uint(p, q, &len)) { ok = false; break; }
+        const uint8_t op = *q;
+        if (op != 'M' && op != 'S' && op != 'H' && op != 'D' && op != 'I') { ok = false; break; }
+        if (op == 'M' || op == 'D') ref += len;
+        if (leading) {
+            if (op == 'S') lead += len;
+            else if (op != 'H') leading = false;
+        }
+        p = q + 1;
+    }
+    if (!ok || sa_pos + ref > 0x7fffffffll) return;
+    // the read's own leading soft clip (query_alignment_start)
+    const uint8_t *rec = raw + rec0 + 4;
+    const int l_name = rec[8];
+    uint16_t n_cig;
+    memcpy(&n_cig, rec + 12, 2);
+    if (rec + 32 + l_name + 4 * (size_t)n_cig > lim) return;
+    long long rlead = 0;
+    for (unsigned j = 0; j < n_cig; j++) {
+        uint32_t cw;
+        memcpy(&cw, rec + 32 + l_name + 4 * (size_t)j, 4);
+        const unsigned op = cw & 0xf;
+        if (op == 5) continue;
+        if (op == 4) rlead += cw >> 4;
+        else break;
+    }
+    o.chr_off = (uint32_t)(f[0] - raw);
+    o.chr_len = (uint32_t)(fend(0) - f[0]);
+    if (sa_mapq < min_q) {                               // :40-41
+        o.status = 0;
+        return;
+    }
+    const int seg_start = (int)sa_pos, seg_end = (int)(sa_pos + (ref ? ref : 1));
+    const bool clip_before = lead < rlead, rev = (flag & 0x10) != 0, sa_minus = f[2][0] == '-';
+    const int read_start = pos + 1, read_end = end + 1;
+    o.read_start = read_start;
+    o.read_end = read_end;
+    o.split_pos = clip_before ? (rev ? read_end : read_start) : (rev ? read_start : read_end);
+    o.sa_split = clip_before ? (sa_minus ? seg_start : seg_end) : (sa_minus ? seg_end : seg_start);
+    o.seg_start = seg_start;
+    o.seg_end = seg_end;
+    o.is_reverse = rev;
+    o.sa_minus = sa_minus;
+    o.status = 1;
+}
+
 extern "C" int tdt_split_fields(const void *meta_, const uint32_t *raw_end, const uint8_t *raw, size_t raw_len, const uint32_t *which, size_t m,
                                 int min_q, void *out_) {
     if (m && (!meta_ || !raw_end || !raw || !which || !out_)) {
@@ -329,89 +405,6 @@ extern "C" int tdt_split_fields(const void *meta_, const uint32_t *raw_end, cons
     static_assert(sizeof(TdtSplitOut) == 40, "TdtSplitOut layout");
     const uint8_t *meta = (const uint8_t *)meta_;
     TdtSplitOut *out = (TdtSplitOut *)out_;
-    for (size_t k = 0; k < m; k++) {
-        TdtSplitOut &o = out[k];
-        memset(&o, 0, sizeof(o));
-        o.status = 2;
-        const uint32_t r = which[k];
-        const size_t rec0 = r ? raw_end[r - 1] : 0u, rec1 = raw_end[r];
-        int32_t pos, end, sa_rel;
-        uint16_t flag;
-        memcpy(&pos, meta + (size_t)r * 28 + 8, 4);
-        memcpy(&end, meta + (size_t)r * 28 + 12, 4);
-        memcpy(&sa_rel, meta + (size_t)r * 28 + 20, 4);
-        memcpy(&flag, meta + (size_t)r * 28 + 24, 2);
-        if (sa_rel < 0 || rec0 + (size_t)sa_rel >= rec1 || rec1 > raw_len) continue;
-        const uint8_t *s = raw + rec0 + sa_rel, *lim = raw + rec1;
-        const uint8_t *e = s;
-        while (e < lim && *e && *e != ';') e++;               // entry 0 of the tag (:36-39 only ever look at it)
-        if (e >= lim) continue;
-        const uint8_t *f[6];
-        int nf = 0;
-        f[nf++] = s;
-        for (const uint8_t *p = s; p < e && nf < 6; p++)
-            if (*p == ',') f[nf++] = p + 1;
-        if (nf < 5) continue;
-        auto fend = [&](int i) { return i + 1 < nf ? f[i + 1] - 1 : e; };
-        // a sixth comma would make fend(5) wrong only for a field nobody reads (NM); fields 0..4 end at the next comma
-        long long sa_pos, sa_mapq;
-        if (!sp_uint(f[1], fend(1), &sa_pos) || !sp_uint(f[4], fend(4), &sa_mapq)) continue;
-        if (fend(2) - f[2] != 1 || (f[2][0] != '+' && f[2][0] != '-')) continue;
-        if (f[0] >= fend(0)) continue;
-        bool ascii = true;
-        for (const uint8_t *p = f[0]; p < fend(0); p++) ascii = ascii && *p < 0x80;
-        if (!ascii) continue;
-        // the SA CIGAR (:17-27): reference length (M, D), leading soft clip (hard clips skipped), well-formedness
-        long long ref = 0, lead = 0;
-        bool leading = true, ok = f[3] < fend(3);
-        for (const uint8_t *p = f[3]; ok && p < fend(3);) {
-            const uint8_t *q = p;
-            while (q < fend(3) && *q >= '0' && *q <= '9') q++;
-            long long len;
-            if (q == p || q >= fend(3) || !sp_uint(p, q, &len)) { ok = false; break; }
-            const uint8_t op = *q;
-            if (op != 'M' && op != 'S' && op != 'H' && op != 'D' && op != 'I') { ok = false; break; }
-            if (op == 'M' || op == 'D') ref += len;
-            if (leading) {
-                if (op == 'S') lead += len;
-                else if (op != 'H') leading = false;
-            }
-            p = q + 1;
-        }
-        if (!ok || sa_pos + ref > 0x7fffffffll) continue;
-        // the read's own leading soft clip (query_alignment_start)
-        const uint8_t *rec = raw + rec0 + 4;
-        const int l_name = rec[8];
-        uint16_t n_cig;
-        memcpy(&n_cig, rec + 12, 2);
-        if (rec + 32 + l_name + 4 * (size_t)n_cig > lim) continue;
-        long long rlead = 0;
-        for (unsigned j = 0; j < n_cig; j++) {
-            uint32_t cw;
-            memcpy(&cw, rec + 32 + l_name + 4 * (size_t)j, 4);
-            const unsigned op = cw & 0xf;
-            if (op == 5) continue;
-            if (op == 4) rlead += cw >> 4;
-            else break;
-        }
-        o.chr_off = (uint32_t)(f[0] - raw);
-        o.chr_len = (uint32_t)(fend(0) - f[0]);
-        if (sa_mapq < min_q) {                               // :40-41
-            o.status = 0;
-            continue;
-        }
-        const int seg_start = (int)sa_pos, seg_end = (int)(sa_pos + (ref ? ref : 1));
-        const bool clip_before = lead < rlead, rev = (flag & 0x10) != 0, sa_minus = f[2][0] == '-';
-        const int read_start = pos + 1, read_end = end + 1;
-        o.read_start = read_start;
-        o.read_end = read_end;
-        o.split_pos = clip_before ? (rev ? read_end : read_start) : (rev ? read_start : read_end);
-        o.sa_split = clip_before ? (sa_minus ? seg_start : seg_end) : (sa_minus ? seg_end : seg_start);
-        o.seg_start = seg_start;
-        o.seg_end = seg_end;
-        o.is_reverse = rev;
-        o.sa_minus = sa_minus;
-        o.status = 1;
-    }
+    for (size_t k = 0; k < m; k++) tdt_split_one(meta, raw_end, raw, raw_len, which[k], min_q, out[k]);
     return TDT_OK;
 }

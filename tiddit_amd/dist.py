@@ -214,6 +214,71 @@ def gather_bytes(blob, dst=0, group=None):
     return out
 
 
+def contig_owners(lengths, kept, world_size):
+    """owner rank of every contig id for the N-rank signal tables: the contigs >= min_contig (`kept`) bin-packed by length (the rows
+    of a pair (chrA, chrB) are almost all intra-chromosomal, so a chrA's share of the work follows its length); every (chrA, *) pair
+    lives on owner[chrA].  -> int32 array, identical on every rank; contigs that own nothing get rank 0."""
+    import numpy
+    ids = [i for i, k in enumerate(kept) if k]
+    owner = numpy.zeros(len(lengths), dtype=numpy.int32)
+    for r, mine in enumerate(shard_contigs([lengths[i] for i in ids], world_size)):
+        for j in mine:
+            owner[ids[j]] = r
+    return owner
+
+
+def allgather_i64(values, group=None):
+    """int64 vector of every rank -> [world, len] numpy array (rank order)"""
+    import numpy
+    import torch
+    import torch.distributed as dist
+    dev = _wire_device(group)
+    world = dist.get_world_size(group)
+    mine = torch.from_numpy(numpy.ascontiguousarray(values, dtype=numpy.int64)).to(dev)
+    out = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.cpu().numpy().reshape(world, -1)
+
+
+def alltoall_bytes(parts, group=None):
+    """parts[r] = the uint8 array this rank has for rank r -> the arrays every rank had for THIS rank, in RANK ORDER.  Sizes by one
+    all-gather; payloads by ONE all_to_all_single over RCCL (device tensors), or point to point over gloo (which has no all-to-all):
+    every receive is posted before the sends."""
+    import numpy
+    import torch
+    import torch.distributed as dist
+    me, world = dist.get_rank(group), dist.get_world_size(group)
+    parts = [numpy.ascontiguousarray(p, dtype=numpy.uint8) for p in parts]
+    sizes = allgather_i64([len(p) for p in parts], group)            # sizes[src][dst]
+    incoming = [int(sizes[r][me]) for r in range(world)]
+    if dist.get_backend(group) == "nccl":
+        dev = _wire_device(group)
+        send = torch.from_numpy(numpy.concatenate(parts) if sum(len(p) for p in parts) else numpy.zeros(0, dtype=numpy.uint8)).to(dev)
+        recv = torch.empty(sum(incoming), dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(recv, send, output_split_sizes=incoming, input_split_sizes=[len(p) for p in parts], group=group)
+        flat = recv.cpu().numpy()
+        out, o = [], 0
+        for n in incoming:
+            out.append(flat[o:o + n])
+            o += n
+        return out
+    bufs, reqs = [], []
+    for r in range(world):
+        if r == me:
+            bufs.append(parts[me])
+            continue
+        buf = torch.empty(incoming[r], dtype=torch.uint8)
+        if incoming[r]:
+            reqs.append(dist.irecv(buf, r, group=group))
+        bufs.append(buf.numpy())
+    for r in range(world):
+        if r != me and len(parts[r]):
+            reqs.append(dist.isend(torch.from_numpy(parts[r]), r, group=group))
+    for q in reqs:
+        q.wait()
+    return bufs
+
+
 # One oversized (chrA,chrB) bucket cut into pieces that cluster independently (SURVEY §8(e)).  A cut is legal between two
 # posA-neighbours a < b with b - a >= eps: every sliding window that spans the gap fails `max(distances) < epsilon`
 # (DBSCAN.py:50), so no x-run — hence no cluster — crosses it.  ONE detail makes a naive cut wrong: the reference's last

@@ -42,7 +42,9 @@ class FastaFile:
         self.path = path
         if not os.path.isfile(path + ".fai"):
             from . import _native
-            _native.check(_native.load().tdt_fasta_write_fai(path.encode(), (path + ".fai").encode()))   # build_fai() in C
+            tmp = "%s.fai.%d.tmp" % (path, os.getpid())          # N ranks may all find the index missing: each writes its own file and
+            _native.check(_native.load().tdt_fasta_write_fai(path.encode(), tmp.encode()))   # build_fai() in C
+            os.replace(tmp, path + ".fai")                       # the rename is atomic — nobody ever parses a half-written index
         self.index = {}
         self.references = []
         for line in open(path + ".fai"):

@@ -6,9 +6,11 @@ keep the reference's arguments and return the same nested ``candidates[chrA][chr
 dictionaries (same keys, same insertion order — the order later defines the VCF ``SV_n`` ids).
 
 What moved to the GPU: the stable sort of every (chrA,chrB) bucket by posA and ``DBSCAN.main`` on it
-(:152-154) — all buckets in ONE ``tdt_sort_dbscan`` call instead of a serial Python loop.  What stays on
-the host: parsing the ``.tab`` signal files (:47-137) and regrouping signals into candidates (:156-336).
-Reference quirks that are reproduced on purpose are marked QUIRK.
+(:152-154) — all buckets in ONE ``tdt_cluster_columns`` call instead of a serial Python loop.  The signal table
+(:47-137) and the per-signal half of the regrouping (:156-254) come from the native signal tables when
+``tiddit_signal.main`` of this process wrote the files (``sigtab.SignalTables``: columns written into pinned
+buffers, candidates' members returned as flat arrays — Python touches candidates, not rows); files from
+elsewhere are parsed as text by the literal loops below.  Reference quirks reproduced on purpose are marked QUIRK.
 """
 from collections import Counter
 
@@ -56,7 +58,8 @@ STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 
 
 def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly):
-    """Parse discordants_/splits_/contigs_{sample}.tab in the reference's order (:46-137).
+    """Parse discordants_/splits_/contigs_{sample}.tab in the reference's order (:46-137) — the text way in (files this process did
+    not write, or --with assembly contigs); the job's own tables never become text rows (:func:`_main_native`).
     -> signals[chrA][chrB] = list of records, positions[chrA][chrB] = flat list posA, posB, i, posA, posB, i, ... (one array
     conversion per bucket later, not one per row)."""
     signals, positions = {}, {}
@@ -72,40 +75,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
 
     for sample in samples:
         disc_path, split_path = "{}_tiddit/discordants_{}.tab".format(prefix, sample), "{}_tiddit/splits_{}.tab".format(prefix, sample)
-        cached = None
-        if skip_assembly:
-            from . import tiddit_signal
-            cached = tiddit_signal.written_tables(disc_path, split_path)      # this process wrote these very files: their rows are still here
-        if cached is not None:
-            # the rows as tiddit_signal wrote them, still as numbers and booleans: the same records as the text loop below builds, without the
-            # str() / int() round trip (positions stay ints — every later use converts with int() anyway; orientations become the text's words)
-            side = _MP_SIDE if is_mp else _PE_SIDE
-            default = (4, 6) if is_mp else (3, 7)
-            words = ("False", "True")
-            pick = []                                   # [revA * 2 + revB] -> (word A, word B, index of posA in the fields, ... of posB)
-            for ra in (0, 1):
-                for rb in (0, 1):
-                    ia, ib = side.get((words[ra], words[rb]), default)
-                    pick.append((words[ra], words[rb], ia - 3, ib - 3))
-            for chrA, chrB, rows in cached[0]:          # the rows of one contig pair, in file order
-                lenA, lenB = contig_length[chrA], contig_length[chrB]
-                if lenA < min_contig or lenB < min_contig or not rows:
-                    continue
-                recs = bucket(chrA, chrB)
-                add, pos = recs.append, pos_of[id(recs)].extend
-                for frag, _, _, o in rows:
-                    oa, ob, ia, ib = pick[o[2] * 2 + o[5]]
-                    posA, posB = o[ia], o[ib]
-                    if posA > lenA:
-                        posA = lenA
-                        if posB > lenB:
-                            posA = lenB                 # QUIRK (:67-70), as below
-                    add([frag, sample, "D", posA, oa, posB, ob, i, o[0], o[1], o[3], o[4]])
-                    pos((posA, posB, i))
-                    i += 1
-            disc_iter = ()
-        else:
-            disc_iter = (line.rstrip().split("\t") for line in open(disc_path))
+        disc_iter = (line.rstrip().split("\t") for line in open(disc_path))
         for c in disc_iter:
             chrA, chrB = c[1], c[2]
             if contig_length[chrA] < min_contig or contig_length[chrB] < min_contig:
@@ -123,21 +93,7 @@ def _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assemb
         if not skip_assembly:
             files.append(("A", "{}_tiddit/contigs_{}.tab"))
         for kind, pattern in files:
-            if kind == "S" and cached is not None:
-                for chrA, chrB, rows in cached[1]:
-                    lenA, lenB = contig_length[chrA], contig_length[chrB]
-                    if lenA < min_contig or lenB < min_contig or not rows:
-                        continue
-                    recs = bucket(chrA, chrB)
-                    add, pos = recs.append, pos_of[id(recs)].extend
-                    for frag, o in rows.items():
-                        posA, posB = min(o[0], lenA), min(o[2], lenB)
-                        add([frag, sample, kind, posA, ("True" if o[1] else "False"), posB, ("True" if o[3] else "False"), i, o[4], o[5], o[6], o[7]])
-                        pos((posA, posB, i))
-                        i += 1
-                continue
-            else:
-                rows_iter = (line.rstrip().split("\t") for line in open(pattern.format(prefix, sample)))
+            rows_iter = (line.rstrip().split("\t") for line in open(pattern.format(prefix, sample)))
             for c in rows_iter:
                 chrA, chrB = c[1], c[2]
                 if contig_length[chrA] < min_contig or contig_length[chrB] < min_contig:
@@ -343,23 +299,148 @@ def _breakpoints_from_discordants(cand, is_mp):
     return pickA(A["discordants"]), pickB(B["discordants"])
 
 
+def _finish_candidates(candidates, is_mp, min_reads):
+    """:256-336 — counts, breakpoints and regions of every candidate, in place"""
+    for chrA in candidates:
+        for chrB in candidates[chrA]:
+            for cand in candidates[chrA][chrB].values():
+                cand["N_discordants"] = len(cand["discordants"])
+                cand["N_splits"] = len(cand["splits"])
+                cand["N_contigs"] = len(cand["contigs"])
+                A, B = cand["positions_A"], cand["positions_B"]
+                if cand["N_splits"] and min_reads <= cand["N_splits"]:      # enough split reads: their mode (:266-268)
+                    cand["posA"], cand["posB"] = _mode(A["splits"]), _mode(B["splits"])
+                elif cand["N_contigs"]:
+                    cand["posA"], cand["posB"] = _mode(A["contigs"]), _mode(B["contigs"])
+                elif cand["N_splits"]:
+                    cand["posA"], cand["posB"] = _mode(A["splits"]), _mode(B["splits"])
+                else:
+                    cand["posA"], cand["posB"] = _breakpoints_from_discordants(cand, is_mp)
+                cand["startB"] = min(B["start"])
+                cand["endB"] = max(B["end"])
+                cand["startA"] = min(A["start"])
+                cand["endA"] = max(A["end"])
+
+
+def cluster_columns_device(posA, posB, off, epsilon, m, lab32, ctx=None):
+    """int32 columns (pinned) of all buckets -> lab32[i] = cluster of signal i, on the device (``tdt_cluster_columns``: stable sort by
+    posA + DBSCAN.main per bucket, :152-160)"""
+    ctx = ctx or _native.default_context()
+    n = len(posA)
+    if not n:
+        return
+    lo, hi = min(int(posA.min()), int(posB.min())), max(int(posA.max()), int(posB.max()))
+    _native.check(ctx.lib.tdt_cluster_columns(ctx.handle, _native.ptr(posA), _native.ptr(posB), n, _native.ptr(off), len(off) - 1, float(epsilon), int(m),
+                                              hi if lo >= 0 else 0, _native.ptr(lab32), None, None))
+
+
+def _native_candidates(tables, sample, is_mp, epsilon, m, min_contig, T):
+    """tiddit_cluster.main (:47-254) from the native signal tables of this process: the signal table is written into pinned int32
+    columns by the library, clustered on the device, and the members of every candidate come back as flat arrays in the reference's
+    order — the Python below runs once per CANDIDATE.  -> candidates[chrA][chrB][cluster id] for the (chrA, *) pairs the tables hold."""
+    import time
+    global _POOL
+    t0 = time.time()
+    n, nb = tables.cluster_table(is_mp, min_contig)
+    if _POOL is None:
+        from .hostutil import PinnedPool
+        _POOL = PinnedPool()
+    posA, posB, lab32 = (_POOL.take(k, n, numpy.int32) for k in ("posA", "posB", "labels"))
+    off, ba, bb = tables.cluster_columns(posA, posB, nb)
+    T["signal table (native, into pinned columns)"] = time.time() - t0
+    t0 = time.time()
+    cluster_columns_device(posA, posB, off, epsilon, m, lab32)
+    T["sort + DBSCAN (device)"] = time.time() - t0
+    t0 = time.time()
+    g = tables.regroup(lab32)
+    names = tables.names
+    candidates = {}
+    slots = []                                              # per bucket: candidates[chrA][chrB]
+    for a, b in zip(ba.tolist(), bb.tolist()):              # header order of (chrA, chrB): the loops of :140-147
+        slots.append(candidates.setdefault(names[a], {}).setdefault(names[b], {}))
+    W = ("False", "True")
+    frag = g["names"].decode().split("\n")
+    sA, eA, sB, eB, pA, pB = (g[k].tolist() for k in ("startA", "endA", "startB", "endB", "posA", "posB"))
+    oA, oB = [W[x] for x in g["oriA"].tolist()], [W[x] for x in g["oriB"].tolist()]
+    lo = 0
+    for bkt, cid, nd, ns in g["cand"].tolist():
+        mid, hi = lo + nd, lo + nd + ns
+        cand = slots[bkt][cid] = _new_candidate()
+        d_names, s_names = set(frag[lo:mid]), set(frag[mid:hi])
+        cand["samples"].add(sample)
+        cand["sample_discordants"][sample] = set(d_names)
+        cand["sample_splits"][sample] = set(s_names)
+        cand["sample_contigs"][sample] = set([])
+        cand["discordants"], cand["splits"] = d_names, s_names
+        A, B = cand["positions_A"], cand["positions_B"]
+        A["start"], A["end"], B["start"], B["end"] = sA[lo:hi], eA[lo:hi], sB[lo:hi], eB[lo:hi]
+        A["discordants"], B["discordants"], A["orientation_discordants"], B["orientation_discordants"] = pA[lo:mid], pB[lo:mid], oA[lo:mid], oB[lo:mid]
+        A["splits"], B["splits"], A["orientation_splits"], B["orientation_splits"] = pA[mid:hi], pB[mid:hi], oA[mid:hi], oB[mid:hi]
+        lo = hi
+    T["regroup + breakpoints"] = time.time() - t0
+    return candidates
+
+
+def _handed_over(prefix, chromosomes, contig_length, samples, min_contig, skip_assembly):
+    """the native tables tiddit_signal.main of THIS process wrote the sample's files from, if they describe the same contigs"""
+    if not skip_assembly or len(samples) != 1:
+        return None, None
+    from . import tiddit_signal
+    paths = ("{}_tiddit/discordants_{}.tab".format(prefix, samples[0]), "{}_tiddit/splits_{}.tab".format(prefix, samples[0]))
+    tables = tiddit_signal.written_tables(*paths)
+    if tables is None or tables.names != list(chromosomes) or tables.min_contig > min_contig:
+        return None, None
+    if any(contig_length.get(n) != ln for n, ln in zip(tables.names, tables.lengths)):
+        return None, None
+    return tables, tiddit_signal.table_owners(*paths)
+
+
+def _is_sharded():
+    try:
+        import torch.distributed as _dist
+        return _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+    except ImportError:
+        return False
+
+
 def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=False):
     import time
+    STAGE_SECONDS.clear()
+    sharded = _is_sharded()
+    tables, owner = _handed_over(prefix, chromosomes, contig_length, samples, min_contig, skip_assembly)
+    if tables is not None and (owner is not None) == sharded:
+        candidates = _native_candidates(tables, samples[0], is_mp, epsilon, m, min_contig, STAGE_SECONDS)
+        t0 = time.time()
+        _finish_candidates(candidates, is_mp, min_reads)
+        STAGE_SECONDS["regroup + breakpoints"] += time.time() - t0
+        if sharded:
+            # every rank holds the candidates of the chrA it owns: rank 0 puts them together in header order (the order of :140-147)
+            import pickle
+            import torch.distributed as _dist
+            from .dist import gather_bytes
+            t1 = time.time()
+            parts = gather_bytes(pickle.dumps(candidates, protocol=4), 0)
+            if _dist.get_rank() == 0:
+                mine = [pickle.loads(p) for p in parts]
+                candidates = {}
+                for t, chrA in enumerate(chromosomes):
+                    part = mine[int(owner[t])]
+                    if chrA in part:
+                        candidates[chrA] = part[chrA]
+            elif root_only:
+                candidates = None
+            STAGE_SECONDS["candidates to rank 0"] = time.time() - t1
+        return candidates
     t0 = time.time()
     signals, positions = _read_signals(prefix, samples, contig_length, is_mp, min_contig, skip_assembly)
-    STAGE_SECONDS.clear()
     STAGE_SECONDS["parse .tab"] = time.time() - t0
     t0 = time.time()
 
     order = [(a, b) for a in chromosomes if a in positions for b in chromosomes if b in positions[a]]
     bucket_arrays = [numpy.array(positions[a][b], dtype=numpy.int64).reshape(-1, 3) for a, b in order]
-    try:
-        import torch.distributed as _dist
-        sharded = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
-    except ImportError:
-        sharded = False
     if sharded:
         import os
+        import torch.distributed as _dist
         labels = cluster_buckets_sharded(bucket_arrays, epsilon, m, min_cut=int(os.environ.get("TIDDIT_CLUSTER_MIN_CUT", "32768")))
     else:
         labels = cluster_buckets(bucket_arrays, epsilon, m)
@@ -404,40 +485,23 @@ def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_in
             cand["positions_B"][name].append(int(rec[5]))
             cand["positions_B"]["orientation_" + name].append(rec[6])
             cand["sample_" + name][sample].add(qname)
-
-    for chrA in candidates:
-        for chrB in candidates[chrA]:
-            for cand in candidates[chrA][chrB].values():
-                cand["N_discordants"] = len(cand["discordants"])
-                cand["N_splits"] = len(cand["splits"])
-                cand["N_contigs"] = len(cand["contigs"])
-                A, B = cand["positions_A"], cand["positions_B"]
-                if cand["N_splits"] and min_reads <= cand["N_splits"]:      # enough split reads: their mode (:266-268)
-                    cand["posA"], cand["posB"] = _mode(A["splits"]), _mode(B["splits"])
-                elif cand["N_contigs"]:
-                    cand["posA"], cand["posB"] = _mode(A["contigs"]), _mode(B["contigs"])
-                elif cand["N_splits"]:
-                    cand["posA"], cand["posB"] = _mode(A["splits"]), _mode(B["splits"])
-                else:
-                    cand["posA"], cand["posB"] = _breakpoints_from_discordants(cand, is_mp)
-                cand["startB"] = min(B["start"])
-                cand["endB"] = max(B["end"])
-                cand["startA"] = min(A["start"])
-                cand["endA"] = max(A["end"])
+    _finish_candidates(candidates, is_mp, min_reads)
     STAGE_SECONDS["regroup + breakpoints"] = time.time() - t0
     return candidates
 
 
 def main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
-    """``tiddit_cluster.main`` (tiddit_cluster.pyx:39-336): .tab files -> candidates dictionary.  (The collector is off while the row
+    """``tiddit_cluster.main`` (tiddit_cluster.pyx:39-336): .tab files -> candidates dictionary.  (The collector is off while the
     tables are built: hostutil.quiet_gc.)"""
     with quiet_gc():
         return _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads)
 
 
 def main_sharded(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads):
-    """:func:`main` for one process per GPU (torch.distributed initialised): every rank parses the signal files, the buckets are
-    clustered where :func:`cluster_buckets_sharded` puts them, and only rank 0 regroups the signals into the candidates dictionary
-    (the other ranks return None)."""
+    """:func:`main` for one process per GPU (torch.distributed initialised).  After tiddit_signal.main_sharded of the same job every
+    rank holds the native tables of the chrA it owns: it clusters THEIR buckets on its GPU and regroups THEIR candidates; rank 0
+    receives the finished candidates (pickled, ~10^4 of them) and returns the dictionary (the other ranks return None).  On files
+    from elsewhere every rank parses the text, the buckets are clustered where :func:`cluster_buckets_sharded` puts them and rank 0
+    regroups."""
     with quiet_gc():
         return _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=True)

@@ -9,7 +9,11 @@ Redesign: the reference forks one joblib worker per contig and calls Python once
 (``worker`` :147-228).  Here ONE process streams the BAM through the C record decoder
 (``bamio.BamReader``); the packed start/end/mapq/flag arrays of every batch go to the device coverage
 histogram (bin 50, same read filter, :171-182), and the signal predicates (:184-221) are evaluated on
-whole arrays — only the ~1 % of reads that are discordant, split or clipped are touched one by one.
+whole arrays on the device (``tdt_signal_scan``).  The ~1 % of reads that are discordant, split or clipped go from the
+batch into NATIVE signal tables (``sigtab.SignalTables``, csrc/tdt_sigtab.hip): merged per (chrA, chrB, fragment) while the file is
+still being scanned, formatted as the .tab / clip files by the host thread pool, and handed to ``tiddit_cluster`` in the same
+process — no Python object per read anywhere.  The literal Python merge (``_merge_and_write``) is what the host-ingest mode
+(``TIDDIT_HOST_INGEST=1``) runs, and what the native tables are tested against.
 ``threads`` and ``skip_index`` are accepted for signature compatibility and ignored (no index needed).
 """
 import concurrent.futures
@@ -242,80 +246,23 @@ def select_discordant(batch, contig_ok, min_q, max_ins, ctx=None):
     return out[:cnt.value]
 
 
-class EarlyTables:
-    """The (chrA, chrB, fragment) dictionaries of tiddit_signal.main (:246-284), filled WHILE the file is scanned.
+def _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None):
+    """One pass over the BAM -> (header, contigs processed, coverage dict, discordant rows, split rows, clip entries, tables).
 
-    main() walks the contigs in header order and, inside a contig, its rows in file order.  On a coordinate-sorted file whose contig
-    order is the header's that IS the order in which ``scan_signals`` produces rows, so a batch's rows can be merged as soon as they
-    exist — on the worker thread, behind the device ingest of the next batch — and main() finds the dictionaries ready.  A row out
-    of contig order switches the early merge off (``ok`` False); main() then merges the per-contig lists as before.
-
-    ``data[chrA][chrB][fragment]`` = the fragment's reads (each ``row[3:]``) as in the reference, and — once the second read has
-    arrived, i.e. the row of :298-318 is complete — two more entries: ``(fragment, chrA, chrB, fields as written)`` and the text line.
-    ``splits[chrA][chrB][fragment]`` = the concatenated fields (:282); ``slines[..]`` = the line as main() writes it."""
-
-    def __init__(self, all_contigs, kept_contigs, enabled=True):
-        self.ok = bool(enabled)
-        self.rank_of = {c: i for i, c in enumerate(kept_contigs)}          # chromosomes of main(): the contigs of at least min_contig, in header order
-        self.last = {"d": -1, "s": -1}
-        self.data = {a: {b: {} for b in all_contigs} for a in self.rank_of}
-        self.splits = {a: {b: {} for b in all_contigs} for a in self.rank_of}
-        self.slines = {a: {b: {} for b in all_contigs} for a in self.rank_of}
-
-    def add(self, chrom, rows, which):
-        """rows of contig `chrom` (file order), which = "d" (discordant rows of worker, :214-221) or "s" (split rows)"""
-        r = self.rank_of.get(chrom)
-        if r is None or not self.ok:
-            return
-        if r < self.last[which]:
-            self.ok = False
-            return
-        self.last[which] = r
-        if which == "d":
-            tab = self.data
-            for signal in rows:
-                chrA = signal[0]
-                a = tab.get(chrA)
-                if a is not None:
-                    chrB = signal[1]
-                    reads = a[chrB].setdefault(signal[2], [])
-                    reads.append(signal[3:])
-                    if len(reads) == 2:
-                        first, second = reads
-                        if chrA == chrB:
-                            if second[-1] < first[-1]:           # QUIRK (:307): compares the two read_chr strings, always equal
-                                first, second = second, first
-                        elif first[-1] != chrA:
-                            first, second = second, first
-                        out = first[0:-1] + second[0:-1]
-                        reads.append((signal[2], chrA, chrB, out))
-                        reads.append("{}\t{}\t{}\t{}\n".format(signal[2], chrA, chrB, "\t".join(map(str, out))))
-        else:
-            tab, lines = self.splits, self.slines
-            for signal in rows:
-                chrA = signal[0]
-                a = tab.get(chrA)
-                if a is not None:
-                    f = a[signal[1]].setdefault(signal[2], [])
-                    f += signal[3:]
-                    lines[chrA][signal[1]][signal[2]] = "{}\t{}\t{}\t{}\n".format(signal[2], chrA, signal[1], "\t".join(map(str, f)))
-
-
-def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None):
-    """One pass over the BAM: -> (header, contigs processed, coverage dict, per-contig discordant rows,
-    split rows, clip FASTA entries).  The discordant and split rows are what ``worker`` returns (:228); the clip entries
-    are pairs whose joined content is the contig's clip FASTA in file order: ``[header, sequence + "\n"]`` strings, one per read,
-    with the host ingest; ``[bytes, ""]``, one per contig run of a batch, already formatted by ``tdt_format_clips``, with the
-    device ingest.  ``_clip_bytes(entry)`` gives the bytes of either — joining is what every consumer does (:223-226).
+    Device ingest (the default): ``tables`` is a :class:`sigtab.SignalTables` holding every row and clip entry, merged; the three row
+    containers are None.  Host ingest (``TIDDIT_HOST_INGEST=1``): ``tables`` is None and the per-contig Python lists are filled as
+    ``worker`` returns them (:228) — discordant rows, split rows, and clip entries ``[header, sequence + "\n"]``.
 
     shard = (rank, world): only the records that start in this rank's byte range of the file (bamio.DeviceBamReader); the
     seam offsets are left in ``LAST_SEAM`` for dist.check_seams.  reduce_bins(hist) -> float64 array of ALL the histogram's
     bins (the sharded caller all-reduces them there); default: this process's own bins."""
     max_ins = int(max_ins)         # the reference's `int max_ins` argument truncates a float percentile (:147,:230; probed with Cython 3.2)
+    from . import bamio
     carry = None
     if shard is None and os.environ.get("TIDDIT_HOST_INGEST") != "1":
-        from . import bamio
         carry = bamio.take_carry(bam_file_name, bin_size)      # the statistics pass of this process left its sampled batches in HBM
+    else:
+        bamio.set_carry(None)                                    # (a carry nobody will consume: its batches, reader and histogram go now)
     if carry is not None:
         reader = carry.reader
     elif shard is None:
@@ -332,65 +279,32 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(names, lengths)], bin_size)
         if hasattr(reader, "bin_for"):
             reader.bin_for(hist)                 # the ingest kernel writes the coverage records for this bin size
-    data = {n: [] for n in names}
-    splits = {n: [] for n in names}
-    clips = {n: [] for n in names}
     T = SCAN_SECONDS
     T.clear()
-    T.update({"ingest (inflate + decode, device)": 0.0, "coverage push": 0.0, "field copies + predicates (host)": 0.0, "clip rows": 0.0,
-              "split rows": 0.0, "discordant select + rows": 0.0})
-    # the per-fragment merge of main() runs while the file is scanned (EarlyTables)
-    early = EarlyTables(list(names), [names[t] for t, ok in enumerate(big) if ok], enabled=shard is None)
-    merge_early = early.add
+    T.update({"ingest (inflate + decode, device)": 0.0, "coverage push": 0.0})
+    tables = data = splits = clips = None
+    if isinstance(reader, DeviceBamReader):
+        from .sigtab import SignalTables
+        tables = SignalTables(names, lengths, min_contig)
+        T.update({"predicates + gather of the selected reads (device)": 0.0, "signal tables (native: clip entries, rows, merge; beside the ingest)": 0.0})
+    else:
+        data = {n: [] for n in names}
+        splits = {n: [] for n in names}
+        clips = {n: [] for n in names}
+        T.update({"field copies + predicates (host)": 0.0, "clip rows": 0.0, "split rows": 0.0, "discordant select + rows": 0.0})
 
     def rows_of(sel):
-        """clip / split / discordant rows of one batch's selected reads (host copies only: runs on the worker thread while the device
-        ingests the next batch — the main thread waits inside the library without the GIL)"""
+        """the selected reads of one batch into the native tables (runs on the worker thread while the device ingests the next batch:
+        the main thread waits inside the library, and so does this one — neither holds the GIL)"""
         t4 = time.time()
-        stid, act = sel.tid, sel.action
-        clip_k = numpy.flatnonzero(act & 2)
-        if len(clip_k):
-            edges = numpy.flatnonzero(numpy.diff(stid[clip_k])) + 1
-            for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(clip_k)]])):
-                chrom = names[stid[clip_k[lo]]]
-                clips[chrom].append([sel.clip_fasta(clip_k[lo:hi], chrom), ""])
-        t5 = time.time()
-        T["clip rows"] += t5 - t4
-        which4 = numpy.flatnonzero(act & 4)
-        tids4 = stid[which4]
-        runs4 = [] if not len(which4) else [int(t) for t in tids4[numpy.concatenate([[0], numpy.flatnonzero(numpy.diff(tids4)) + 1])]]
-        before = {t: len(splits[names[t]]) for t in set(runs4)}
-        split_rows_native(sel, which4, names, min_q, splits)
-        if early.ok:
-            if len(set(runs4)) != len(runs4):
-                early.ok = False                                 # a contig twice in one batch: not coordinate sorted
-            for t in runs4:
-                merge_early(names[t], splits[names[t]][before[t]:], "s")
-        t6 = time.time()
-        T["split rows"] += t6 - t5
-        which = numpy.flatnonzero(act & 8)
-        rb = sel.raw_bytes
-        cols = zip(stid[which].tolist(), sel.mate_tid[which].tolist(), sel.pos[which].tolist(), sel.end[which].tolist(),
-                   sel.flag[which].tolist(), sel.rec_off[which].tolist())
-        cur_t, cur_rows = None, None
-        for t_, m_, p_, e_, f_, o_ in cols:
-            chrom, mate = names[t_], names[m_]
-            chrA, chrB = (mate, chrom) if mate < chrom else (chrom, mate)
-            qname = rb[o_ + 36:o_ + 35 + rb[o_ + 12]].decode()          # block_size, 32 fixed bytes, then l_read_name bytes (NUL included)
-            row = [chrA, chrB, qname, p_ + 1, e_ + 1, bool(f_ & 0x10), chrom]
-            data[chrom].append(row)
-            if t_ != cur_t:
-                if cur_rows:
-                    merge_early(names[cur_t], cur_rows, "d")
-                cur_t, cur_rows = t_, []
-            cur_rows.append(row)
-        if cur_rows:
-            merge_early(names[cur_t], cur_rows, "d")
-        T["discordant select + rows"] += time.time() - t6
+        tables.add(sel.meta, sel.raw_end, sel.raw, min_q,
+                   literal=lambda k: SA_analysis(_ReadProxy(sel, k), min_q, "SA", names[int(sel.tid[k])]))     # (an unusual SA tag: the literal code, and its exceptions)
+        T["signal tables (native: clip entries, rows, merge; beside the ingest)"] += time.time() - t4
 
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     pending = None
     t0 = time.time()
+
     def all_batches():
         if carry is None:
             yield from reader.batches()
@@ -405,34 +319,32 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
         for b in all_batches():
             t1 = time.time()
             T["ingest (inflate + decode, device)"] += t1 - t0
-            if not isinstance(b, DeviceBatch):
-                tid = b.tid
-                flag = b.flag.astype(numpy.int32)
-                placed = tid >= 0
-                ok_contig = numpy.zeros(len(tid), dtype=bool)
-                ok_contig[placed] = big[tid[placed]]
-            t2 = time.time()
-            # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
             if isinstance(b, DeviceBatch):                      # the decoded arrays are already in HBM
-                hist.push_device_batch(b, min_q, big)
-            else:
-                edges = numpy.flatnonzero(numpy.diff(tid)) + 1
-                for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
-                    t = int(tid[lo])
-                    if t >= 0 and big[t]:
-                        hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
-            t3 = time.time()
-            T["coverage push"] += t3 - t2
-            if isinstance(b, DeviceBatch):
+                hist.push_device_batch(b, min_q, big)           # coverage (filter on the device, :171-182)
+                t3 = time.time()
+                T["coverage push"] += t3 - t1
                 # the per-read chain of worker (:171-221) on the device; only the selected reads come back (fields + raw records)
                 sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
-                t4 = time.time()
-                T["predicates + gather of the selected reads (device)"] = T.get("predicates + gather of the selected reads (device)", 0.0) + (t4 - t3) + (t2 - t1)
+                T["predicates + gather of the selected reads (device)"] += time.time() - t3
                 if pending is not None:
-                    pending.result()                                  # rows are built in batch order, one batch behind the device
+                    pending.result()                            # batches enter the tables in file order, one batch behind the device
                 pending = pool.submit(rows_of, sel)
                 t0 = time.time()
                 continue
+            tid = b.tid
+            flag = b.flag.astype(numpy.int32)
+            placed = tid >= 0
+            ok_contig = numpy.zeros(len(tid), dtype=bool)
+            ok_contig[placed] = big[tid[placed]]
+            t2 = time.time()
+            # coverage: runs of equal tid go to the device as they are (filter on device, :171-182)
+            edges = numpy.flatnonzero(numpy.diff(tid)) + 1
+            for lo, hi in zip(numpy.concatenate([[0], edges]), numpy.concatenate([edges, [len(tid)]])):
+                t = int(tid[lo])
+                if t >= 0 and big[t]:
+                    hist.push(t, b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], min_q)
+            t3 = time.time()
+            T["coverage push"] += t3 - t2
             primary = ok_contig & ((flag & 0x404) == 0) & ((flag & 0x900) == 0) & (b.mapq >= min_q)   # :171,:184,:188
             same_chr = b.mate_tid == tid
             abs_isize = numpy.abs(b.tlen.astype(numpy.int64))
@@ -469,6 +381,11 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
             T["discordant select + rows"] += t0 - t6
         if pending is not None:
             pending.result()
+    except BaseException:
+        if tables is not None:
+            pool.shutdown(wait=True)
+            tables.close()
+        raise
     finally:
         pool.shutdown(wait=True)                              # (also on an error: no row thread outlives the scan)
     if shard is not None:
@@ -485,19 +402,29 @@ def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_
                 o = hist.offset(i)
                 coverage[n] = allbins[o:o + hist.nbins(i)[0]].copy()
     hist.close()
-    PREMERGED.clear()
-    if early.ok and isinstance(reader, DeviceBamReader):
-        PREMERGED["tables"] = (early.data, early.splits, data, splits, early.slines)   # (keyed to the very lists main() merges)
+    return header, chromosomes, coverage, data, splits, clips, tables
+
+
+def scan_signals(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, bin_size=50, shard=None, reduce_bins=None):
+    """:func:`_scan` with the rows as Python lists whichever way the file was read: -> (header, contigs processed, coverage dict,
+    per-contig discordant rows, split rows, clip FASTA entries) — what the reference's ``worker`` returns per contig (:228).  A clip
+    entry is a pair whose joined content is FASTA text: ``[header, sequence + "\n"]`` strings, one per read, with the host ingest;
+    ``[bytes, ""]``, the contig's whole text, with the device ingest (``_clip_bytes(entry)`` gives the bytes of either)."""
+    header, chromosomes, coverage, data, splits, clips, tables = _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len,
+                                                                       bin_size, shard, reduce_bins)
+    if tables is not None:
+        data, splits = tables.rows()
+        clips = {n: ([[tables.clips(t), ""]] if tables.clips(t) else []) for t, n in enumerate(tables.names)}
+        tables.close()
     return header, chromosomes, coverage, data, splits, clips
 
 
 _SCAN_CACHE = {}
 STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
-SCAN_SECONDS = {}           # ... and of the last scan_signals() pass, by what the host waited for
-LAST_SEAM = {}              # seam offsets of the last sharded scan_signals() pass (dist.check_seams)
-PREMERGED = {}              # the (chrA, chrB, fragment) dictionaries the last scan_signals() merged while it scanned (see rows_of)
-AFTER_SCAN = []             # callables main() invokes once the file has been scanned, before the tables are merged and written (host-only work from there on)
-WRITTEN_TABLES = {}         # (discordants path, splits path) -> stamps + the rows the last main() wrote there (tiddit_cluster reads them back)
+SCAN_SECONDS = {}           # ... and of the last scan pass, by what the host waited for
+LAST_SEAM = {}              # seam offsets of the last sharded scan pass (dist.check_seams)
+AFTER_SCAN = []             # callables main() invokes once the file has been scanned, before the tables are written (host-only work from there on)
+WRITTEN_TABLES = {}         # (discordants path, splits path) -> stamps + the native tables the last main() wrote them from (tiddit_cluster takes them over)
 
 
 def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bin_size, skip_index, min_anchor_len, min_clip_len):
@@ -521,25 +448,20 @@ def worker(chromosome, bam_file_name, ref, prefix, min_q, max_ins, sample_id, bi
 
 
 def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id):
-    """the merge loop and the three writers of tiddit_signal.main (:246-332) over per-contig row lists in file order"""
+    """the merge loop and the three writers of tiddit_signal.main (:246-332) over per-contig row lists in file order — the literal
+    Python form (host ingest; the device ingest's rows never leave the native tables: :func:`_write_tables`)"""
     all_contigs = [c["SN"] for c in header["SQ"]]
-    pre = PREMERGED.pop("tables", None)
-    if pre is not None and pre[2] is res_data and pre[3] is res_splits and list(pre[0]) == list(chromosomes):
-        data, splits = pre[0], pre[1]                                        # merged while the file was scanned (scan_signals)
-    else:
-        pre = None
-        data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
-        splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
+    data = {a: {b: {} for b in all_contigs} for a in chromosomes}        # :246-256
+    splits = {a: {b: {} for b in all_contigs} for a in chromosomes}
     os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
-    clip_fasta = []
     with open("{}_tiddit/clips_{}.fa".format(prefix, sample_id), "wb") as all_clips:      # (written last in the reference; same bytes)
         for chrom in chromosomes:                                            # results in contig order (:262-284)
             print("Collecting signals on contig: {}".format(chrom))
-            for signal in (res_data[chrom] if pre is None else ()):
+            for signal in res_data[chrom]:
                 if signal[0] not in data:
                     continue
                 data[signal[0]][signal[1]].setdefault(signal[2], []).append(signal[3:])
-            for signal in (res_splits[chrom] if pre is None else ()):
+            for signal in res_splits[chrom]:
                 if signal[0] not in splits:
                     continue
                 splits[signal[0]][signal[1]].setdefault(signal[2], [])
@@ -550,25 +472,11 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                     text = _clip_bytes(clip)
                     f.write(text)
                     all_clips.write(text)                # clips_{sample}.fa is the per-contig files one after the other (:328-332)
-            clip_fasta.append(path)
     print("Writing signals to file")
-
-    # the rows as written, per contig pair in file order: tiddit_cluster in the same process takes them from here (no text re-parse).
-    # disc_rows: (chrA, chrB, [(fragment, chrA, chrB, fields), ...]); split_rows: (chrA, chrB, {fragment: fields})
-    disc_rows, split_rows = [], []
     disc_path, split_path = "{}_tiddit/discordants_{}.tab".format(prefix, sample_id), "{}_tiddit/splits_{}.tab".format(prefix, sample_id)
     with open(disc_path, "w") as f:      # :298-318
         for chrA in data:
             for chrB in data[chrA]:
-                if pre is not None:                     # the rows were formatted when their second read arrived: same order, same text
-                    frags = data[chrA][chrB]
-                    if frags:
-                        rows = [reads[2] for reads in frags.values() if len(reads) > 2]
-                        f.write("".join([reads[3] for reads in frags.values() if len(reads) > 2]))
-                        if rows:
-                            disc_rows.append((chrA, chrB, rows))
-                    continue
-                rows = []
                 for fragment, reads in data[chrA][chrB].items():
                     if len(reads) < 2:
                         continue
@@ -580,24 +488,88 @@ def _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefi
                         first, second = second, first
                     out = first[0:-1] + second[0:-1]
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, out))))
-                    rows.append((fragment, chrA, chrB, out))
-                if rows:
-                    disc_rows.append((chrA, chrB, rows))
     with open(split_path, "w") as f:           # :320-326
         for chrA in splits:
             for chrB in splits[chrA]:
-                if pre is not None:
-                    frags = splits[chrA][chrB]
-                    if frags:
-                        f.write("".join(pre[4][chrA][chrB].values()))
-                        split_rows.append((chrA, chrB, frags))
-                    continue
                 for fragment, fields in splits[chrA][chrB].items():
                     f.write("{}\t{}\t{}\t{}\n".format(fragment, chrA, chrB, "\t".join(map(str, fields))))
-                if splits[chrA][chrB]:
-                    split_rows.append((chrA, chrB, splits[chrA][chrB]))
+    _forget_tables()
+
+
+def _write_tables(scanned, merged, chromosomes, prefix, sample_id, group=None, owner=None):
+    """The three writers of tiddit_signal.main (:298-332) from the native tables: clips/{contig}.fa and their concatenation
+    clips_{sample}.fa, discordants_{sample}.tab, splits_{sample}.tab.  Every file is a sequence of per-contig blocks in header order
+    (the rows of one chrA; one contig's clip entries), so the writers never hold a file in Python: the library writes each block at its
+    offset (``tdt_sigtab_pwrite``).  On N ranks — `scanned` holds the clip entries of this rank's share of the file, `merged` the rows
+    of the chrA this rank owns — the block sizes of every rank meet in one all-gather, rank 0 creates the files at their final size and
+    every rank places its own blocks: nothing but the sizes travels.  (One node, one output directory: BASELINE configs[4].)
+    `merged` stays alive for tiddit_cluster.main of this process (:func:`written_tables`)."""
+    names = merged.names
+    n = len(names)
+    kept = [i for i, ln in enumerate(merged.lengths) if ln >= merged.min_contig]                 # main()'s `chromosomes`, as contig ids
+    mine = numpy.stack([merged.sizes(0), merged.sizes(1), scanned.sizes(2)])                     # [what][contig]
+    rank, world = 0, 1
+    if owner is not None:
+        import torch.distributed as dist
+        from . import dist as tdist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        sizes = tdist.allgather_i64(mine.reshape(-1), group).reshape(world, 3, n)
+    else:
+        sizes = mine.reshape(1, 3, n)
+    total = sizes.sum(axis=0)                                                                    # [what][contig]
+    before = numpy.cumsum(sizes, axis=0) - sizes                                                 # bytes of the earlier ranks, per block
+    d_path, s_path = "{}_tiddit/discordants_{}.tab".format(prefix, sample_id), "{}_tiddit/splits_{}.tab".format(prefix, sample_id)
+    all_path = "{}_tiddit/clips_{}.fa".format(prefix, sample_id)
+    clip_path = lambda t: "{}_tiddit/clips/{}.fa".format(prefix, names[t])
+    if rank == 0:
+        os.makedirs("{}_tiddit/clips".format(prefix), exist_ok=True)
+        for c in chromosomes:
+            print("Collecting signals on contig: {}".format(c))
+        print("Writing signals to file")
+        for path, size in [(d_path, int(total[0][kept].sum())), (s_path, int(total[1][kept].sum())), (all_path, int(total[2][kept].sum()))] + \
+                          [(clip_path(t), int(total[2][t])) for t in kept]:
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o666)
+            os.ftruncate(fd, size)
+            os.close(fd)
+    if world > 1:
+        dist.barrier(group)
+    base = numpy.zeros((3, n), dtype=numpy.int64)                                                # where a contig's block starts in the three big files
+    for w in range(3):
+        base[w][kept] = numpy.cumsum(total[w][kept]) - total[w][kept]
+    for w, path in ((0, d_path), (1, s_path)):
+        todo = [t for t in kept if mine[w][t]]
+        if todo:
+            fd = os.open(path, os.O_WRONLY)
+            try:
+                for t in todo:
+                    merged.pwrite(w, t, fd, int(base[w][t] + before[rank][w][t]))
+            finally:
+                os.close(fd)
+    todo = [t for t in kept if mine[2][t]]
+    if todo:
+        fd_all = os.open(all_path, os.O_WRONLY)
+        try:
+            for t in todo:
+                scanned.pwrite(2, t, fd_all, int(base[2][t] + before[rank][2][t]))
+                fd = os.open(clip_path(t), os.O_WRONLY)
+                try:
+                    scanned.pwrite(2, t, fd, int(before[rank][2][t]))
+                finally:
+                    os.close(fd)
+        finally:
+            os.close(fd_all)
+    if world > 1:
+        dist.barrier(group)                                      # the files are complete when any rank returns
+    _forget_tables()
+    WRITTEN_TABLES[(os.path.abspath(d_path), os.path.abspath(s_path))] = (_file_stamp(d_path), _file_stamp(s_path), merged, owner)
+    if scanned is not merged:
+        scanned.close()
+
+
+def _forget_tables():
+    for ent in WRITTEN_TABLES.values():
+        ent[2].close()
     WRITTEN_TABLES.clear()
-    WRITTEN_TABLES[(os.path.abspath(disc_path), os.path.abspath(split_path))] = (_file_stamp(disc_path), _file_stamp(split_path), disc_rows, split_rows)
 
 
 def _file_stamp(path):
@@ -606,9 +578,8 @@ def _file_stamp(path):
 
 
 def written_tables(disc_path, split_path):
-    """the (discordant, split) rows of the last `main` of THIS process if the two files on disk are still the ones it wrote
-    (size, mtime, inode) — else None, and the caller parses the text.  Per contig pair in file order: discordants
-    (chrA, chrB, [(fragment, chrA, chrB, fields as written, not yet str), ...]), splits (chrA, chrB, {fragment: fields})."""
+    """the native signal tables (sigtab.SignalTables) of the last `main` of THIS process if the two files on disk are still the ones
+    it wrote (size, mtime, inode) — else None, and the caller parses the text."""
     ent = WRITTEN_TABLES.get((os.path.abspath(disc_path), os.path.abspath(split_path)))
     if ent is None:
         return None
@@ -617,37 +588,44 @@ def written_tables(disc_path, split_path):
             return None
     except OSError:
         return None
-    return ent[2], ent[3]
+    return ent[2]
+
+
+def table_owners(disc_path, split_path):
+    """the owner rank of every contig's rows when the tables :func:`written_tables` returns are one rank's share of an N-rank job
+    (else None)"""
+    ent = WRITTEN_TABLES.get((os.path.abspath(disc_path), os.path.abspath(split_path)))
+    return None if ent is None else ent[3]
 
 
 def _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
     t = time.time()
-    header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
+    header, chromosomes, coverage_data, res_data, res_splits, res_clips, tables = _scan(
         bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50)
     STAGE_SECONDS.clear()
-    STAGE_SECONDS["scan (ingest, coverage, predicates, rows)"] = time.time() - t
+    STAGE_SECONDS["scan (ingest, coverage, predicates, signal tables)"] = time.time() - t
     STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
     for hook in list(AFTER_SCAN):
         hook()
     t1 = time.time()
-    _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id)
+    if tables is not None:
+        _write_tables(tables, tables, chromosomes, prefix, sample_id)
+    else:
+        _merge_and_write(header, chromosomes, res_data, res_splits, res_clips, prefix, sample_id)
     print("total", time.time() - t)
-    STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
-    t1 = time.time()
-    del res_data, res_splits, res_clips
-    STAGE_SECONDS["free the row lists"] = time.time() - t1
-    STAGE_SECONDS["_end"] = time.time()
+    STAGE_SECONDS["write .tab / clips" if tables is not None else "merge + write .tab / clips"] = time.time() - t1
     return coverage_data
 
 
 def _main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len, group):
-    """tiddit_signal.main with one process per GPU on ONE file (BASELINE configs[4]).  The reference fans out one worker per contig
-    and merges their rows in contig order (:259-284); here rank r scans the records that start in its 1/N of the file's bytes
-    (BGZF blocks are independent; the seams are checked, dist.check_seams), the 50-bp bins meet in ONE exact all-reduce, and the
-    rows of every contig are gathered on rank 0 in RANK order — the file is coordinate sorted, so that is the file order of the
-    single-process scan, and the per-fragment merge (a fragment's two reads may sit on different ranks) runs after the ordered
-    gather exactly as in :262-284.  Rank 0 writes the byte-identical .tab / clip files; every rank returns the coverage dictionary."""
-    import pickle
+    """tiddit_signal.main with one process per GPU on ONE file (BASELINE configs[4]).  The reference fans out one worker per contig and
+    merges their rows in contig order on one core (:259-284).  Here rank r scans the records that start in its 1/N of the file's bytes
+    (BGZF blocks are independent; the seams are checked, dist.check_seams) into its own native tables; the 50-bp bins meet in ONE exact
+    all-reduce; and the rows travel ONCE, in one all-to-all, to the owner rank of their chrA (dist.contig_owners: contigs bin-packed by
+    length).  The owner appends what it receives in RANK order — the file is coordinate sorted, so that is the file order of the
+    single-process scan, and a fragment whose two reads were scanned by different ranks is paired exactly as in :262-284 — formats its
+    chrA's rows and places them in the .tab files itself (:func:`_write_tables`); the clip FASTA blocks are placed by the ranks that
+    scanned them.  No rank gathers rows, and no rank parses text later: tiddit_cluster.main_sharded takes the owner's tables over."""
     import torch
     import torch.distributed as dist
     from . import dist as tdist
@@ -668,33 +646,35 @@ def _main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads
             tdist.allreduce_bins(bins, group)
         return bins.cpu().numpy()
 
-    header, chromosomes, coverage_data, res_data, res_splits, res_clips = scan_signals(
+    header, chromosomes, coverage_data, _, _, _, scanned = _scan(
         bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_len, 50, shard=(rank, world), reduce_bins=reduce_bins)
     STAGE_SECONDS.clear()
-    STAGE_SECONDS["scan (ingest, coverage, predicates, rows; this rank's shard)"] = time.time() - t
+    STAGE_SECONDS["scan (ingest, coverage, predicates, signal tables; this rank's shard)"] = time.time() - t
     STAGE_SECONDS.update({"  " + k: v for k, v in SCAN_SECONDS.items()})
     for hook in list(AFTER_SCAN):
         hook()
-    t1 = time.time()
-    mine = {c: (res_data[c], res_splits[c], [_clip_bytes(x) for x in res_clips[c]]) for c in chromosomes
-            if res_data[c] or res_splits[c] or res_clips[c]}
-    parts = tdist.gather_bytes(pickle.dumps(mine, protocol=4), 0, group)
-    STAGE_SECONDS["row gather"] = time.time() - t1
-    t1 = time.time()
-    if rank == 0:
-        parts = [pickle.loads(p) for p in parts]
-        data = {c: [] for c in chromosomes}
-        splits = {c: [] for c in chromosomes}
-        clips = {c: [] for c in chromosomes}
-        for part in parts:                                   # rank order = file order inside every contig
-            for c, (d, s, cl) in part.items():
-                data[c] += d
-                splits[c] += s
-                clips[c] += [[x, ""] for x in cl]
-        _merge_and_write(header, chromosomes, data, splits, clips, prefix, sample_id)
-    dist.barrier(group)                                      # the files exist when any rank returns
-    STAGE_SECONDS["merge + write .tab / clips"] = time.time() - t1
+    share_and_write(scanned, chromosomes, prefix, sample_id, group)
     return coverage_data
+
+
+def share_and_write(scanned, chromosomes, prefix, sample_id, group=None):
+    """the N-rank job behind the scan: this rank's rows to the owner ranks of their chrA (ONE all-to-all), the owner's merge in rank
+    order, and the output files from every rank's own blocks (:func:`_write_tables`)"""
+    import torch.distributed as dist
+    from . import dist as tdist
+    from .sigtab import SignalTables
+    world = dist.get_world_size(group)
+    t1 = time.time()
+    owner = tdist.contig_owners(scanned.lengths, [ln >= scanned.min_contig for ln in scanned.lengths], world)
+    got = tdist.alltoall_bytes([scanned.export_rows(owner, r) for r in range(world)], group)
+    merged = SignalTables(scanned.names, scanned.lengths, scanned.min_contig)
+    for blob in got:                                             # rank order = file order inside every contig
+        merged.import_rows(blob)
+    STAGE_SECONDS["rows to their owner ranks (all-to-all) + merge"] = time.time() - t1
+    t1 = time.time()
+    _write_tables(scanned, merged, chromosomes, prefix, sample_id, group=group, owner=owner)
+    STAGE_SECONDS["write .tab / clips (every rank its own blocks)"] = time.time() - t1
+    return merged, owner
 
 
 def main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len, group=None):
@@ -705,8 +685,6 @@ def main_sharded(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads,
 
 def main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len):
     """``tiddit_signal.main`` (tiddit_signal.pyx:230-334): signals of every contig -> discordants_/splits_ .tab, clips_ .fa; returns the
-    50-bp coverage dictionary.  (The collector is off while the row tables are built: hostutil.quiet_gc.)"""
+    50-bp coverage dictionary."""
     with quiet_gc():
-        coverage_data = _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len)
-    STAGE_SECONDS["collector back on"] = time.time() - STAGE_SECONDS.pop("_end")
-    return coverage_data
+        return _main(bam_file_name, ref, prefix, min_q, max_ins, sample_id, threads, min_contig, skip_index, min_anchor_len, min_clip_len)

@@ -36,7 +36,7 @@ def _device_figures(lib, h, state):
     return mean, numpy.sqrt(numpy.float64(msd.value)), numpy.float64(pct)
 
 
-def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
+def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False):
     import os
     from . import bamio
     library = {}
@@ -46,7 +46,7 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     # `tiddit --sv` scans the same file for signals next (tiddit_signal.main): the sampled batches stay in HBM with their coverage records
     # written for the 50-bp histogram, and that pass starts from them instead of reading and inflating this part of the file again
     on_device = isinstance(reader, bamio.DeviceBamReader)
-    carry = on_device and os.environ.get("TIDDIT_NO_CARRY") != "1"
+    carry = carry and on_device and os.environ.get("TIDDIT_NO_CARRY") != "1"
     kept, hist = [], None
     if carry:
         from . import tiddit_coverage
@@ -108,6 +108,7 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
         reader.retain = False
         bamio.set_carry(bamio.ScanCarry(bam_file_name, reader, batches, kept, hist))
     else:
+        batches.close()                          # (the generator's finally stops the span thread and hands its pinned buffers back)
         reader.close()
     is_innie, is_outtie = int(state[3]), int(state[4])
     # numpy.average of the read lengths: an exact integer sum over an exact count
@@ -135,7 +136,9 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
     return library
 
 
-def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads):
-    """``tiddit_stats.statistics`` (tiddit_stats.py:5-78); the collector is off meanwhile (hostutil.quiet_gc)."""
+def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False):
+    """``tiddit_stats.statistics`` (tiddit_stats.py:5-78); the collector is off meanwhile (hostutil.quiet_gc).
+    carry=True (the one-process `tiddit --sv` sets it: the signal scan of the same file follows at once and takes it,
+    bamio.take_carry): the sampled batches stay in HBM with an open reader for that scan.  A library caller leaves nothing behind."""
     with quiet_gc():
-        return _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads)
+        return _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=carry)
