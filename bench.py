@@ -755,6 +755,34 @@ def main():
                                             "h2d_prefetched_batches": sum(1 for b in batch_times if b["h2d_prefetched"]),
                                             "rows": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in b.items()} for b in batch_times[:8]]}
             ingest_chunk[0] = 448 << 20
+            # what the BINNED coverage records cost where the pipeline pays for them: the record-decode kernel (bam_decode_fields) with the
+            # reader bound to a 500-bp histogram (it then also computes first_bin, the bin shape and the two table indices of
+            # tiddit_coverage.pyx:50-63 and writes the 8-byte record) against the same kernel unbound — the headline launch reads these records
+            def decode_ms(bind):
+                best = None
+                for _ in range(4):
+                    r = bamio.DeviceBamReader(path, ctx=ctx, chunk=448 << 20)
+                    r.collect_timing = True
+                    hh = None
+                    if bind:
+                        hh = tiddit_coverage.CoverageHistogram([(n_, l_) for n_, l_ in zip(r.references, r.lengths)], 500, ctx=ctx)
+                        r.bin_for(hh)
+                    k = 0
+                    for b in r.batches():
+                        k += len(b)
+                    ms = sum(t["decode_ms"] for t in r.timings)
+                    r.close()
+                    if hh is not None:
+                        hh.close()
+                    best = ms if best is None else min(best, ms)
+                return best, k
+            ms_bound, k_ = decode_ms(True)
+            ms_plain, _ = decode_ms(False)
+            ires["binning"] = {"decode_ms_bound_to_histogram": ms_bound, "decode_ms_unbound": ms_plain, "records": k_,
+                               "binning_ms_per_600M_reads": (ms_bound - ms_plain) / k_ * 600e6,
+                               "decode_ms_per_600M_reads_bound": ms_bound / k_ * 600e6,
+                               "note": "bam_decode_fields (HIP events, best of 4 passes) with and without tdt_ingest_bin_for; the difference scaled to "
+                                       "configs[1]'s 600 M reads is what the binned layout of the headline launch costs in the ingest kernel"}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             lib = ctx.lib
             threads = int(lib.tdt_host_threads(0))
@@ -847,14 +875,39 @@ def main():
 
     # ---- BASELINE configs[3]: `tiddit --sv --skip_assembly` end to end, from the BAM file to the candidates table (rank 0)
     # (one process, one GPU: at N > 1 the section is left out rather than run beside idle ranks)
-    # (N > 1: ONE job over the ranks — byte-range shards of the one BAM, exact all-reduce of the bins, rows gathered in file order,
-    # buckets bin-packed / cut over the ranks: tiddit_amd.__main__.run_sv under WORLD_SIZE > 1 = BASELINE configs[4]'s code path)
+    # (N > 1: ONE job over the ranks — byte-range shards of the one BAM, exact all-reduce of the bins, rows sent to the owner rank of
+    # their chrA, which writes, clusters and regroups them: tiddit_amd.__main__.run_sv under WORLD_SIZE > 1 = BASELINE configs[4]'s code path)
     if not args.no_sv_e2e:
         r_ = sv_e2e(args, ctx, not args.no_cpu_baseline and world == 1, rank, world, local_rank, barrier)
         if rank == 0:
             result["sv_e2e"] = r_
 
     if rank == 0:
+        # every fraction a reader of the driver's one-line record needs, inside `roofline` (the sections' own dictionaries hold the detail)
+        def compact(r, ms_key):
+            rf = r.get("roofline") if r else None
+            if not rf:
+                return None
+            tr = rf.get("traffic")
+            alg = rf.get("algorithmic_bytes_per_launch", rf.get("algorithmic_bytes_per_pass"))
+            return {"ms": rf.get(ms_key), "frac": rf.get("frac"), "traffic_ratio": None if tr is None or not alg else tr / alg}
+        sections = {"coverage_sv": compact(result.get("coverage_sv"), "avg_launch_ms"), "dbscan": compact(result.get("dbscan"), "avg_pass_ms"),
+                    "gc": compact(result.get("gc"), "avg_launch_ms")}
+        ing = result.get("ingest")
+        if ing:
+            sections["ingest"] = {"ms": ing.get("ms_per_step"), "records_per_sec": ing.get("value"), "bam_MB_per_sec": ing.get("bam_MB_per_sec"),
+                                  "bound": "instruction issue (inflate), not HBM: no fraction of the HBM roofline is claimed"}
+            if "binning" in ing:
+                result["roofline"]["binning_ms_per_600M_reads"] = ing["binning"]["binning_ms_per_600M_reads"]
+        sv = result.get("sv_e2e")
+        if sv:
+            sections["sv_e2e"] = {"wall_s": sv.get("wall_s"), "serial_s": sv.get("serial_s")}
+        result["roofline"]["sections"] = {k: v for k, v in sections.items() if v}
+        if "four_array_layout" in result:
+            f4 = result["four_array_layout"]
+            result["roofline"]["contract"] = {"layout": "SURVEY 8(d): start i32, end i32, mapq u8, flag u16 - all of update_coverage in ONE launch, no packing pass",
+                                              "ms": f4["avg_launch_ms"], "frac": f4["frac"], "frac_survey_8d_12B_per_read": f4["frac_survey_8d_12B_per_read"],
+                                              "bins_per_sec": result["config"]["bins"] / (f4["avg_launch_ms"] * 1e-3)}
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
@@ -987,6 +1040,11 @@ def sv_e2e(args, ctx, with_oracle, rank=0, world=1, local_rank=0, barrier=lambda
         stages = dict(cli.STAGE_SECONDS)
         if rep == 0:
             first_stages = stages
+    all_stages = None
+    if world > 1:
+        import torch.distributed as dist
+        all_stages = [None] * world
+        dist.all_gather_object(all_stages, stages)
     if rank != 0:
         return None
     res = {"metric": "tiddit --sv --skip_assembly end to end (BAM file -> candidates table), wall seconds", "wall_s": walls[-1],
@@ -994,8 +1052,18 @@ def sv_e2e(args, ctx, with_oracle, rank=0, world=1, local_rank=0, barrier=lambda
            "first_pass_stage_seconds": {k: round(v, 4) for k, v in first_stages.items()},      # (a fresh process: allocations, first touches)
            "config": {"workload": "BASELINE configs[3]: %d-Mb genome (24 chromosomes + chrM + 2 scaffolds), 30x 150-bp pairs, planted DEL/DUP/INV/BND at 3 per Mb; "
                                   "%.0f MB BAM (zlib level 1, reads cut from the reference), file in the page cache%s" % (mb, os.path.getsize(bam) / 1e6,
-                                  "" if world == 1 else "; ONE job on %d ranks: byte-range shards of the file, rows gathered on rank 0, buckets packed / cut over the ranks" % world)},
+                                  "" if world == 1 else "; ONE job on %d ranks: byte-range shards of the file, rows sent once to the owner rank of their chrA, every owner writes its blocks and clusters / regroups its buckets" % world)},
            "bam_generation_s": t_gen, "candidates": sum(1 for l in open(out + ".candidates.tab") if not l.startswith("#"))}
+    # what only rank 0 does (at N = 1: the stages an N-rank job could not share out) — the Amdahl term of DESIGN.md section 6
+    serial_keys = ("library statistics", "GC bins", "ploidy (masked medians)", "candidates table", "  candidates to rank 0")
+    res["serial_s"] = round(sum(v for k, v in stages.items() if k in serial_keys), 4)
+    res["serial_stages"] = list(serial_keys)
+    if all_stages is not None:
+        keys = []
+        for st in all_stages:
+            keys += [k for k in st if k not in keys]
+        res["stage_seconds_max_over_ranks"] = {k: round(max(st.get(k, 0.0) for st in all_stages), 4) for k in keys}
+        res["stage_seconds_per_rank"] = [{k: round(v, 4) for k, v in st.items()} for st in all_stages]
     if with_oracle:
         res.update(sv_e2e_cpu_legs(mb, bam, fa, out, contigs, walls[-1], args.sv_cpu_full_mb))
     return res

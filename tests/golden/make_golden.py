@@ -8,7 +8,8 @@ below, and only DATA (inputs + the reference's outputs) is written here.  tiddit
 pysam for FastaFile only; a tiny in-memory stand-in (oracle-side tooling, lives in /tmp) serves
 the sequences.  Nothing in tests/, bench.py or smoke() reads /root/reference at run time.
 
-usage: python tests/golden/make_golden.py [--slow]     (--slow adds the 1M-point DBSCAN run, ~6 min)
+usage: python tests/golden/make_golden.py [--slow | --large | --only-y-labels]
+  --slow adds the 1M-point DBSCAN run (~6 min); --large makes ONLY sv_e2e_large.json (the 240-Mb file of bench.py's sv_e2e section, ~12 min)
 """
 import hashlib
 import importlib
@@ -499,6 +500,9 @@ def main():
     M = build_reference()
     if "--only-y-labels" in sys.argv:
         golden_dbscan_y_labels(M, HERE)
+        return
+    if "--large" in sys.argv:       # tests/golden/sv_e2e_large.json: the 240-Mb file bench.py's sv_e2e section times (48 M records; ~12 min here)
+        golden_sv_e2e(M, HERE, params={"total_mb": 240}, name="sv_e2e_large.json")
         return
     golden_coverage(M, HERE)
     golden_gc(M, HERE)

@@ -1,6 +1,7 @@
 """The native coverage table writer (tdt_format_coverage, host code) against the reference's Python formatting
 (`"{}".format(numpy.float64)` rows of print_coverage, tiddit_coverage.pyx:30-44) — CPU only."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -76,3 +77,25 @@ def test_native_fai_matches_python_index(tmp_path):
         py = open(p + ".fai").read()
         _native.check(_native.load().tdt_fasta_write_fai(p.encode(), (p + ".fai2").encode()))
         assert open(p + ".fai2").read() == py and len(want) == 5
+
+
+def test_variant_stage_hand_off_with_stub_modules(tmp_path):
+    """`tiddit --sv` ends by handing the candidates to the reference's own variant stage when that package is importable
+    (__main__.py:193-207); it never is in this image (it needs pysam), so the hand-off is exercised with stand-in modules: same
+    call signatures, variants of every contig written sorted by position behind the header, contigs in header order"""
+    import types
+    from tiddit_amd import __main__ as cli
+    seen = {}
+
+    def variant_main(bam, sv_clusters, args, library, min_mapq, samples, coverage_data, contig_number, max_ins_len, gc_dictionary):
+        seen["args"] = (bam, sorted(sv_clusters), library["mp"], min_mapq, samples, sorted(coverage_data), contig_number, max_ins_len, sorted(gc_dictionary))
+        return {"chr2": [(5, ["chr2", "5", "SV_2"]), (1, ["chr2", "1", "SV_1"])], "chr1": [(9, ["chr1", "9", "SV_3"])], "chrUn": [(1, ["x"])]}
+    variant = types.SimpleNamespace(main=variant_main)
+    header = types.SimpleNamespace(main=lambda bam_header, library, sample_id, version: "##fileformat=VCFv4.1 %s %s" % (sample_id, version))
+    args = types.SimpleNamespace(bam="x.bam")
+    prefix = str(tmp_path / "o")
+    ok = cli.variant_stage(variant, header, prefix, ["chr1", "chr2", "chr3"], {"SQ": []}, {"mp": False}, "S", "3.9.5", args, {"chr1": {}}, 5, ["S"],
+                           {"chr1": None}, {"chr1": 0}, 600, {"chr1": None})
+    assert ok and open(prefix + ".vcf").read() == "##fileformat=VCFv4.1 S 3.9.5\nchr1\t9\tSV_3\nchr2\t1\tSV_1\nchr2\t5\tSV_2\n"
+    assert seen["args"] == ("x.bam", ["chr1"], False, 5, ["S"], ["chr1"], {"chr1": 0}, 600, ["chr1"])
+    assert not cli.variant_stage(None, None, prefix + "2", [], {}, {}, "S", "v", args, {}, 5, [], {}, {}, 1, {}) and not os.path.exists(prefix + "2.vcf")

@@ -218,9 +218,9 @@ def test_bench_runs_every_section_on_two_ranks_sharing_the_gpu(tmp_path):
 
 
 def test_signal_main_on_a_file_that_is_not_in_contig_order(sv_bam, tmp_path):
-    """the rows are merged into the (chrA, chrB, fragment) dictionaries while the file is scanned — legal only while the records come in
-    the header's contig order; here the records of the first contig are moved behind all others: the early merge must switch itself
-    off and the tables must still equal the literal restatement (which visits the contigs in header order, tiddit_signal.pyx:259-284)"""
+    """the rows are merged into the native (chrA, chrB, fragment) tables while the file is scanned — legal only while the records come in
+    the header's contig order; here the records of the first contig are moved behind all others: the incremental merge must switch
+    itself off and the tables must still equal the literal restatement (which visits the contigs in header order, tiddit_signal.pyx:259-284)"""
     import struct
     from tiddit_amd import bamio, tiddit_signal
     bam, fa, info, d = sv_bam
@@ -244,27 +244,18 @@ def test_signal_main_on_a_file_that_is_not_in_contig_order(sv_bam, tmp_path):
     prefix = str(tmp_path / "m")
     os.makedirs(prefix + "_tiddit/clips")
     cov = tiddit_signal.main(path, fa, prefix, 5, 600, "SYN", 1, 1000, False, 60, 25)
-    assert "tables" not in tiddit_signal.PREMERGED                       # (consumed or never offered)
+    tables = tiddit_signal.written_tables(prefix + "_tiddit/discordants_SYN.tab", prefix + "_tiddit/splits_SYN.tab")
+    assert tables is not None and not tables.stats()["discordants_in_order"]       # the incremental merge stood down
     wcov, wdisc, wsplit, wclips, wclip_each = signal_oracle.signal_main(hdr, reads, 5, 600, "SYN", 1000, 60, 25)
     assert open(prefix + "_tiddit/discordants_SYN.tab").read() == wdisc and wdisc.count("\n") > 20
     assert open(prefix + "_tiddit/splits_SYN.tab").read() == wsplit
     assert open(prefix + "_tiddit/clips_SYN.fa").read() == wclips
     for c in wcov:
         assert np.array_equal(cov[c], wcov[c]), c
-    # and on the sorted file the early merge is what main() used
-    seen = {}
-    real = tiddit_signal._merge_and_write
-
-    def spy(header, chromosomes, res_data, res_splits, *a, **k):
-        seen["offered"] = "tables" in tiddit_signal.PREMERGED and tiddit_signal.PREMERGED["tables"][2] is res_data
-        return real(header, chromosomes, res_data, res_splits, *a, **k)
-    tiddit_signal._merge_and_write = spy
-    try:
-        p2 = str(tmp_path / "s")
-        os.makedirs(p2 + "_tiddit/clips")
-        tiddit_signal.main(bam, fa, p2, 5, 600, "SYN", 1, 1000, False, 60, 25)
-        assert seen["offered"]
-        tiddit_signal.main(path, fa, p2, 5, 600, "SYN", 1, 1000, False, 60, 25)
-        assert not seen["offered"]
-    finally:
-        tiddit_signal._merge_and_write = real
+    # and on the sorted file the rows were merged while it was scanned
+    p2 = str(tmp_path / "s")
+    os.makedirs(p2 + "_tiddit/clips")
+    tiddit_signal.main(bam, fa, p2, 5, 600, "SYN", 1, 1000, False, 60, 25)
+    st = tiddit_signal.written_tables(p2 + "_tiddit/discordants_SYN.tab", p2 + "_tiddit/splits_SYN.tab").stats()
+    assert st["discordants_in_order"] and st["splits_in_order"]
+    tiddit_signal._forget_tables()

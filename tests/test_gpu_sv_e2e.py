@@ -166,6 +166,49 @@ def test_sv_on_n_ranks_is_byte_identical(run, tmp_path, world):
     assert all(len(v) == 1 for v in res.values()) and max(shares) < sum(shares)
 
 
+def test_sv_60x_on_one_and_two_ranks(golden_dir, tmp_path):
+    """BASELINE configs[4] names a 60x file: the 24-Mb genome at twice the depth (9.6 M records) as one process and as two ranks
+    sharing the GPU — byte-identical outputs, and the signal tables equal the CPU restatement's on the same file"""
+    import socket
+    import torch.multiprocessing as mp
+    from tiddit_amd import __main__ as cli, synth_bam
+    fx = load_fixture(golden_dir, "sv_e2e.json")
+    P = dict(fx["params"], depth=60)
+    contigs = synth_bam.wgs_contigs(P["total_mb"])
+    fa, bam = str(tmp_path / "ref.fa"), str(tmp_path / "WGS.bam")
+    seqs = synth_bam.write_fasta(fa, contigs, seed=P["fasta_seed"])
+    info = synth_bam.write_wgs_sv_bam(bam, contigs, depth=60, read_len=P["read_len"], insert=P["insert"], insert_sd=P["insert_sd"], seed=P["seed"],
+                                      sv_per_mb=P["sv_per_mb"], threads=min(16, os.cpu_count() or 1), ref_seqs=seqs)
+    assert info["n_records"] > 1.9 * fx["n_records"]
+    one = str(tmp_path / "one")
+    argv = ["--sv", "--bam", bam, "--ref", fa, "--skip_assembly", "-s", str(P["n_reads_stats"])]
+    cli.main(argv + ["-o", one])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    two = str(tmp_path / "two")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sv_rank, args=(r, 2, port, q, argv + ["-o", two], 40)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(120)
+    assert all(isinstance(v, list) for v in res.values()), res
+    for rel in ["_tiddit/discordants_WGS.tab", "_tiddit/splits_WGS.tab", "_tiddit/clips_WGS.fa", ".ploidies.tab", ".candidates.tab"] + \
+               ["_tiddit/clips/%s.fa" % n for n, ln in contigs if ln >= P["min_contig"]]:
+        assert open(two + rel, "rb").read() == open(one + rel, "rb").read(), rel
+    from tiddit_amd import tiddit_stats
+    lib = tiddit_stats.statistics(bam, fa, P["min_q"], 100000, P["n_reads_stats"])
+    cov, disc, split, clips, each, n = signal_oracle.signal_main_file(bam, P["min_q"], lib["percentile_insert_size"], "WGS", P["min_contig"],
+                                                                      P["min_anchor_len"], P["min_clip_len"], want_clips=False)
+    assert open(one + "_tiddit/discordants_WGS.tab").read() == disc and open(one + "_tiddit/splits_WGS.tab").read() == split
+    assert disc.count("\n") > 1.5 * fx["discordants_rows"]
+    assert sum(1 for l in open(one + ".candidates.tab")) > 50
+
+
 def test_library_statistics_on_the_device_equal_the_host_loop(run):
     """tiddit_stats.statistics with the sampling loop, the cut-off and numpy's mean / std / 99.9th percentile on the device
     (csrc/tdt_stats.hip) == the read-by-read C loop + numpy on the host, for cut-offs inside a batch, at a batch edge, of one read and

@@ -123,6 +123,24 @@ def write_candidates(path, contigs, sv_clusters):
                                                 c["startA"], c["endA"], c["startB"], c["endB"]])) + "\n")
 
 
+def variant_stage(tiddit_variant, tiddit_vcf_header, prefix, contigs, bam_header, library, sample_id, version, args, sv_clusters, min_mapq, samples,
+                  coverage_data, contig_number, max_ins_len, gc_dictionary):
+    """the tail of the reference's driver (__main__.py:193-207) with the two modules handed in: header, variants per contig sorted by
+    position, {prefix}.vcf.  -> False (nothing written) when the reference package is not there."""
+    if tiddit_variant is None or tiddit_vcf_header is None:
+        return False
+    vcf_header = tiddit_vcf_header.main(bam_header, library, sample_id, version)
+    variants = tiddit_variant.main(args.bam, sv_clusters, args, library, min_mapq, samples, coverage_data, contig_number, max_ins_len, gc_dictionary)
+    with open(prefix + ".vcf", "w") as f:
+        f.write(vcf_header + "\n")
+        for chrom in contigs:
+            if chrom not in variants:
+                continue
+            for variant in sorted(variants[chrom], key=lambda x: x[0]):
+                f.write("\t".join(variant[1]) + "\n")
+    return True
+
+
 def run_sv(args, version):
     from . import tiddit_cluster, tiddit_coverage_analysis, tiddit_gc, tiddit_signal, tiddit_stats
     from .bamio import BamReader
@@ -281,27 +299,16 @@ def run_sv(args, version):
         # Variant typing / filtering / the VCF (tiddit_variant.pyx, tiddit_vcf_header.py) are outside this build's scope.  When the
         # reference package itself is importable (it needs pysam) the candidates are handed to it, as the reference's driver does
         # (__main__.py:193-207), so that a full installation still ends with {prefix}.vcf.
-        handed = False
         try:
             import tiddit.tiddit_variant as tiddit_variant
             import tiddit.tiddit_vcf_header as tiddit_vcf_header
         except Exception:
-            tiddit_variant = None
-        if tiddit_variant is not None:
-            t = time.time()
-            vcf_header = tiddit_vcf_header.main(bam_header, library, sample_id, version)
-            variants = tiddit_variant.main(args.bam, sv_clusters, args, library, min_mapq, samples, coverage_data, contig_number, max_ins_len,
-                                           gc_dictionary)
-            with open(prefix + ".vcf", "w") as f:
-                f.write(vcf_header + "\n")
-                for chrom in contigs:
-                    if chrom not in variants:
-                        continue
-                    for variant in sorted(variants[chrom], key=lambda x: x[0]):
-                        f.write("\t".join(variant[1]) + "\n")
+            tiddit_variant = tiddit_vcf_header = None
+        t = time.time()
+        if variant_stage(tiddit_variant, tiddit_vcf_header, prefix, contigs, bam_header, library, sample_id, version, args, sv_clusters, min_mapq,
+                         samples, coverage_data, contig_number, max_ins_len, gc_dictionary):
             T["variant typing (reference package)"] = time.time() - t
-            handed = True
-        if not handed:
+        else:
             print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
     if world > 1:
         dist.barrier()                                                   # every output file exists when any rank returns
