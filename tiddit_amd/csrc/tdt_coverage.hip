@@ -305,6 +305,9 @@ __global__ void cov_pack_binned(const int32_t *__restrict__ start, const int32_t
 #define COV_WIN1 2048                                 // MODE 1 window (16 KiB: eight workgroups per CU)
 #endif
 #define COV_DQMAX 256                               // MODE 1: a register-path read ends at most this many bins after K
+#ifndef COV_SPARES1
+#define COV_SPARES1 64                              // MODE 1: spare words behind the window, one per lane (see the binned loop)
+#endif
 
 #ifndef COV_MIN_WAVES
 #define COV_MIN_WAVES 4                            // waves per SIMD the register allocation must allow (MODE 0)
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
     int *s_wsum = reinterpret_cast<int *>(smem);
     int *s_tbin = s_wsum + 4;                          // [COV_READS_PER_BLOCK / TILE] <= 16 entries
     unsigned long long *win = smem + 12;
-    unsigned long long *lutS = win + WIN + 2;
+    unsigned long long *lutS = win + WIN + (MODE == 1 ? COV_SPARES1 : 2);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -586,7 +589,9 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
                 const unsigned notsafe = safe ? 0u : 8u;
                 const unsigned tA = (unsigned)(size_t)(lutS + 2 * (z + 1)), zb2 = (z + 1u) << 1;            // tabA, then tabB = tabA + (z+1) entries
                 const unsigned tL = tA + ((z + 1u) << 4), tL0 = tL + ((z + 1u) << 3);                        // tabL and its zero entry
-                const unsigned wK = (unsigned)(size_t)(win + kw), wSpare = (unsigned)(size_t)(win + WIN);
+                // a masked read adds a zero to a spare word behind the window — one word PER LANE: with a single word the masked lanes of
+                // an instruction (filtered reads, ~5 %) all hit one address and the ds_add_u64 serialises over them
+                const unsigned wK = (unsigned)(size_t)(win + kw), wSpare = (unsigned)(size_t)(win + WIN + (COV_SPARES1 >= 64 ? lane : 0));
                 unsigned d12 = 0, d2 = 0;                        // reads that put their +1 on bin K+1 or K+2 / on K+2
                 unsigned long long vL[RPL];
                 unsigned woff[RPL];
@@ -609,11 +614,42 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
                     vL[j] = cov_lds_read64(cov_select(m_multi, (((hi >> 8) & 0xffu) << 3) + tL, tL0));     // the last bin's quotient with the -1 of the pair
                     woff[j] = cov_select(m_multi, (((d >> 2) + ((hi >> 16) & 0xffu)) << 3) + wK, wSpare);
                 }
+#ifndef COV_M1X_NOLAST   // COV_M1X_*: measurement variants (tools/build_variant.sh) — what each group of LDS operations costs
 #pragma unroll
                 for (int j = 0; j < RPL; j++) cov_lds_add64(woff[j], vL[j]);
+#else
+                if (vL[0] + vL[1] + vL[2] + vL[3] + woff[0] + woff[1] + woff[2] + woff[3] == 0x1234567ull) win[0] = 1;
+#endif
+#ifdef COV_M1X_NOK
+                if (a0 + a1 + d12 + d2 == 0x1234567ull) win[0] = a0;
+#elif defined(COV_M1_SCANK)
+                // equal-K neighbours (2-3 lanes share a 50-bp first bin) merged before they reach the window: inclusive wave scan of the
+                // two sums, the run's tail adds P[tail], its head takes P[head - 1] back (exact in modular arithmetic, like MODE 0)
+                {
+                    unsigned long long s0 = a0, s1 = a1 + ((unsigned long long)(d12 - d2) << COV_DBIT);
+                    if (d2) atomicAdd(&win[kw + 2], (unsigned long long)d2 << COV_DBIT);
+                    wave_scan2_u64(s0, s1);
+                    const int Kprev = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHR1, 0xf, 0xf, false);
+                    const int Knext = (int)__builtin_amdgcn_update_dpp((unsigned)~K, (unsigned)K, DPP_WAVE_SHL1, 0xf, 0xf, false);
+                    const unsigned long long q0 = dpp_u64<DPP_WAVE_SHR1>(s0), q1 = dpp_u64<DPP_WAVE_SHR1>(s1);
+                    if (safe && Knext != K) {
+                        atomicAdd(&win[kw], s0);
+                        atomicAdd(&win[kw + 1], s1);
+                    }
+                    if (safe && Kprev != K && lane != 0) {
+                        atomicAdd(&win[kw], 0ull - q0);
+                        atomicAdd(&win[kw + 1], 0ull - q1);
+                    }
+                }
+#else
                 atomicAdd(&win[kw], a0);
                 atomicAdd(&win[kw + 1], a1 + ((unsigned long long)(d12 - d2) << COV_DBIT));
+#ifdef COV_M1_SKIPZERO
+                if (d2) atomicAdd(&win[kw + 2], (unsigned long long)d2 << COV_DBIT);
+#else
                 atomicAdd(&win[kw + 2], (unsigned long long)d2 << COV_DBIT);
+#endif
+#endif
                 if (slow_any) {
                     const unsigned long long idx = t0 + (unsigned long long)tid * RPL;
 #pragma unroll
@@ -1149,7 +1185,7 @@ static int cov_launch_items(tdt_cov *c, const CovItem &single, const CovItem *d_
     P.m15 = c->m15;
     P.k15 = c->k15;
     const bool lds_lut = c->bin_size + 1 <= COV_LUT_LDS_MAX;
-    const size_t lds = 96 + ((size_t)(small ? COV_WIN1 : COV_WIN) + 2) * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0) +
+    const size_t lds = 96 + ((size_t)(small ? COV_WIN1 + COV_SPARES1 : COV_WIN + 2)) * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0) +
                        (small ? (3 * ((size_t)c->bin_size + 1) + 1) * 8 : 0) + ((!small && lds_lut && c->shift >= 0) ? 4 * ((size_t)c->bin_size + 1) * 8 : 0);
     // small bins: few reads share a bin, a read covers several -> difference-pair kernel
     const bool packed = single.packed != nullptr;

@@ -544,18 +544,18 @@ const char *tdt_bz_err_name(unsigned e) {
 
 // Device-resident form: d_comp holds `comp_len` bytes of whole BGZF blocks followed by >= 1024 readable bytes of padding,
 // d_blocks the block table; inflates into d_out and verifies CRC32.  Leaves the per-block status in scratch.
-void tdt_bz_launch_lanes(hipStream_t st, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,
-                         unsigned *d_status);   // tdt_inflate2.hip
+void tdt_bz_launch_lanes(hipStream_t st, int num_cu, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,
+                         unsigned *d_status, unsigned *d_next_block);   // tdt_inflate2.hip
 
 int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out, bool check_crc,
                      unsigned *d_status, unsigned *d_summary) {
     hipStream_t st = ctx->stream;
     TDT_HIP(hipMemsetAsync(d_summary, 0xff, 4, st));
-    TDT_HIP(hipMemsetAsync(d_summary + 1, 0, 4, st));
+    TDT_HIP(hipMemsetAsync(d_summary + 1, 0, 8, st));            // (+ the lanes kernel's block counter, d_summary[2])
     const unsigned grid = (unsigned)((nblocks + BZ_WAVES - 1) / BZ_WAVES);
     const bool sequential = getenv("TIDDIT_INFLATE_SEQ") != nullptr;   // the one-symbol-at-a-time kernel of this file
     if (sequential) hipLaunchKernelGGL(bgzf_inflate, dim3(grid), dim3(64 * BZ_WAVES), 0, st, d_comp, d_blocks, (int)nblocks, d_out, d_status);
-    else tdt_bz_launch_lanes(st, d_comp, d_blocks, nblocks, d_out, d_status);
+    else tdt_bz_launch_lanes(st, ctx->num_cu, d_comp, d_blocks, nblocks, d_out, d_status, d_summary + 2);
     TDT_CHECK_LAUNCH();
     if (check_crc) {
         hipLaunchKernelGGL(bgzf_crc32, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, st, d_blocks, (int)nblocks, d_out, d_status);

@@ -16,6 +16,8 @@
 //   * every loop is bounded by ISIZE / the compressed length; damage sets the block's status.
 #include "tdt_common.h"
 
+#include <algorithm>
+
 // LUT widths and the occupancy target: 9/8 bits keep a wave's LDS at 4.7 KB and, with registers held to 64, eight waves per
 // SIMD — measured 40 ms per 1.94 GB against 51 ms for 10/9 bits at five waves (latency hiding beats the rarer long-code path)
 #ifndef B2_TB_LL
@@ -27,8 +29,11 @@
 #ifndef B2_OCC
 #define B2_OCC 8
 #endif
+#ifndef B2_WAVES
 #define B2_WAVES 4
-// LDS bytes per wave: lens 320 | lut_ll 4 << TB_LL | lut_d 4 << TB_D | sorted_ll 576 | sorted_d 64 | meta_ll 96 | meta_d 96 | ring 512
+#endif
+// LDS bytes per wave: lens 320 | lut_ll 4 << TB_LL | lut_d 4 << TB_D | sorted_ll 576 | sorted_d 64 | meta_ll 96 | meta_d 96 | ring 512 + 16
+// (the ring's first two dwords are mirrored behind it: a lane's three consecutive dwords never wrap, one address serves all three reads)
 #define B2_OFF_LUTLL 320
 #define B2_OFF_LUTD (B2_OFF_LUTLL + (4 << B2_TB_LL))
 #define B2_OFF_SORTLL (B2_OFF_LUTD + (4 << B2_TB_D))
@@ -36,12 +41,17 @@
 #define B2_OFF_METALL (B2_OFF_SORTD + 64)
 #define B2_OFF_METAD (B2_OFF_METALL + 96)
 #define B2_OFF_WIN (B2_OFF_METAD + 96)
-#define B2_LDS (B2_OFF_WIN + 512)
-// LUT entry: bits 0-3 code length, 4-7 number of extra bits, 8-23 base value (literal byte / base length / base distance /
-// raw symbol), 28-31 kind: 0 literal (or plain symbol), 1 length, 2 end of block; 0xffffffff = longer code or unused.
-#define B2_ESC 0xffffffffu
-#define B2_KIND_LEN (1u << 28)
-#define B2_KIND_EOB (2u << 28)
+#define B2_LDS (B2_OFF_WIN + 512 + 16)
+// LUT entry (32 bits): 0-3 code length l, 4-7 number of extra bits eb, 8-22 base value (literal byte / base length <= 258 / base
+// distance <= 24577 / raw symbol), 20 = length code, 21 = end of block (literal/length table only: its bases need 9 bits), and
+// 23-31 STEP: how far the bit cursor moves past this code and its extra bits — l for a literal, l + eb for a length or a distance,
+// 256 + l for the end of block, 128 for "longer than the LUT / unused" (B2_ESC).  A lane's next[] is then lane + step (+ the distance
+// entry's step behind a length code): no compare, no select; values in [128, 256) stop the chain at a code the tables cannot
+// resolve, values >= 256 at the end of the block.
+#define B2_ESC 0x40000000u
+#define B2_F_LEN (1u << 20)
+#define B2_F_EOB (1u << 21)
+#define B2_STEP(e) ((e) >> 23)
 enum { B2_MODE_RAW = 0, B2_MODE_LL = 1, B2_MODE_DIST = 2 };
 enum { B2_OK = 0, B2_E_BTYPE = 1, B2_E_STORED = 2, B2_E_TABLE = 3, B2_E_SYMBOL = 4, B2_E_DIST = 5, B2_E_OVERRUN = 6, B2_E_INPUT = 7, B2_E_SIZE = 8 };
 
@@ -56,13 +66,37 @@ struct __attribute__((packed, aligned(1))) B2U128 {
 __device__ __forceinline__ unsigned b2_rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned b2_rl(unsigned v, unsigned lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, (int)lane); }
 
+#ifdef B2_STATS   // measurement builds only (tools/inflate_stats2.py): what the windows of the lanes kernel are made of
+__device__ unsigned long long b2_stats[16];   // 0 windows, 1 symbols, 2 literals, 3 matches copied by their own lane, 4 replayed: longer than 16, 5 replayed: source
+                                              // inside the window's own output, 6 stops at a long code, 7 match bytes, 8 replayed match bytes
+extern "C" int tdt_debug_b2_stats(unsigned long long *out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(b2_stats), z, sizeof z) == hipSuccess ? 0 : -2;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2_stats), 16 * 8) == hipSuccess ? 0 : -2;
+}
+#endif
+
+// lane's bit of a 64-bit scalar mask selects between two values: ONE v_cndmask with the mask as its SGPR-pair operand
+__device__ __forceinline__ unsigned b2_sel(u64 m, unsigned if_set, unsigned if_clear) {
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+
+// one lane of a vector register <- a scalar value (v_writelane_b32; value and lane index are wave-uniform)
+__device__ __forceinline__ void b2_wl(unsigned &reg, unsigned value, unsigned lane_index) {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(value), "s"(lane_index) : "m0");   // (one SGPR per VOP3 on gfx9: the lane goes through M0)
+}
+
 __constant__ unsigned char b2_clorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __device__ __forceinline__ unsigned b2_entry(int mode, unsigned sym, unsigned l) {
     if (mode == B2_MODE_RAW) return (sym << 8) | l;
     if (mode == B2_MODE_LL) {
-        if (sym < 256) return (sym << 8) | l;
-        if (sym == 256) return B2_KIND_EOB | l;
+        if (sym < 256) return (l << 23) | (sym << 8) | l;
+        if (sym == 256) return ((256u + l) << 23) | B2_F_EOB | l;
         const unsigned lc = sym - 257;
         if (lc > 28) return B2_ESC;
         unsigned eb = 0, base = 3 + lc;
@@ -71,7 +105,7 @@ __device__ __forceinline__ unsigned b2_entry(int mode, unsigned sym, unsigned l)
             eb = (lc - 4) >> 2;
             base = 3 + ((4 + (lc & 3)) << eb);
         }
-        return B2_KIND_LEN | (base << 8) | (eb << 4) | l;
+        return ((l + eb) << 23) | B2_F_LEN | (base << 8) | (eb << 4) | l;
     }
     if (sym > 29) return B2_ESC;
     unsigned eb = 0, base = 1 + sym;
@@ -79,7 +113,7 @@ __device__ __forceinline__ unsigned b2_entry(int mode, unsigned sym, unsigned l)
         eb = (sym >> 1) - 1;
         base = 1 + ((2 + (sym & 1)) << eb);
     }
-    return (base << 8) | (eb << 4) | l;
+    return ((l + eb) << 23) | (base << 8) | (eb << 4) | l;
 }
 
 // Canonical Huffman tables from `n` code lengths in LDS (lane k carries the state of code length k).
@@ -178,20 +212,32 @@ __device__ __forceinline__ unsigned b2_scan(unsigned v) {
 
 // 64 stream bits starting `q` bits into the stream, gathered from the LDS ring (any lane, any q inside the staged windows)
 __device__ __forceinline__ u64 b2_bits_at(const unsigned *win, unsigned q) {
-    const unsigned d = q >> 5, s = q & 31;
-    const unsigned a = win[d & 127], b = win[(d + 1) & 127], c = win[(d + 2) & 127];
+    const unsigned d = (q >> 5) & 127, s = q & 31;
+    const unsigned a = win[d], b = win[d + 1], c = win[d + 2];                 // (the mirror behind the ring: no wrap)
     const unsigned lo = __builtin_amdgcn_alignbit(b, a, s), hi = __builtin_amdgcn_alignbit(c, b, s);
     return ((u64)hi << 32) | lo;
 }
 
 __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B2_OCC, 8))) void bgzf_inflate_lanes(const unsigned char *__restrict__ comp, const BzDesc *__restrict__ blocks,
                                                                     int nblocks, unsigned char *__restrict__ out,
-                                                                    unsigned *__restrict__ status) {
+                                                                    unsigned *__restrict__ status, unsigned *__restrict__ next_block) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[B2_WAVES][B2_LDS];
     const int lane = threadIdx.x & 63;
     const int wv = (int)b2_rfl(threadIdx.x >> 6);
+    // Persistent waves: the grid is what the chip holds at once (8 waves per SIMD) and every wave takes BGZF blocks off one counter
+    // until none is left.  With one launch slot per block, a span of 20 k blocks ran as 2.5 "rounds" of 8192 resident waves, the last
+    // one 60 % empty, and a workgroup's four slots stayed taken until its slowest block was done.
+#ifdef B2_NOPERSIST   // measurement variant: one launch slot per block, as before round 4
+    for (int once = 0; once < 1; once++) {
     const int b = blockIdx.x * B2_WAVES + wv;
     if (b >= nblocks) return;
+#else
+    for (;;) {
+    unsigned b_ = 0;
+    if (lane == 0) b_ = atomicAdd(next_block, 1u);
+    const int b = (int)b2_rfl(b_);
+    if (b >= nblocks) return;
+#endif
     unsigned char *lds = lds_all[wv];
     unsigned char *lens = lds;
     unsigned *lut_ll = (unsigned *)(lds + B2_OFF_LUTLL), *lut_d = (unsigned *)(lds + B2_OFF_LUTD);
@@ -210,8 +256,15 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
     unsigned err = B2_OK;
     unsigned op = 0;
 
-    win[lane] = base[lane];
-    win[64 + lane] = base[64 + lane];
+// ring half h (0 / 1) <- the 64 dwords of window w_; the ring's first two dwords are mirrored behind its end
+#define B2_STAGE(h_, w_)                                                                   \
+    do {                                                                                   \
+        const unsigned v_ = base[(size_t)(w_) * 64 + lane];                                \
+        win[(h_) * 64 + lane] = v_;                                                        \
+        if ((h_) == 0 && lane < 2) win[128 + lane] = v_;                                   \
+    } while (0)
+    B2_STAGE(0u, 0u);
+    B2_STAGE(1u, 1u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -223,8 +276,8 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             if (bp > end_bit + 64) err = B2_E_INPUT;                                      \
             else {                                                                        \
                 __builtin_amdgcn_wave_barrier();                                          \
-                if (w_ != cw + 1) win[(w_ & 1) * 64 + lane] = base[(size_t)w_ * 64 + lane]; \
-                win[((w_ + 1) & 1) * 64 + lane] = base[(size_t)(w_ + 1) * 64 + lane];     \
+                if (w_ != cw + 1) B2_STAGE(w_ & 1u, w_);                                  \
+                B2_STAGE((w_ + 1u) & 1u, w_ + 1u);                                        \
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                    \
                 __builtin_amdgcn_wave_barrier();                                          \
             }                                                                             \
@@ -380,52 +433,94 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             // every lane: the symbol that would start at bit bp + lane
             // (three dwords from the ring; every field but the distance's extra bits lies in the first 32 stream bits:
             //  9-bit code + 5 extra + 8-bit code = 22, so 64-bit shifts are not needed)
-            const unsigned q = bp + (unsigned)lane, qd = q >> 5, qs = q & 31;
-            const unsigned wa = win[qd & 127], wb = win[(qd + 1) & 127], wc = win[(qd + 2) & 127];
+            const unsigned q = bp + (unsigned)lane, qd = (q >> 5) & 127, qs = q & 31;
+            const unsigned wa = win[qd], wb = win[qd + 1], wc = win[qd + 2];      // one address, three reads (the ring's mirror: no wrap)
             const unsigned lo = __builtin_amdgcn_alignbit(wb, wa, qs), hi = __builtin_amdgcn_alignbit(wc, wb, qs);
             const unsigned e1 = lut_ll[lo & ((1u << B2_TB_LL) - 1)];
-            const unsigned l1 = e1 & 15, eb1 = (e1 >> 4) & 15, base1 = (e1 >> 8) & 0xffff, kind = e1 >> 28;
-            const bool is_len = kind == 1, is_lit = kind == 0;
-            const unsigned c1 = l1 + eb1;                           // <= 9 + 5 on the LUT path (an escape entry is never used)
-            const unsigned mlen = base1 + ((lo >> l1) & ((1u << eb1) - 1));
-            const unsigned e2 = lut_d[(lo >> (c1 & 31)) & ((1u << B2_TB_D) - 1)];
-            const unsigned l2 = e2 & 15, eb2 = (e2 >> 4) & 15, base2 = (e2 >> 8) & 0xffff;
-            const unsigned c2 = (c1 + l2) & 31;                     // <= 22: the extra bits start here and may reach into `hi`
-            const unsigned dist = base2 + (__builtin_amdgcn_alignbit(hi, lo, c2) & ((1u << eb2) - 1));
-            // next[i], with the two ways a chain ends folded in so the walk needs no second lookup:
-            // 128 + i = the code at bit i is longer than the LUT, 192 + (bit after it) = end of block
-            const bool slow = e1 == B2_ESC || (is_len && e2 == B2_ESC);
-            unsigned nxt = (unsigned)lane + (is_len ? c1 + l2 + eb2 : l1);
-            nxt = kind == 2 ? 192u + nxt : nxt;
-            nxt = slow ? 128u + (unsigned)lane : nxt;
-            // the true chain of symbol starts (scalar: one readlane per symbol)
+            const unsigned step1 = B2_STEP(e1);                     // literal: l1; length: l1 + eb1 (<= 9 + 5); 256 + l1 at the end of block; 128 = escape
+            const unsigned e2 = lut_d[__builtin_amdgcn_ubfe(lo, step1, B2_TB_D)];   // (offset = step1 & 31: only a length code's lane uses e2)
+            const bool is_len = e1 & B2_F_LEN;
+            // next[i] = i + bits consumed; a chain ends at a value >= 64: [128, 256) = a code the tables do not resolve (the literal /
+            // length code itself or the distance code behind it), >= 256 = end of block (256 + the bit after it)
+            const unsigned nxt = (unsigned)lane + step1 + (is_len ? B2_STEP(e2) : 0u);
+            // what a symbol starting at this lane's bit would write — 1 byte (literal), its length (match), nothing (end of block) — and,
+            // for a match, from how far back
+            const unsigned l1 = e1 & 15, eb1 = (e1 >> 4) & 15;
+            unsigned litv = (e1 >> 8) & 0x1ff;                      // literal byte / base length
+            unsigned mlen = litv + __builtin_amdgcn_ubfe(lo >> l1, 0u, eb1);
+            unsigned olraw = is_len ? mlen : ((e1 & B2_F_EOB) ? 0u : 1u);
+            const unsigned l2 = e2 & 15, eb2 = (e2 >> 4) & 15, base2 = (e2 >> 8) & 0x7fff;
+            unsigned dist = base2 + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, (step1 + l2) & 31), 0u, eb2);
+            // The true chain of symbol starts (scalar: one readlane per symbol).  A code longer than the LUTs (one symbol in ten on
+            // BAM-shaped data) does not end the window: it is resolved right here by the scalar canonical walk, its lane is patched with
+            // what the symbol writes, and the chain goes on behind it — the symbol's bytes leave with the window's other output instead of
+            // costing an iteration and a memory round trip of their own.
             unsigned cur = 0;
             u64 chain = 0;
-            while (cur < 64) {
-                chain |= 1ull << cur;
-                cur = b2_rl(nxt, cur);
+            unsigned stop = 0;                                      // 2 = end of block
+            for (;;) {
+                while (cur < 64) {
+                    chain |= 1ull << cur;
+                    cur = b2_rl(nxt, cur);
+                }
+                if (cur >= 256) {
+                    stop = 2;
+                    cur -= 256;
+                    break;
+                }
+                if (cur < 128) break;
+                const unsigned at = 63u - (unsigned)__builtin_clzll(chain);      // the chain's last member is the symbol the LUTs did not resolve
+                const unsigned qq = bp + at, d = (qq >> 5) & 127, sh = qq & 31;
+                const unsigned w0 = b2_rfl(win[d]), w1 = b2_rfl(win[d + 1]), w2 = b2_rfl(win[d + 2]);
+                u64 v = ((u64)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+                unsigned e = b2_rfl(lut_ll[(unsigned)v & ((1u << B2_TB_LL) - 1)]);
+                if (e == B2_ESC) e = b2_rfl(b2_long_code((unsigned)v, B2_TB_LL, B2_MODE_LL, sorted_ll, meta_ll));   // (a call's result counts as per-lane)
+                if (e == B2_ESC) {
+                    err = B2_E_SYMBOL;
+                    break;
+                }
+                unsigned used = e & 15;
+                v >>= used;
+                unsigned s_ol = 1, s_len = 0, s_dist = 0;
+                if (e & B2_F_EOB) {
+                    s_ol = 0;
+                    stop = 2;
+                } else if (e & B2_F_LEN) {
+                    unsigned eb = (e >> 4) & 15;
+                    s_len = ((e >> 8) & 0x1ff) + ((unsigned)v & ((1u << eb) - 1));
+                    v >>= eb;
+                    used += eb;
+                    unsigned ed = b2_rfl(lut_d[(unsigned)v & ((1u << B2_TB_D) - 1)]);
+                    if (ed == B2_ESC) ed = b2_rfl(b2_long_code((unsigned)v, B2_TB_D, B2_MODE_DIST, sorted_d, meta_d));
+                    if (ed == B2_ESC) {
+                        err = B2_E_DIST;
+                        break;
+                    }
+                    v >>= ed & 15;
+                    eb = (ed >> 4) & 15;
+                    s_dist = ((ed >> 8) & 0x7fff) + ((unsigned)v & ((1u << eb) - 1));
+                    used += (ed & 15) + eb;
+                    s_ol = s_len;
+                }
+                b2_wl(olraw, s_ol, at);
+                b2_wl(mlen, s_len, at);
+                b2_wl(dist, s_dist, at);
+                b2_wl(litv, (e >> 8) & 0xff, at);
+                cur = at + used;                                    // (<= 63 + 48: the ring holds bp .. bp + 160 bits)
+                if (stop == 2) break;
             }
-            unsigned stop = 0;                                      // 1 = a long code sits at bit cur, 2 = end of block
-            if (cur >= 192) {
-                stop = 2;
-                cur -= 192;
-            } else if (cur >= 128) {
-                stop = 1;
-                cur -= 128;
-                chain &= ~(1ull << cur);
-            }
-            const bool on = (chain >> lane) & 1;
-            const unsigned ol = on ? (is_lit ? 1u : is_len ? mlen : 0u) : 0u;
+            if (err != B2_OK) break;
+            const unsigned ol = b2_sel(chain, olraw, 0u);           // off the chain: nothing
             const unsigned incl = b2_scan(ol);
             const unsigned tot = b2_rl(incl, 63);
             const unsigned pos = op + incl - ol;
-            const bool copy = on && is_len;
+            const bool copy = ol >= 3;                              // (a match is at least 3 bytes long, a literal exactly 1)
             if (op + tot > isize || __ballot(copy && dist > pos)) {
                 err = op + tot > isize ? B2_E_OVERRUN : B2_E_DIST;
                 break;
             }
 #ifndef B2_EXP_NOLIT   // B2_EXP_*: ablation switches (tools/build_variant.sh) behind the stage costs quoted in DESIGN.md 3.6
-            if (on && is_lit) dst[pos] = (unsigned char)base1;
+            if (ol == 1) dst[pos] = (unsigned char)litv;
 #endif
             const unsigned srco = pos - dist;                       // first source byte of this lane's match
             // Matches whose source lies wholly before this window's output cannot depend on anything decoded in it: each of
@@ -449,6 +544,27 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 if (t >= 1) p_[b4] = (unsigned char)wt;
                 if (t >= 2) p_[b4 + 1] = (unsigned char)(wt >> 8);
                 if (t == 3) p_[b4 + 2] = (unsigned char)(wt >> 16);
+            }
+#endif
+#ifdef B2_STATS
+            {
+                const u64 m_lit = __ballot(ol == 1), m_par = __ballot(par), m_long = __ballot(copy && !par && srco + mlen <= op), m_dep = __ballot(copy && !par && srco + mlen > op);
+                unsigned mb = copy ? mlen : 0u, rb = (copy && !par) ? mlen : 0u;
+                for (int d_ = 32; d_ > 0; d_ >>= 1) {
+                    mb += __shfl_xor(mb, d_);
+                    rb += __shfl_xor(rb, d_);
+                }
+                if (lane == 0) {
+                    atomicAdd(&b2_stats[0], 1ull);
+                    atomicAdd(&b2_stats[1], (unsigned long long)__popcll(chain));
+                    atomicAdd(&b2_stats[2], (unsigned long long)__popcll(m_lit));
+                    atomicAdd(&b2_stats[3], (unsigned long long)__popcll(m_par));
+                    atomicAdd(&b2_stats[4], (unsigned long long)__popcll(m_long));
+                    atomicAdd(&b2_stats[5], (unsigned long long)__popcll(m_dep));
+                    atomicAdd(&b2_stats[6], 0ull);
+                    atomicAdd(&b2_stats[7], (unsigned long long)mb);
+                    atomicAdd(&b2_stats[8], (unsigned long long)rb);
+                }
             }
 #endif
 #ifdef B2_EXP_NOSEQ
@@ -476,66 +592,24 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             }
             B2_ENSURE();
             if (err != B2_OK || stop == 2) break;
-            if (stop == 1) {  // one symbol whose code is longer than the LUT: scalar canonical walk
-                const unsigned d = bp >> 5, s = bp & 31;
-                const unsigned w0 = b2_rfl(win[d & 127]), w1 = b2_rfl(win[(d + 1) & 127]), w2 = b2_rfl(win[(d + 2) & 127]);
-                u64 v = ((u64)__builtin_amdgcn_alignbit(w2, w1, s) << 32) | __builtin_amdgcn_alignbit(w1, w0, s);
-                unsigned e = b2_rfl(lut_ll[(unsigned)v & ((1u << B2_TB_LL) - 1)]);
-                if (e == B2_ESC) e = b2_long_code((unsigned)v, B2_TB_LL, B2_MODE_LL, sorted_ll, meta_ll);
-                if (e == B2_ESC) {
-                    err = B2_E_SYMBOL;
-                    break;
-                }
-                unsigned used = e & 15;
-                v >>= used;
-                if (e < B2_KIND_LEN) {
-                    if (op >= isize) {
-                        err = B2_E_OVERRUN;
-                        break;
-                    }
-                    dst[op] = (unsigned char)(e >> 8);
-                    op++;
-                } else if (e >= B2_KIND_EOB) {
-                    bp += used;
-                    B2_ENSURE();
-                    break;
-                } else {
-                    unsigned eb = (e >> 4) & 15;
-                    const unsigned len = ((e >> 8) & 0xffff) + ((unsigned)v & ((1u << eb) - 1));
-                    v >>= eb;
-                    used += eb;
-                    unsigned ed = b2_rfl(lut_d[(unsigned)v & ((1u << B2_TB_D) - 1)]);
-                    if (ed == B2_ESC) ed = b2_long_code((unsigned)v, B2_TB_D, B2_MODE_DIST, sorted_d, meta_d);
-                    if (ed == B2_ESC) {
-                        err = B2_E_DIST;
-                        break;
-                    }
-                    v >>= ed & 15;
-                    eb = (ed >> 4) & 15;
-                    const unsigned dd = ((ed >> 8) & 0xffff) + ((unsigned)v & ((1u << eb) - 1));
-                    used += (ed & 15) + eb;
-                    if (dd > op || op + len > isize) {
-                        err = dd > op ? B2_E_DIST : B2_E_OVERRUN;
-                        break;
-                    }
-                    const unsigned char *src = dst + op - dd;
-                    for (unsigned i = lane; i < len; i += 64) dst[op + i] = src[dd >= len ? i : i % dd];
-                    op += len;
-                }
-                bp += used;
-                B2_ENSURE();
-                if (err != B2_OK) break;
-            }
         }
     }
     if (err == B2_OK && op != isize) err = B2_E_SIZE;
     if (err == B2_OK && bp > end_bit + 7) err = B2_E_INPUT;
     if (lane == 0) status[b] = err;
+    __builtin_amdgcn_wave_barrier();                          // (the next block's staging writes the ring this one may still be reading)
+    }
 #undef B2_ENSURE
+#undef B2_STAGE
 }
 
-void tdt_bz_launch_lanes(hipStream_t st, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,
-                         unsigned *d_status) {
-    const unsigned grid = (unsigned)((nblocks + B2_WAVES - 1) / B2_WAVES);
-    hipLaunchKernelGGL(bgzf_inflate_lanes, dim3(grid), dim3(64 * B2_WAVES), 0, st, d_comp, d_blocks, (int)nblocks, d_out, d_status);
+void tdt_bz_launch_lanes(hipStream_t st, int num_cu, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,
+                         unsigned *d_status, unsigned *d_next_block) {
+#ifdef B2_NOPERSIST
+    const size_t resident = ~(size_t)0;
+#else
+    const size_t resident = (size_t)num_cu * (4 * B2_OCC / B2_WAVES);                  // workgroups the chip holds at 8 waves per SIMD
+#endif
+    const unsigned grid = (unsigned)std::min(resident, (nblocks + B2_WAVES - 1) / B2_WAVES);
+    hipLaunchKernelGGL(bgzf_inflate_lanes, dim3(grid), dim3(64 * B2_WAVES), 0, st, d_comp, d_blocks, (int)nblocks, d_out, d_status, d_next_block);
 }
