@@ -45,6 +45,17 @@ __device__ __forceinline__ unsigned db_absdiff(unsigned a, unsigned b) { return 
 #include "tdt_dbscan_fused.h"
 #include "tdt_dbscan_tile.h"
 
+// workgroups of a dbt_tile launch: what the chip holds at once (eight 256-thread workgroups per CU), or one per tile if that is fewer
+static inline int dbt_grid(const tdt_ctx *ctx, int ntiles) {
+#ifndef DT_PERSIST
+    (void)ctx;
+    return ntiles;
+#else
+    const int resident = ctx->num_cu * 8;
+    return ntiles < resident ? ntiles : resident;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------- scan
 // In-place inclusive scan of a u32 array: reduce tiles -> scan the tile sums (one block) -> apply.
 __global__ __launch_bounds__(DB_THREADS) void scan_reduce(const unsigned *__restrict__ v, int n, unsigned *__restrict__ tsum) {
@@ -529,10 +540,11 @@ extern "C" int tdt_dbscan_device(tdt_ctx *ctx, const uint32_t *d_x, const uint32
         unsigned seq = ++tile_seq;
         if (seq == 0) seq = ++tile_seq;                                    // never 0
         hw[1] = 0;
-        if (nb == 1 && mode == 0) hipLaunchKernelGGL((dbt_tile<true, false>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
-        else if (nb == 1) hipLaunchKernelGGL((dbt_tile<true, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
-        else if (mode == 0) hipLaunchKernelGGL((dbt_tile<false, false>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
-        else hipLaunchKernelGGL((dbt_tile<false, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
+        const int tgrid = dbt_grid(ctx, ntt);
+        if (nb == 1 && mode == 0) hipLaunchKernelGGL((dbt_tile<true, false>), dim3(tgrid), dim3(DT_THREADS), 0, st, TP);
+        else if (nb == 1) hipLaunchKernelGGL((dbt_tile<true, true>), dim3(tgrid), dim3(DT_THREADS), 0, st, TP);
+        else if (mode == 0) hipLaunchKernelGGL((dbt_tile<false, false>), dim3(tgrid), dim3(DT_THREADS), 0, st, TP);
+        else hipLaunchKernelGGL((dbt_tile<false, true>), dim3(tgrid), dim3(DT_THREADS), 0, st, TP);
         TDT_CHECK_LAUNCH();
         if (nb == 1) {
             ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
@@ -817,7 +829,7 @@ extern "C" int tdt_dbscan_y_device(tdt_ctx *ctx, const int32_t *d_xlab, const ui
     static std::atomic<unsigned> y_seq{0x40000000u};
     const unsigned seq = ++y_seq | 0x40000000u;
     hw[1] = 0;
-    hipLaunchKernelGGL((dbt_tile<true, false, true>), dim3(ntt), dim3(DT_THREADS), 0, st, TP);
+    hipLaunchKernelGGL((dbt_tile<true, false, true>), dim3(dbt_grid(ctx, ntt)), dim3(DT_THREADS), 0, st, TP);
     ctx->tile_groups_max = std::max(ctx->tile_groups_max, (ntt + DT_GRP - 1) / DT_GRP);
     hipLaunchKernelGGL(dbt_finish1, dim3((ntt + DT_FTPB - 1) / DT_FTPB), dim3(256), 0, st, (const unsigned short *)t_code, d_labels, n, (const int *)d_xlab,
                        (const unsigned *)t_aggR, (const unsigned *)t_aggE, ntt, (const unsigned *)TP.grp, odd ? t_grp0 : t_grp1, ctx->tile_groups_max,

@@ -49,7 +49,7 @@
 // variant builds only (tools/dt_prof.sh): shader-clock cycles per phase of dbt_tile as seen by thread 0, per workgroup
 #define DT_PROF_TILES 8192
 __device__ unsigned dt_prof[DT_PROF_TILES * 16];
-#define DT_MARK(k) do { if (ONE_BUCKET && !LABELS && tid == 0 && blockIdx.x < DT_PROF_TILES) { const unsigned long long t_ = clock64(); dt_prof[blockIdx.x * 16 + k] = (unsigned)(t_ - t_last); t_last = t_; } } while (0)
+#define DT_MARK(k) do { if (ONE_BUCKET && !LABELS && tid == 0 && tile < DT_PROF_TILES) { const unsigned long long t_ = clock64(); dt_prof[tile * 16 + k] = (unsigned)(t_ - t_last); t_last = t_; } } while (0)
 #else
 #define DT_MARK(k) do { } while (0)
 #endif
@@ -74,6 +74,7 @@ __device__ __forceinline__ void dt_signal_host(unsigned *flags, volatile unsigne
     if (blockIdx.x == 0 && threadIdx.x == 0 && host) {
         host[0] = flags[0];
         flags[0] = 0;                      // ready for the next call (nothing else touches it before the next tile kernel)
+        flags[1] = 0;                      // ... and so is the tile counter of the persistent grid
         __threadfence_system();
         host[1] = seq;
     }
@@ -107,7 +108,7 @@ __device__ __forceinline__ unsigned dt_add_bit(unsigned r, ull mask) {
 // DBSCAN.y_coordinate_clustering's `clusters` argument (DBSCAN.py:66-74); sub-run 1 keeps the label, extra sub-runs are numbered
 // from the caller's cluster_id by dbt_finish1.
 template <bool ONE_BUCKET, bool XONLY, bool LABELS = false>
-__global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void dbt_tile(DtParams P) {
+__device__ __forceinline__ void dbt_tile_body(const DtParams &P, const int tile) {
     __shared__ __attribute__((aligned(16))) unsigned xs[DT_XS];        // x, later the y values in sorted order
     __shared__ __attribute__((aligned(16))) unsigned yv[DT_S + 8];      // + 8: the rank loop's masked reads past the last cluster
     // run starts lie at least two positions apart (a start needs a non-p position in front of it), so the staged range holds at
@@ -120,8 +121,13 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     ull *SY = BM;                        // the bucket-boundary stream is read by the x pass only
     __shared__ unsigned runBase[DT_NW + 1], extBase[DT_NW + 1];
     __shared__ unsigned s_owned, s_b0, s_b1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x;
+    int tid_ = threadIdx.x;
+#ifdef DT_PERSIST
+    // (inlined into the tile loop: without this opaque copy the compiler hoists everything derived from the thread index out of the
+    // loop and keeps it live across tiles — 64 VGPRs + 22 spilled to scratch against 42)
+    asm volatile("" : "+v"(tid_));
+#endif
+    const int tid = tid_, lane = tid & 63, wave = tid >> 6;
     const int n = P.n, m = P.m;
     const int t0 = tile * DT_T;          // the host takes this path only for n < 2^31 - 2^16: int arithmetic cannot overflow
     const int sh0 = t0 - 64;
@@ -510,6 +516,28 @@ __global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             }
         }
     }
+}
+
+// The launch: one workgroup per tile.  5 M points are 3552 tiles on 2048 resident slots — 1.73 "rounds", the second one 27 % empty — so a
+// PERSISTENT grid (as many workgroups as the chip holds, each taking tiles off one counter, P.flags[1]) was measured in round 4
+// (-DDT_PERSIST, tools/ab_db.sh): 93-100 us between events against 65-67 us, with or without the register spills the tile loop first
+// caused (64 VGPRs + 22 spilled; 57 and none with the opaque thread index below).  The tail round is cheaper than the loop: kept off.
+template <bool ONE_BUCKET, bool XONLY, bool LABELS = false>
+__global__ __launch_bounds__(DT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void dbt_tile(DtParams P) {
+#ifndef DT_PERSIST
+    dbt_tile_body<ONE_BUCKET, XONLY, LABELS>(P, (int)blockIdx.x);
+#else
+    __shared__ int s_tile;
+    const int ntiles = (P.n + DT_T - 1) / DT_T;
+    for (;;) {
+        __syncthreads();                     // the previous tile's last LDS reads are done
+        if (threadIdx.x == 0) s_tile = (int)atomicAdd(P.flags + 1, 1u);
+        __syncthreads();
+        const int tile = s_tile;
+        if (tile >= ntiles) return;
+        dbt_tile_body<ONE_BUCKET, XONLY, LABELS>(P, tile);
+    }
+#endif
 }
 
 // exclusive scans of the per-tile counts; bases of every bucket; last_id; the host's status word
