@@ -1045,6 +1045,8 @@ def sv_e2e(args, ctx, with_oracle, rank=0, world=1, local_rank=0, barrier=lambda
         import torch.distributed as dist
         all_stages = [None] * world
         dist.all_gather_object(all_stages, stages)
+        all_notes = [None] * world
+        dist.all_gather_object(all_notes, dict(cli.STAGE_NOTES))
     if rank != 0:
         return None
     res = {"metric": "tiddit --sv --skip_assembly end to end (BAM file -> candidates table), wall seconds", "wall_s": walls[-1],
@@ -1064,6 +1066,7 @@ def sv_e2e(args, ctx, with_oracle, rank=0, world=1, local_rank=0, barrier=lambda
             keys += [k for k in st if k not in keys]
         res["stage_seconds_max_over_ranks"] = {k: round(max(st.get(k, 0.0) for st in all_stages), 4) for k in keys}
         res["stage_seconds_per_rank"] = [{k: round(v, 4) for k, v in st.items()} for st in all_stages]
+        res["notes_per_rank"] = all_notes
     if with_oracle:
         res.update(sv_e2e_cpu_legs(mb, bam, fa, out, contigs, walls[-1], args.sv_cpu_full_mb))
     return res

@@ -109,6 +109,7 @@ def run_cov(args):
 
 
 STAGE_SECONDS = {}          # wall seconds of the last run_sv, stage by stage (bench.py reads it)
+STAGE_NOTES = {}            # ... and counts that are not seconds
 
 
 def write_candidates(path, contigs, sv_clusters):
@@ -208,13 +209,40 @@ def run_sv(args, version):
     max_ins_len = 100000
     T = STAGE_SECONDS
     T.clear()
+    STAGE_NOTES.clear()
     from .trace import stage
     t = time.time()
     with stage("tiddit: library statistics"):
-        if rank == 0:                                                    # the sample is a prefix of the file: one rank's job
-            library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=world == 1)   # (N ranks scan byte-range shards: nobody would take a carry)
-        if world > 1:
-            library = tdist.broadcast_object(library if rank == 0 else None, 0)
+        if world == 1:
+            library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=True)
+        else:
+            # The sample is the head of the file = the head of rank 0's byte range: rank 0 samples it through its own share's reader and
+            # keeps the batches for its scan.  Nothing in inflate / record decode / the coverage records depends on the statistics, so the
+            # other ranks do not wait idle for the broadcast: they ingest the head of THEIR shares meanwhile (bamio.preingest) and their
+            # scans start from those batches.  TIDDIT_DIST_PREINGEST=0: wait idle (what the first N-rank build did).
+            import pickle
+            import numpy
+            from . import bamio
+            wire = torch.zeros(8192, dtype=torch.uint8, device=tdist._wire_device())
+            overlap = os.environ.get("TIDDIT_DIST_PREINGEST", "1") != "0" and os.environ.get("TIDDIT_HOST_INGEST") != "1"
+            if rank == 0:
+                library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=overlap, shard=(0, world) if overlap else None)
+                blob = pickle.dumps(library, protocol=4)
+                host = numpy.zeros(8192, dtype=numpy.uint8)
+                host[:4] = numpy.array([len(blob)], dtype="<u4").view(numpy.uint8)
+                host[4:4 + len(blob)] = numpy.frombuffer(blob, dtype=numpy.uint8)
+                wire.copy_(torch.from_numpy(host))
+                dist.broadcast(wire, 0)
+            else:
+                work = dist.broadcast(wire, 0, async_op=True)
+                held = 0
+                if overlap:
+                    held = bamio.preingest(args.bam, (rank, world), 50, stop=work.is_completed,
+                                           chunk=int(os.environ.get("TIDDIT_INGEST_CHUNK", str(448 << 20))))
+                work.wait()
+                host = wire.cpu().numpy()
+                library = pickle.loads(host[4:4 + int(host[:4].view("<u4")[0])].tobytes())
+                STAGE_NOTES["batches ingested beside rank 0's statistics"] = held
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
     T["library statistics"] = time.time() - t
 

@@ -414,6 +414,7 @@ class ScanCarry:
         import os
         self.path, self.stamp = os.path.abspath(path), os.stat(path).st_mtime_ns
         self.reader, self.iterator, self.batches, self.hist = reader, iterator, batches, hist
+        self.shard = getattr(reader, "shard", None)          # (rank, world) when the reader covers one rank's byte range of the file
 
     def drop(self):
         for b in self.batches:
@@ -438,21 +439,53 @@ def set_carry(carry):
     _CARRY = carry
 
 
-def take_carry(path, bin_size):
-    """the carry of `path` if the statistics pass of this process left one for that bin size (the caller owns it then), else None"""
+def take_carry(path, bin_size, shard=None):
+    """the carry of `path` if this process left one for that bin size and that share of the file (the caller owns it then), else None"""
     global _CARRY
     import os
     c, _CARRY = _CARRY, None
     if c is None:
         return None
     try:
-        ok = c.path == os.path.abspath(path) and c.stamp == os.stat(path).st_mtime_ns and c.hist.bin_size == int(bin_size)
+        ok = c.path == os.path.abspath(path) and c.stamp == os.stat(path).st_mtime_ns and c.hist.bin_size == int(bin_size) and \
+            (None if c.shard is None else tuple(c.shard)) == (None if shard is None else tuple(shard))
     except OSError:
         ok = False
     if not ok:
         c.drop()
         return None
     return c
+
+
+def preingest(path, shard, bin_size, stop, max_batches=12, chunk=448 << 20, ctx=None):
+    """Start on this rank's share of the file before the scan's parameters are known: the N-rank `tiddit --sv` needs the library
+    statistics (rank 0 samples them from the head of the file) before any signal predicate can run, but inflate, record decode and the
+    coverage records depend on nothing — so the other ranks ingest their first batches meanwhile and keep them in HBM (retained, like
+    the statistics pass's own).  Reads batches until ``stop()`` is true, the share is exhausted or `max_batches` are held (a batch
+    holds ~1.8 GB of device memory at the default span); leaves a :class:`ScanCarry` for :func:`take_carry`.  -> batches held."""
+    from . import tiddit_coverage
+    reader = DeviceBamReader(path, ctx=ctx, chunk=chunk, shard=shard)
+    hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(reader.references, reader.lengths)], bin_size, ctx=reader.ctx)
+    reader.bin_for(hist)
+    reader.retain = True
+    it = reader.batches()
+    kept = []
+    try:
+        while len(kept) < max_batches and not stop():
+            b = next(it, None)
+            if b is None:
+                break
+            kept.append(b)
+    except BaseException:
+        for b in kept:
+            b.release()
+        it.close()
+        reader.close()
+        hist.close()
+        raise
+    reader.retain = False
+    set_carry(ScanCarry(path, reader, it, kept, hist))
+    return len(kept)
 
 
 _SPAN_POOLS = []                 # free list of hostutil.PinnedPool objects, each holding a reader's four span buffers

@@ -259,8 +259,10 @@ def _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_le
     max_ins = int(max_ins)         # the reference's `int max_ins` argument truncates a float percentile (:147,:230; probed with Cython 3.2)
     from . import bamio
     carry = None
-    if shard is None and os.environ.get("TIDDIT_HOST_INGEST") != "1":
-        carry = bamio.take_carry(bam_file_name, bin_size)      # the statistics pass of this process left its sampled batches in HBM
+    if os.environ.get("TIDDIT_HOST_INGEST") != "1":
+        # the statistics pass of this process (or, on the other ranks of an N-rank job, the pre-ingest that ran beside it) left the head
+        # of this very share of the file in HBM; a carry for anything else is dropped there
+        carry = bamio.take_carry(bam_file_name, bin_size, shard)
     else:
         bamio.set_carry(None)                                    # (a carry nobody will consume: its batches, reader and histogram go now)
     if carry is not None:

@@ -36,13 +36,17 @@ def _device_figures(lib, h, state):
     return mean, numpy.sqrt(numpy.float64(msd.value)), numpy.float64(pct)
 
 
-def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False):
+def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False, shard=None):
     import os
     from . import bamio
     library = {}
     t = time.time()
     bamio.set_carry(None)
-    reader = open_bam(bam_file_name)
+    # shard = (0, world): rank 0 of an N-rank job samples from ITS byte range of the file, so that the batches it keeps are the head of
+    # its own scan; a sample that does not end inside that range is taken again from the whole file (below)
+    sharded = shard is not None and os.environ.get("TIDDIT_HOST_INGEST") != "1" and os.environ.get("TIDDIT_STATS_HOST") != "1"
+    reader = bamio.DeviceBamReader(bam_file_name, shard=shard, chunk=int(os.environ.get("TIDDIT_INGEST_CHUNK", str(448 << 20)))) if sharded \
+        else open_bam(bam_file_name)
     # `tiddit --sv` scans the same file for signals next (tiddit_signal.main): the sampled batches stay in HBM with their coverage records
     # written for the 50-bp histogram, and that pass starts from them instead of reading and inflating this part of the file again
     on_device = isinstance(reader, bamio.DeviceBamReader)
@@ -73,9 +77,21 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False)
                                                         len(b), ctypes.byref(done)))
                 if done.value:
                     break
+            if sharded and not done.value:
+                # the share ended before the sample did (a small file, many ranks): the reference samples on into the rest of the file
+                lib.tdt_stats_destroy(h)
+                h = None
+                for b in kept:
+                    b.release()
+                batches.close()
+                reader.close()
+                if hist is not None:
+                    hist.close()
+                return _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False, shard=None)
             figures = _device_figures(lib, h, state)
         finally:
-            lib.tdt_stats_destroy(h)
+            if h is not None:
+                lib.tdt_stats_destroy(h)
     else:
         def scan(cols, n):
             # the sampling loop of the reference (:17-47), read by read, in C (csrc/tdt_bam.hip: tdt_stats_scan); `state` carries over
@@ -136,9 +152,11 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False)
     return library
 
 
-def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False):
+def statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False, shard=None):
     """``tiddit_stats.statistics`` (tiddit_stats.py:5-78); the collector is off meanwhile (hostutil.quiet_gc).
     carry=True (the one-process `tiddit --sv` sets it: the signal scan of the same file follows at once and takes it,
-    bamio.take_carry): the sampled batches stay in HBM with an open reader for that scan.  A library caller leaves nothing behind."""
+    bamio.take_carry): the sampled batches stay in HBM with an open reader for that scan.  A library caller leaves nothing behind.
+    shard=(0, world): rank 0 of an N-rank job — the sample is read through the reader of rank 0's byte range, so the carry is the head
+    of that rank's own scan (same figures: the sample is a prefix of the file either way)."""
     with quiet_gc():
-        return _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=carry)
+        return _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=carry, shard=shard)
