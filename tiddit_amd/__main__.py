@@ -246,22 +246,29 @@ def run_sv(args, version):
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
     T["library statistics"] = time.time() - t
 
-    # The GC / N-mask bins depend on the reference FASTA alone (the reference computes them after the signals, __main__.py:166):
-    # a second host thread with its own library context (own streams and scratch) reads the FASTA and runs the GC kernel while the
-    # main thread merges and writes the signal tables — pure Python, while the GC pass waits on the page cache, PCIe and the device.
-    # It starts when the BAM scan is over (tiddit_signal.AFTER_SCAN): beside the scan itself the two compete for the link and the
-    # scan of a 54-GB file lost 0.3 s to it.  TIDDIT_GC_OVERLAP=0: in sequence, on the main thread.
+    # The GC / N-mask bins depend on the reference FASTA alone (the reference computes them after the signals, __main__.py:166): a
+    # second host thread with its own library context (own streams and scratch) reads the FASTA and runs the GC kernel BESIDE the BAM
+    # scan — the scan waits inside the library (inflate-kernel bound; its row path holds no Python since round 4), so the thread's
+    # short Python moments cost it nothing, and 3 GB more over a link that carries 54 GB in 2.2 s are noise.  (While the rows were
+    # Python objects the thread started behind the scan, tiddit_signal.AFTER_SCAN, because the two fought over the GIL: that left
+    # 0.42 s of a 3-Gb job waiting for it.)  On N ranks every rank computes the bins of ITS contigs (dist.shard_contigs) and rank 0
+    # receives them.  TIDDIT_GC_OVERLAP=0: in sequence on rank 0's main thread; =after: the thread starts when the scan is over.
     gc_job = None
-    if rank == 0 and os.environ.get("TIDDIT_GC_OVERLAP", "1") != "0":
+    gc_mode = os.environ.get("TIDDIT_GC_OVERLAP", "1")
+    if gc_mode != "0":
         import threading
         from . import _native
         gc_job = {}
+        gc_mine = list(chromosomes)
+        if world > 1:
+            owned = tdist.shard_contigs([contig_length[c] for c in chromosomes], world)[rank]
+            gc_mine = [chromosomes[i] for i in owned]
 
         def gc_thread():
             try:
                 ctx = _native.Context(_native.default_context().device)
                 fasta = FastaFile(args.ref)
-                gc_job["result"] = {c: tiddit_gc.binned_gc(fasta, c, 50, 0.5, ctx=ctx)[1] for c in chromosomes}
+                gc_job["result"] = {c: tiddit_gc.binned_gc(fasta, c, 50, 0.5, ctx=ctx)[1] for c in gc_mine}
             except BaseException as e:           # re-raised on the main thread
                 gc_job["error"] = e
             gc_job["seconds"] = time.time() - gc_job["t0"]
@@ -271,7 +278,10 @@ def run_sv(args, version):
                 gc_job["t0"] = time.time()
                 gc_job["thread"] = threading.Thread(target=gc_thread, name="tiddit-gc")
                 gc_job["thread"].start()
-        tiddit_signal.AFTER_SCAN.append(start_gc)
+        if gc_mode == "after":
+            tiddit_signal.AFTER_SCAN.append(start_gc)
+        else:
+            start_gc()
     t = time.time()
     with stage("tiddit: signal extraction + coverage"):
         signal_main = tiddit_signal.main_sharded if world > 1 else tiddit_signal.main
@@ -279,27 +289,39 @@ def run_sv(args, version):
             coverage_data = signal_main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
                                         False, args.min_anchor_len, args.min_clip_len)
         finally:
-            if gc_job is not None:
+            if gc_job is not None and gc_mode == "after":
                 tiddit_signal.AFTER_SCAN.remove(start_gc)
+            if gc_job is not None and sys.exc_info()[0] is not None and "thread" in gc_job:
+                gc_job["thread"].join()          # (the scan failed: no helper thread outlives the error)
     if rank == 0:
         print("extracted signals in:")
         print(t - time.time())
     T["signal extraction + coverage"] = time.time() - t
     T.update({"  " + k: v for k, v in tiddit_signal.STAGE_SECONDS.items()})
-    if rank == 0:
-        t = time.time()
-        with stage("tiddit: GC bins"):
-            if gc_job is None:
+    t = time.time()
+    gc_dictionary = None
+    with stage("tiddit: GC bins"):
+        if gc_job is None:
+            if rank == 0:
                 gc_dictionary = tiddit_gc.main(args.ref, chromosomes, args.threads, 50, 0.5)
-            else:
-                start_gc()                      # (already running unless the signal stage never reached the end of its scan)
-                gc_job["thread"].join()
-                if "error" in gc_job:
-                    raise gc_job["error"]
-                gc_dictionary = gc_job["result"]
-        T["GC bins"] = time.time() - t
-        if gc_job is not None:
-            T["  GC bins, on their own thread beside merge + write"] = gc_job["seconds"]
+        else:
+            start_gc()                          # (already running unless the thread waits for the end of the scan, or the scan never got there)
+            gc_job["thread"].join()
+            if "error" in gc_job:
+                raise gc_job["error"]
+            gc_dictionary = gc_job["result"]
+            if world > 1:                       # every rank's contigs to rank 0 (int8 bins: 60 MB for a human genome)
+                import pickle
+                parts = tdist.gather_bytes(pickle.dumps(gc_dictionary, protocol=4), 0)
+                if rank == 0:
+                    merged = {}
+                    for p_ in parts:
+                        merged.update(pickle.loads(p_))
+                    gc_dictionary = {c: merged[c] for c in chromosomes}
+    T["GC bins"] = time.time() - t
+    if gc_job is not None:
+        T["  GC bins, on their own thread beside the scan"] = gc_job["seconds"]
+    if rank == 0:
         t = time.time()
         with stage("tiddit: ploidy"):
             library = tiddit_coverage_analysis.determine_ploidy(coverage_data, contigs, library, args.n, prefix, args.c, args.ref, 50,

@@ -28,8 +28,17 @@ int rccl_load() {
     if (g_rccl.h) return TDT_OK;
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names)                      // an instance the process already has (e.g. PyTorch's) first
-        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    // TIDDIT_RCCL_LIB=<path>: bind exactly this library (a site's own RCCL build; the tests' shared-memory stand-in that lets N ranks
+    // share one GPU, tests/rccl_standin/) — RTLD_LOCAL, so that its nccl* symbols do not shadow an RCCL the process already carries
+    if (const char *forced = getenv("TIDDIT_RCCL_LIB")) {
+        if (!(h = dlopen(forced, RTLD_NOW | RTLD_LOCAL))) {
+            tdt_set_error("TIDDIT_RCCL_LIB=%s: %s", forced, dlerror());
+            return TDT_E_UNSUPPORTED;
+        }
+    }
+    if (!h)
+        for (const char *n : names)                  // an instance the process already has (e.g. PyTorch's) first
+            if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
     if (!h)
         for (const char *n : names)
             if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
