@@ -268,22 +268,92 @@ static double ing_now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-static int ing_grow(tdt_ingest *g, tdt_buf &b, size_t bytes, bool keep = false) {
-    if (b.cap >= bytes) return TDT_OK;
-    const size_t cap = bytes + bytes / 4 + 4096;
+// Device buffers of the ingest come from — and go back to — a process-wide cache instead of hipMalloc / hipFree: a reader's buffers are
+// hundreds of megabytes to gigabytes, `tiddit --sv` keeps seven batches of the statistics pass (tdt_ingest_retain: a fresh 1.7-GB
+// output buffer and a fresh 0.4-GB array block each) and frees them a moment later, and every pass over a file opens a reader.  GB-sized
+// hipMalloc / hipFree calls take 10-40 ms apiece when the driver has to map or unmap the range, and they came in bursts: the
+// statistics stage of a 240-Mb job measured 0.13 s or 0.5-0.7 s from one run to the next.  Bounded (TDT_ING_CACHE_MAX bytes per
+// device); a request takes the smallest cached buffer that is large enough and at most twice the size.
+namespace {
+struct IngCached {
+    void *p;
+    size_t cap;
+    int device;
+};
+std::mutex ing_cache_mu;
+std::vector<IngCached> ing_cache;
+size_t ing_cache_bytes = 0;
+const size_t TDT_ING_CACHE_MAX = (size_t)64 << 30;
+
+void *ing_dev_alloc(int device, size_t cap, size_t *got_cap) {
+    {
+        std::lock_guard<std::mutex> lock(ing_cache_mu);
+        int best = -1;
+        for (int i = 0; i < (int)ing_cache.size(); i++)
+            if (ing_cache[(size_t)i].device == device && ing_cache[(size_t)i].cap >= cap && ing_cache[(size_t)i].cap <= 2 * cap + (1u << 20) &&
+                (best < 0 || ing_cache[(size_t)i].cap < ing_cache[(size_t)best].cap))
+                best = i;
+        if (best >= 0) {
+            const IngCached c = ing_cache[(size_t)best];
+            ing_cache.erase(ing_cache.begin() + best);
+            ing_cache_bytes -= c.cap;
+            *got_cap = c.cap;
+            return c.p;
+        }
+    }
     void *p = nullptr;
     if (hipMalloc(&p, cap) != hipSuccess) {
+        (void)hipGetLastError();
+        // the cache may be what is in the way: give it back and try once more
+        std::vector<IngCached> drop;
+        {
+            std::lock_guard<std::mutex> lock(ing_cache_mu);
+            drop.swap(ing_cache);
+            ing_cache_bytes = 0;
+        }
+        for (auto &c : drop) (void)hipFree(c.p);
+        if (hipMalloc(&p, cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    *got_cap = cap;
+    return p;
+}
+
+void ing_dev_free(int device, void *p, size_t cap) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(ing_cache_mu);
+        if (cap >= (1u << 20) && ing_cache_bytes + cap <= TDT_ING_CACHE_MAX) {
+            ing_cache.push_back(IngCached{p, cap, device});
+            ing_cache_bytes += cap;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+}  // namespace
+
+static int ing_grow(tdt_ingest *g, tdt_buf &b, size_t bytes, bool keep = false) {
+    if (b.cap >= bytes) return TDT_OK;
+    size_t cap = bytes + bytes / 4 + 4096;
+    void *p = ing_dev_alloc(g->ctx->device, cap, &cap);
+    if (!p) {
         tdt_set_error("tdt_ingest: device allocation of %zu bytes failed", cap);
         return TDT_E_NOMEM;
     }
     if (keep && b.p) {
         if (hipMemcpyAsync(p, b.p, b.cap, hipMemcpyDeviceToDevice, g->ctx->stream) != hipSuccess || hipStreamSynchronize(g->ctx->stream) != hipSuccess) {
-            (void)hipFree(p);
+            ing_dev_free(g->ctx->device, p, cap);
             tdt_set_error("tdt_ingest: device copy failed");
             return TDT_E_HIP;
         }
+    } else if (b.p) {
+        // the old buffer may still be read by kernels in flight on the launch stream: it leaves this reader only behind them
+        if (hipStreamSynchronize(g->ctx->stream) != hipSuccess) (void)hipGetLastError();
     }
-    if (b.p) (void)hipFree(b.p);
+    ing_dev_free(g->ctx->device, b.p, b.cap);
     b.p = p;
     b.cap = cap;
     return TDT_OK;
@@ -321,7 +391,7 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
     for (auto &e : g->tev)
         if (e) (void)hipEventDestroy(e);
     for (tdt_buf *b : {&g->comp, &g->pf[0].buf, &g->pf[1].buf, &g->pf[2].buf, &g->pf[0].table, &g->pf[1].table, &g->pf[2].table, &g->table, &g->out, &g->seg, &g->soa})
-        if (b->p) (void)hipFree(b->p);
+        ing_dev_free(g->ctx->device, b->p, b->cap);                  // (both streams are idle: synchronised above)
     if (g->pin.p) (void)hipHostFree(g->pin.p);
     delete g;
     return TDT_OK;
@@ -347,16 +417,15 @@ extern "C" int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t le
     if (!slot) return TDT_OK;                            // every slot holds a span that has not been pushed yet: this one is copied by its push
     // (a buffer swapped into a slot by an earlier push is free: that push waited for its inflate kernel before returning)
     if (slot->buf.cap < comp_pad) {                     // grow without touching the launch stream (ing_grow's copy path is not needed here)
-        void *np_ = nullptr;
-        const size_t cap = comp_pad + comp_pad / 4 + 4096;
-        if (hipMalloc(&np_, cap) != hipSuccess) {
-            (void)hipGetLastError();
+        size_t cap = comp_pad + comp_pad / 4 + 4096;
+        void *np_ = ing_dev_alloc(ctx->device, cap, &cap);
+        if (!np_) {
             tdt_set_error("tdt_ingest_prefetch: device allocation of %zu bytes failed", cap);
             return TDT_E_NOMEM;
         }
         if (slot->buf.p) {
             (void)hipStreamSynchronize(ctx->copy_stream);
-            (void)hipFree(slot->buf.p);
+            ing_dev_free(ctx->device, slot->buf.p, slot->buf.cap);
         }
         slot->buf.p = np_;
         slot->buf.cap = cap;
@@ -378,12 +447,12 @@ extern "C" int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t le
         const size_t nb = slot->blocks.size();
         const size_t tab = (nb * sizeof(BzDesc) + 255) & ~(size_t)255, stb = (nb * 4 + 255) & ~(size_t)255;
         if (slot->table.cap < tab + stb + 256) {
-            void *np_ = nullptr;
-            const size_t cap = (tab + stb + 256) * 5 / 4 + 4096;
-            if (hipMalloc(&np_, cap) == hipSuccess) {
+            size_t cap = (tab + stb + 256) * 5 / 4 + 4096;
+            void *np_ = ing_dev_alloc(ctx->device, cap, &cap);
+            if (np_) {
                 if (slot->table.p) {
                     (void)hipStreamSynchronize(ctx->copy_stream);
-                    (void)hipFree(slot->table.p);
+                    ing_dev_free(ctx->device, slot->table.p, slot->table.cap);
                 }
                 slot->table.p = np_;
                 slot->table.cap = cap;
@@ -765,6 +834,7 @@ extern "C" int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned) {
 struct tdt_retained {
     tdt_ctx *ctx;
     void *out, *soa;
+    size_t out_cap, soa_cap;
 };
 extern "C" int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle) {
     if (!g || !handle) {
@@ -780,16 +850,15 @@ extern "C" int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle) {
     hipStream_t st = g->ctx->stream;
     tdt_buf fresh;
     if (g->out.cap) {
-        if (hipMalloc(&fresh.p, g->out.cap) != hipSuccess) {
-            (void)hipGetLastError();
+        fresh.p = ing_dev_alloc(g->ctx->device, g->out.cap, &fresh.cap);
+        if (!fresh.p) {
             tdt_set_error("tdt_ingest_retain: device allocation of %zu bytes failed", g->out.cap);
             return TDT_E_NOMEM;
         }
-        fresh.cap = g->out.cap;
         if (g->carry) TDT_HIP(hipMemcpyAsync(fresh.p, (char *)g->out.p + g->tail_off, g->carry, hipMemcpyDeviceToDevice, st));
         TDT_HIP(hipStreamSynchronize(st));
     }
-    tdt_retained *r = new tdt_retained{g->ctx, g->out.p, g->soa.p};
+    tdt_retained *r = new tdt_retained{g->ctx, g->out.p, g->soa.p, g->out.cap, g->soa.cap};
     g->out = fresh;
     g->tail_off = 0;
     g->soa = tdt_buf();
@@ -806,8 +875,8 @@ extern "C" int tdt_ingest_release(tdt_retained *r) {
     if (!r) return TDT_OK;
     (void)hipSetDevice(r->ctx->device);
     (void)hipStreamSynchronize(r->ctx->stream);
-    if (r->out) (void)hipFree(r->out);
-    if (r->soa) (void)hipFree(r->soa);
+    ing_dev_free(r->ctx->device, r->out, r->out_cap);
+    ing_dev_free(r->ctx->device, r->soa, r->soa_cap);
     delete r;
     return TDT_OK;
 }

@@ -36,12 +36,17 @@ def _device_figures(lib, h, state):
     return mean, numpy.sqrt(numpy.float64(msd.value)), numpy.float64(pct)
 
 
+STAGE_SECONDS = {}          # wall seconds inside the last statistics() call, by what it waited for
+
+
 def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False, shard=None):
     import os
     from . import bamio
     library = {}
     t = time.time()
+    STAGE_SECONDS.clear()
     bamio.set_carry(None)
+    STAGE_SECONDS["drop a stale carry"] = time.time() - t
     # shard = (0, world): rank 0 of an N-rank job samples from ITS byte range of the file, so that the batches it keeps are the head of
     # its own scan; a sample that does not end inside that range is taken again from the whole file (below)
     sharded = shard is not None and os.environ.get("TIDDIT_HOST_INGEST") != "1" and os.environ.get("TIDDIT_STATS_HOST") != "1"
@@ -49,6 +54,7 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False,
         else open_bam(bam_file_name)
     # `tiddit --sv` scans the same file for signals next (tiddit_signal.main): the sampled batches stay in HBM with their coverage records
     # written for the 50-bp histogram, and that pass starts from them instead of reading and inflating this part of the file again
+    STAGE_SECONDS["open the reader"] = time.time() - t
     on_device = isinstance(reader, bamio.DeviceBamReader)
     carry = carry and on_device and os.environ.get("TIDDIT_NO_CARRY") != "1"
     kept, hist = [], None
@@ -57,11 +63,13 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False,
         hist = tiddit_coverage.CoverageHistogram([(n, l) for n, l in zip(reader.references, reader.lengths)], 50, ctx=reader.ctx)
         reader.bin_for(hist)
         reader.retain = True
+    STAGE_SECONDS["50-bp histogram for the carried batches"] = time.time() - t - STAGE_SECONDS["open the reader"]
     lib = _native.load()
     state = numpy.zeros(6, dtype=numpy.int64)
     chunks = []
     figures = None
     batches = reader.batches()
+    t_loop, t_first = time.time(), None
     if on_device and os.environ.get("TIDDIT_STATS_HOST") != "1":
         # the sampling loop (:17-47), its cut-off and the three numpy figures (:52-56) on the device: the decoded fields of every batch
         # are in HBM already, and nothing but a handful of counters comes back
@@ -70,6 +78,9 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False,
         try:
             done = ctypes.c_int(0)
             for b in batches:
+                if t_first is None:
+                    t_first = time.time()
+                    STAGE_SECONDS["first batch (pinned spans, first read, first push)"] = t_first - t_loop
                 if carry:
                     kept.append(b)
                 d = b.dev
@@ -88,7 +99,10 @@ def _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False,
                 if hist is not None:
                     hist.close()
                 return _statistics(bam_file_name, ref, min_mapq, max_ins_len, n_reads, carry=False, shard=None)
+            STAGE_SECONDS["the other batches + sampling kernels"] = time.time() - (t_first or t_loop)
+            t_f = time.time()
             figures = _device_figures(lib, h, state)
+            STAGE_SECONDS["figures (mean, std, percentile)"] = time.time() - t_f
         finally:
             if h is not None:
                 lib.tdt_stats_destroy(h)

@@ -12,7 +12,7 @@ if not (os.path.exists(bam) and os.path.exists(fa)):
     seqs = synth_bam.write_fasta(fa, contigs)
     synth_bam.write_wgs_sv_bam(bam, contigs, threads=min(32, os.cpu_count() or 1), ref_seqs=seqs)
 out = os.path.join(d, "modes")
-for mode in ("1", "after", "0", "1", "after"):
+for mode in ("1", "1", "1", "1", "1", "1"):
     os.environ["TIDDIT_GC_OVERLAP"] = mode
     for rep in range(4):
         shutil.rmtree(out + "_tiddit", ignore_errors=True)
@@ -24,3 +24,6 @@ for mode in ("1", "after", "0", "1", "after"):
         print("GC_OVERLAP=%-5s rep %d wall %.3f | stats %.3f signal %.3f (scan %.3f) gc wait %.3f ploidy %.3f clustering %.3f" % (
             mode, rep, wall, T["library statistics"], T["signal extraction + coverage"], T.get("  scan (ingest, coverage, predicates, signal tables)", 0),
             T["GC bins"], T["ploidy (masked medians)"], T["clustering"]), flush=True)
+        if T["library statistics"] > 0.25:
+            from tiddit_amd import tiddit_stats
+            print("   slow statistics:", {k: round(v, 3) for k, v in tiddit_stats.STAGE_SECONDS.items()}, flush=True)
