@@ -443,3 +443,55 @@ def test_sv_signal_tables_on_n_ranks_gloo_world2_and_3(tmp_path):
         rows = [res[r]["rows"] for r in range(world)]
         assert all(x > 0 for x in rows) and max(rows) < sum(rows)
         assert all("candidates to rank 0" in res[r]["stages"] and "parse .tab" not in res[r]["stages"] for r in range(world))
+
+
+def _a2a_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from tiddit_amd import dist as tdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank s has (s + 1) * 1000 * d bytes for rank d (nothing for rank 0, nothing for itself when s is odd): every byte says who sent it to whom
+        def part(s, d):
+            n = 0 if d == 0 or (s == d and s % 2) else (s + 1) * 1000 * d
+            return np.full(n, 16 * s + d, dtype=np.uint8)
+        got = tdist.alltoall_bytes([part(rank, d) for d in range(world)])
+        assert len(got) == world
+        for s in range(world):
+            assert np.array_equal(np.asarray(got[s]), part(s, rank)), (rank, s)
+        sizes = tdist.allgather_i64([rank, 10 * rank, -rank])
+        assert sizes.shape == (world, 3) and sizes[:, 1].tolist() == [10 * r for r in range(world)]
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_alltoall_bytes_and_contig_owners_gloo_world3():
+    """the one exchange of the N-rank signal tables: ragged and empty payloads arrive in rank order; the owner map is a pure function"""
+    import torch.multiprocessing as mp
+    from tiddit_amd.dist import contig_owners
+    lengths = [248, 242, 198, 0.5, 190, 182, 171, 16e-3, 159]
+    kept = [ln >= 1 for ln in lengths]
+    for world in (1, 2, 3, 8):
+        own = contig_owners(lengths, kept, world)
+        assert own.dtype == np.int32 and len(own) == len(lengths) and set(own.tolist()) <= set(range(world))
+        load = [sum(l for l, o, k in zip(lengths, own.tolist(), kept) if k and o == r) for r in range(world)]
+        assert max(load) - min(l for l in load if l or world <= 7) <= max(lengths) or world >= 7      # LPT: no rank more than one contig ahead
+        assert np.array_equal(own, contig_owners(lengths, kept, world))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_a2a_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert all(v == "ok" for v in res.values()), res

@@ -32,6 +32,9 @@
 #ifndef B2_WAVES
 #define B2_WAVES 4
 #endif
+#ifndef B2_PARMAX
+#define B2_PARMAX 16                       // longest match a lane copies by itself (bytes): 16 or 32
+#endif
 // LDS bytes per wave: lens 320 | lut_ll 4 << TB_LL | lut_d 4 << TB_D | sorted_ll 576 | sorted_d 64 | meta_ll 96 | meta_d 96 | ring 512 + 16
 // (the ring's first two dwords are mirrored behind it: a lane's three consecutive dwords never wrap, one address serves all three reads)
 #define B2_OFF_LUTLL 320
@@ -525,25 +528,34 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             const unsigned srco = pos - dist;                       // first source byte of this lane's match
             // Matches whose source lies wholly before this window's output cannot depend on anything decoded in it: each of
             // those is copied by its own lane, all at once (3 bytes unconditionally — the minimum match — then the rest).
-            const bool par = copy && srco + mlen <= op && mlen <= 16;
+            const bool par = copy && srco + mlen <= op && mlen <= B2_PARMAX;
 #ifndef B2_EXP_NOPAR
-            const bool wide = par && srco + 16 <= isize;            // the 16-byte read stays inside this block's output
-            if (par && !wide)                                       // (a source in the block's last bytes: plain byte copy)
+            const bool wide = par && mlen >= 4 && srco + (B2_PARMAX > 16 && mlen > 16 ? 32u : 16u) <= isize;   // the 16-byte reads stay inside this block's output
+            if (par && !wide)                                       // (a 3-byte match, or a source in the block's last bytes: plain byte copy)
                 for (unsigned k = 0; k < mlen; k++) dst[pos + k] = dst[srco + k];
             if (wide) {
-                // all (<= 16) source bytes in ONE unaligned load, then the stores: a byte-by-byte loop costs one memory round trip
-                // per byte, and on BAM-shaped data the typical match is ~10 bytes long
-                const B2U128 v = *reinterpret_cast<const B2U128 *>(dst + srco);
+                // the source bytes in ONE round trip — one (or two) unaligned 16-byte loads and the match's LAST four bytes once more —
+                // then whole dwords, the last one overlapping its predecessor: no byte stores, no select chain for the tail
+                // (a byte-by-byte loop costs one memory round trip per byte; on BAM-shaped data the typical match is ~10 bytes long)
+                const unsigned char *const s_ = dst + srco;
                 unsigned char *const p_ = dst + pos;
-                if (mlen >= 4) reinterpret_cast<B2U32 *>(p_)->v = v.w[0];
+                const B2U128 v = *reinterpret_cast<const B2U128 *>(s_);
+#if B2_PARMAX > 16
+                B2U128 v2 = {{0, 0, 0, 0}};
+                if (mlen > 16) v2 = *reinterpret_cast<const B2U128 *>(s_ + 16);
+#endif
+                const unsigned tailw = reinterpret_cast<const B2U32 *>(s_ + mlen - 4)->v;
+                reinterpret_cast<B2U32 *>(p_)->v = v.w[0];
                 if (mlen >= 8) reinterpret_cast<B2U32 *>(p_ + 4)->v = v.w[1];
                 if (mlen >= 12) reinterpret_cast<B2U32 *>(p_ + 8)->v = v.w[2];
                 if (mlen >= 16) reinterpret_cast<B2U32 *>(p_ + 12)->v = v.w[3];
-                const unsigned q4 = mlen >> 2, t = mlen & 3, b4 = mlen & ~3u;
-                const unsigned wt = q4 == 0 ? v.w[0] : q4 == 1 ? v.w[1] : q4 == 2 ? v.w[2] : v.w[3];
-                if (t >= 1) p_[b4] = (unsigned char)wt;
-                if (t >= 2) p_[b4 + 1] = (unsigned char)(wt >> 8);
-                if (t == 3) p_[b4 + 2] = (unsigned char)(wt >> 16);
+#if B2_PARMAX > 16
+                if (mlen >= 20) reinterpret_cast<B2U32 *>(p_ + 16)->v = v2.w[0];
+                if (mlen >= 24) reinterpret_cast<B2U32 *>(p_ + 20)->v = v2.w[1];
+                if (mlen >= 28) reinterpret_cast<B2U32 *>(p_ + 24)->v = v2.w[2];
+                if (mlen >= 32) reinterpret_cast<B2U32 *>(p_ + 28)->v = v2.w[3];
+#endif
+                if (mlen & 3) reinterpret_cast<B2U32 *>(p_ + mlen - 4)->v = tailw;
             }
 #endif
 #ifdef B2_STATS
