@@ -166,6 +166,35 @@ def test_sv_on_n_ranks_is_byte_identical(run, tmp_path, world):
     assert all(len(v) == 1 for v in res.values()) and max(shares) < sum(shares)
 
 
+def test_sv_n_rank_path_over_real_rccl_with_one_rank(run, tmp_path):
+    """The N-rank job's collectives over REAL RCCL: backend nccl refuses two ranks on one device, so the 2 / 3-rank runs above exchange
+    over gloo and the nccl-only branches (all_to_all_single on device tensors, the asynchronous broadcast of the library statistics,
+    device-side all-gathers, the all-reduce of the bins) would never execute on a one-GPU box.  TIDDIT_FORCE_DIST=1 takes the N-rank
+    path with WORLD_SIZE=1: one process, one rank, every collective a real RCCL call — same files, byte for byte."""
+    import socket
+    import subprocess
+    import sys
+    fx, bam, fa, contigs, out = run
+    if fx["params"]["total_mb"] > 30:
+        pytest.skip("the smaller files cover it")
+    P = fx["params"]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    nout = str(tmp_path / "rccl1")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TIDDIT_FORCE_DIST="1",
+               TIDDIT_INGEST_CHUNK=str(48 << 20))
+    env.pop("TIDDIT_DIST_BACKEND", None)                       # nccl
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "tiddit_amd", "--sv", "--bam", bam, "--ref", fa, "-o", nout, "--skip_assembly", "-s", str(P["n_reads_stats"])],
+                       cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for rel in ["_tiddit/discordants_WGS.tab", "_tiddit/splits_WGS.tab", "_tiddit/clips_WGS.fa", ".ploidies.tab", ".candidates.tab"] + \
+               ["_tiddit/clips/%s.fa" % n for n, ln in contigs if ln >= P["min_contig"]]:
+        assert open(nout + rel, "rb").read() == open(out + rel, "rb").read(), rel
+
+
 def test_sv_60x_on_one_and_two_ranks(golden_dir, tmp_path):
     """BASELINE configs[4] names a 60x file: the 24-Mb genome at twice the depth (9.6 M records) as one process and as two ranks
     sharing the GPU — byte-identical outputs, and the signal tables equal the CPU restatement's on the same file"""

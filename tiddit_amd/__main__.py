@@ -184,7 +184,10 @@ def run_sv(args, version):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = 0
     dist = None
-    if world > 1:
+    # TIDDIT_FORCE_DIST=1: take the N-rank code path with whatever WORLD_SIZE says, also 1 — a one-GPU box can then run every
+    # collective of the job over real RCCL (backend nccl refuses two ranks on one device; tests/test_gpu_sv_e2e.py)
+    multi = world > 1 or os.environ.get("TIDDIT_FORCE_DIST") == "1"
+    if multi:
         import torch
         import torch.distributed as dist
         from . import dist as tdist
@@ -201,7 +204,7 @@ def run_sv(args, version):
         except Exception:
             if not args.force_overwrite:
                 print("Eror output folder exists")
-                if world > 1:
+                if multi:
                     dist.destroy_process_group()
                     os._exit(1)                                          # (the other ranks sit in the broadcast below: take the job down)
                 quit()
@@ -213,7 +216,7 @@ def run_sv(args, version):
     from .trace import stage
     t = time.time()
     with stage("tiddit: library statistics"):
-        if world == 1:
+        if not multi:
             library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=True)
         else:
             # The sample is the head of the file = the head of rank 0's byte range: rank 0 samples it through its own share's reader and
@@ -260,7 +263,7 @@ def run_sv(args, version):
         from . import _native
         gc_job = {}
         gc_mine = list(chromosomes)
-        if world > 1:
+        if multi:
             owned = tdist.shard_contigs([contig_length[c] for c in chromosomes], world)[rank]
             gc_mine = [chromosomes[i] for i in owned]
 
@@ -284,7 +287,7 @@ def run_sv(args, version):
             start_gc()
     t = time.time()
     with stage("tiddit: signal extraction + coverage"):
-        signal_main = tiddit_signal.main_sharded if world > 1 else tiddit_signal.main
+        signal_main = tiddit_signal.main_sharded if multi else tiddit_signal.main
         try:
             coverage_data = signal_main(args.bam, args.ref, prefix, min_mapq, max_ins_len, sample_id, args.threads, args.min_contig,
                                         False, args.min_anchor_len, args.min_clip_len)
@@ -310,7 +313,7 @@ def run_sv(args, version):
             if "error" in gc_job:
                 raise gc_job["error"]
             gc_dictionary = gc_job["result"]
-            if world > 1:                       # every rank's contigs to rank 0 (int8 bins: 60 MB for a human genome)
+            if multi:                           # every rank's contigs to rank 0 (int8 bins: 60 MB for a human genome)
                 import pickle
                 parts = tdist.gather_bytes(pickle.dumps(gc_dictionary, protocol=4), 0)
                 if rank == 0:
@@ -335,7 +338,7 @@ def run_sv(args, version):
         args.e = 50
     t = time.time()
     with stage("tiddit: clustering"):
-        cluster_main = tiddit_cluster.main_sharded if world > 1 else tiddit_cluster.main
+        cluster_main = tiddit_cluster.main_sharded if multi else tiddit_cluster.main
         sv_clusters = cluster_main(prefix, contigs, contig_length, samples, library["mp"], args.e, args.l, max_ins_len, args.min_contig,
                                    args.skip_assembly, args.r)
     T["clustering"] = time.time() - t
@@ -360,7 +363,7 @@ def run_sv(args, version):
             T["variant typing (reference package)"] = time.time() - t
         else:
             print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
-    if world > 1:
+    if multi:
         dist.barrier()                                                   # every output file exists when any rank returns
 
 

@@ -32,9 +32,10 @@
 #ifndef B2_WAVES
 #define B2_WAVES 4
 #endif
-#ifndef B2_PARMAX
-#define B2_PARMAX 16                       // longest match a lane copies by itself (bytes): 16 or 32
-#endif
+#define B2_PARMAX 16                       // longest match a lane copies by itself (bytes); 32 with two loads was measured: slower
+#ifndef B2_PIPE
+#define B2_PIPE 0                          // 1: the copies pipelined over two windows (measured in round 4: 18.3 ms against 17.9, 22.4 against 21.7 —
+#endif                                     // the wait it moves is not what a window waits for; ten more live registers spill).  Kept as a variant.
 // LDS bytes per wave: lens 320 | lut_ll 4 << TB_LL | lut_d 4 << TB_D | sorted_ll 576 | sorted_d 64 | meta_ll 96 | meta_d 96 | ring 512 + 16
 // (the ring's first two dwords are mirrored behind it: a lane's three consecutive dwords never wrap, one address serves all three reads)
 #define B2_OFF_LUTLL 320
@@ -288,6 +289,38 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
         }                                                                                 \
     } while (0)
 
+#if B2_PIPE
+    // copies of the previous window that are still to be stored: per lane its kind (1 = own-lane copy with the source bytes loaded,
+    // 2 = own-lane byte copy, 3 = replayed in stream order by all lanes), where, how long, how far back, and the loaded bytes
+    unsigned pd_kind = 0, pd_pos = 0, pd_mlen = 0, pd_dist = 0, pd_tail = 0;
+    B2U128 pd_v = {{0, 0, 0, 0}};
+#define B2_FLUSH()                                                                                               \
+    do {                                                                                                         \
+        if (pd_kind == 2u)                      /* a 3-byte match, or a source in the block's last bytes */      \
+            for (unsigned k_ = 0; k_ < pd_mlen; k_++) dst[pd_pos + k_] = dst[pd_pos - pd_dist + k_];             \
+        if (pd_kind == 1u) {                    /* whole dwords, the last one overlapping its predecessor */     \
+            unsigned char *const p_ = dst + pd_pos;                                                              \
+            reinterpret_cast<B2U32 *>(p_)->v = pd_v.w[0];                                                        \
+            if (pd_mlen >= 8) reinterpret_cast<B2U32 *>(p_ + 4)->v = pd_v.w[1];                                  \
+            if (pd_mlen >= 12) reinterpret_cast<B2U32 *>(p_ + 8)->v = pd_v.w[2];                                 \
+            if (pd_mlen >= 16) reinterpret_cast<B2U32 *>(p_ + 12)->v = pd_v.w[3];                                \
+            if (pd_mlen & 3) reinterpret_cast<B2U32 *>(p_ + pd_mlen - 4)->v = pd_tail;                           \
+        }                                                                                                        \
+        u64 mm_ = __ballot(pd_kind == 3u);      /* the others in stream order (they may read each other's output) */ \
+        while (mm_) {                                                                                            \
+            const unsigned l_ = (unsigned)__builtin_ctzll(mm_);                                                  \
+            mm_ &= ~(1ull << l_);                                                                                \
+            const unsigned len_ = b2_rl(pd_mlen, l_), dd_ = b2_rl(pd_dist, l_), q_ = b2_rl(pd_pos, l_), so_ = q_ - dd_; \
+            unsigned i_ = (unsigned)lane;                                                                        \
+            do {                                                                                                 \
+                const unsigned j_ = dd_ >= len_ ? i_ : i_ % dd_;   /* a distance shorter than the match repeats its source */ \
+                if (i_ < len_) dst[q_ + i_] = dst[so_ + j_];                                                     \
+                i_ += 64;                                                                                        \
+            } while (i_ - (unsigned)lane < len_);                                                                \
+        }                                                                                                        \
+        pd_kind = 0;                                                                                             \
+    } while (0)
+#endif
     bool last = false;
     while (!last && err == B2_OK) {
         u64 hb;
@@ -529,32 +562,34 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             // Matches whose source lies wholly before this window's output cannot depend on anything decoded in it: each of
             // those is copied by its own lane, all at once (3 bytes unconditionally — the minimum match — then the rest).
             const bool par = copy && srco + mlen <= op && mlen <= B2_PARMAX;
-#ifndef B2_EXP_NOPAR
-            const bool wide = par && mlen >= 4 && srco + (B2_PARMAX > 16 && mlen > 16 ? 32u : 16u) <= isize;   // the 16-byte reads stay inside this block's output
+            const bool wide = par && mlen >= 4 && srco + 16 <= isize;   // the 16-byte read stays inside this block's output
+#if B2_PIPE
+            // (measurement variant) The copies are PIPELINED over two windows: this window was decoded while the previous window's loads
+            // were in flight; now the previous window's bytes are stored (B2_FLUSH waits for them here, one decode later than it used to), and
+            // only then are this window's loads issued — a source may lie in what the flush has just written, and the memory operations
+            // of one wave stay in order.
+            B2_FLUSH();
+            pd_kind = wide ? 1u : par ? 2u : copy ? 3u : 0u;
+            pd_pos = pos;
+            pd_mlen = mlen;
+            pd_dist = dist;
+            if (wide) {
+                const unsigned char *const s_ = dst + srco;
+                pd_v = *reinterpret_cast<const B2U128 *>(s_);
+                pd_tail = reinterpret_cast<const B2U32 *>(s_ + mlen - 4)->v;
+            }
+#else
             if (par && !wide)                                       // (a 3-byte match, or a source in the block's last bytes: plain byte copy)
                 for (unsigned k = 0; k < mlen; k++) dst[pos + k] = dst[srco + k];
             if (wide) {
-                // the source bytes in ONE round trip — one (or two) unaligned 16-byte loads and the match's LAST four bytes once more —
-                // then whole dwords, the last one overlapping its predecessor: no byte stores, no select chain for the tail
-                // (a byte-by-byte loop costs one memory round trip per byte; on BAM-shaped data the typical match is ~10 bytes long)
                 const unsigned char *const s_ = dst + srco;
                 unsigned char *const p_ = dst + pos;
                 const B2U128 v = *reinterpret_cast<const B2U128 *>(s_);
-#if B2_PARMAX > 16
-                B2U128 v2 = {{0, 0, 0, 0}};
-                if (mlen > 16) v2 = *reinterpret_cast<const B2U128 *>(s_ + 16);
-#endif
                 const unsigned tailw = reinterpret_cast<const B2U32 *>(s_ + mlen - 4)->v;
                 reinterpret_cast<B2U32 *>(p_)->v = v.w[0];
                 if (mlen >= 8) reinterpret_cast<B2U32 *>(p_ + 4)->v = v.w[1];
                 if (mlen >= 12) reinterpret_cast<B2U32 *>(p_ + 8)->v = v.w[2];
                 if (mlen >= 16) reinterpret_cast<B2U32 *>(p_ + 12)->v = v.w[3];
-#if B2_PARMAX > 16
-                if (mlen >= 20) reinterpret_cast<B2U32 *>(p_ + 16)->v = v2.w[0];
-                if (mlen >= 24) reinterpret_cast<B2U32 *>(p_ + 20)->v = v2.w[1];
-                if (mlen >= 28) reinterpret_cast<B2U32 *>(p_ + 24)->v = v2.w[2];
-                if (mlen >= 32) reinterpret_cast<B2U32 *>(p_ + 28)->v = v2.w[3];
-#endif
                 if (mlen & 3) reinterpret_cast<B2U32 *>(p_ + mlen - 4)->v = tailw;
             }
 #endif
@@ -579,11 +614,8 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 }
             }
 #endif
-#ifdef B2_EXP_NOSEQ
-            u64 mm = 0;
-#else
+#if !B2_PIPE
             u64 mm = __ballot(copy && !par);
-#endif
             while (mm) {                                            // the others in stream order (they may read each other's output)
                 const unsigned l = (unsigned)__builtin_ctzll(mm);
                 mm &= ~(1ull << l);
@@ -595,6 +627,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                     i += 64;
                 } while (i - (unsigned)lane < len);
             }
+#endif
             if (err != B2_OK) break;
             op += tot;
             bp += cur;
@@ -605,6 +638,9 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             B2_ENSURE();
             if (err != B2_OK || stop == 2) break;
         }
+#if B2_PIPE
+        if (err == B2_OK) B2_FLUSH();                              // the last window's copies, before the next DEFLATE block writes behind them
+#endif
     }
     if (err == B2_OK && op != isize) err = B2_E_SIZE;
     if (err == B2_OK && bp > end_bit + 7) err = B2_E_INPUT;
@@ -613,6 +649,9 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
     }
 #undef B2_ENSURE
 #undef B2_STAGE
+#if B2_PIPE
+#undef B2_FLUSH
+#endif
 }
 
 void tdt_bz_launch_lanes(hipStream_t st, int num_cu, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,

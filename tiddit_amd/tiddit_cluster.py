@@ -398,7 +398,8 @@ def _handed_over(prefix, chromosomes, contig_length, samples, min_contig, skip_a
 def _is_sharded():
     try:
         import torch.distributed as _dist
-        return _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+        import os
+        return _dist.is_available() and _dist.is_initialized() and (_dist.get_world_size() > 1 or os.environ.get("TIDDIT_FORCE_DIST") == "1")
     except ImportError:
         return False
 
