@@ -82,6 +82,26 @@ extern "C" int tdt_debug_b2_stats(unsigned long long *out, int reset) {
 }
 #endif
 
+#ifdef B2_PROF   // measurement builds only (tools/inflate_prof.py): shader-clock cycles per phase of the window loop, summed over all waves
+__device__ unsigned long long b2_prof[16];    // 0 gather + LUT lookups, 1 per-lane lengths / distances, 2 chain walk (+ long codes), 3 prefix sum + checks,
+                                              // 4 literal store + own-lane copies (load, wait, stores), 5 replayed matches, 6 cursor + ring refill, 7 tables / headers, 8 windows
+extern "C" int tdt_debug_b2_prof(unsigned long long *out, int reset) {
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(b2_prof), z, sizeof z) == hipSuccess ? 0 : -2;
+    }
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(b2_prof), 16 * 8) == hipSuccess ? 0 : -2;
+}
+#define B2_MARK(k_)                                               \
+    do {                                                          \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        pf[k_] += (unsigned)(t_ - pf_last);                       \
+        pf_last = t_;                                             \
+    } while (0)
+#else
+#define B2_MARK(k_) do { } while (0)
+#endif
+
 // lane's bit of a 64-bit scalar mask selects between two values: ONE v_cndmask with the mask as its SGPR-pair operand
 __device__ __forceinline__ unsigned b2_sel(u64 m, unsigned if_set, unsigned if_clear) {
     unsigned r;
@@ -186,18 +206,21 @@ __device__ __forceinline__ bool b2_build(const unsigned char *lens, int n, int t
     return true;
 }
 
-// code longer than the LUT: canonical walk over lengths tb+1..15 (uniform).  -> LUT entry, B2_ESC if no code matches
-__device__ __noinline__ unsigned b2_long_code(unsigned bits, int tb, int mode, const unsigned short *sorted, const unsigned short *meta) {
-#pragma nounroll
-    for (int l = tb + 1; l <= 15; l++) {
-        const unsigned code = __brev(bits & ((1u << l) - 1u)) >> (32 - l);
-        const unsigned f = b2_rfl(meta[l]), c = b2_rfl(meta[16 + l]);
-        if (code - f < c) {
-            const unsigned sym = b2_rfl(sorted[b2_rfl(meta[32 + l]) + code - f]);
-            return b2_entry(mode, sym, (unsigned)l);
-        }
-    }
-    return B2_ESC;
+// Code longer than the LUT.  Lane l (tb < l <= 15) tests code length l — first code, count and offset of that length come from the
+// table's meta block in one round of LDS reads — a ballot picks the shortest length that matches (a prefix code has exactly one), and
+// one more read fetches the symbol: two LDS round trips, where the length-by-length walk of rounds 1-3 needed up to three per length
+// (one symbol in ten takes this path on BAM-shaped data, and it sits inside the scalar chain walk).  -> LUT entry, B2_ESC if no code matches
+__device__ __forceinline__ unsigned b2_long_code(unsigned bits, int tb, int mode, const unsigned short *sorted, const unsigned short *meta, int lane) {
+    const unsigned l = (unsigned)lane & 15u;
+    const unsigned code = l ? __brev(bits & ((1u << l) - 1u)) >> (32 - l) : 0u;
+    const unsigned f = meta[l], c = meta[16 + l], off = meta[32 + l];
+    const bool hit = lane < 16 && (int)l > tb && code - f < c;
+    const u64 m = __ballot(hit);
+    if (!m) return B2_ESC;
+    const unsigned L = (unsigned)__builtin_ctzll(m);
+    const unsigned idx = b2_rl(off + code - f, L);
+    const unsigned sym = b2_rfl(sorted[idx]);
+    return b2_entry(mode, sym, L);
 }
 
 // inclusive prefix sum over the 64 lanes: six fused DPP adds (Hillis-Steele inside each row of 16, then the two row
@@ -259,6 +282,10 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
     unsigned cw = 0;                                            // windows cw and cw+1 are staged (window w in ring half w & 1)
     unsigned err = B2_OK;
     unsigned op = 0;
+#ifdef B2_PROF
+    unsigned pf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pf_last = __builtin_readcyclecounter();
+#endif
 
 // ring half h (0 / 1) <- the 64 dwords of window w_; the ring's first two dwords are mirrored behind its end
 #define B2_STAGE(h_, w_)                                                                   \
@@ -469,6 +496,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             // every lane: the symbol that would start at bit bp + lane
             // (three dwords from the ring; every field but the distance's extra bits lies in the first 32 stream bits:
             //  9-bit code + 5 extra + 8-bit code = 22, so 64-bit shifts are not needed)
+            B2_MARK(7);                                               // (whatever came before this window: tables, headers, the previous window's tail)
             const unsigned q = bp + (unsigned)lane, qd = (q >> 5) & 127, qs = q & 31;
             const unsigned wa = win[qd], wb = win[qd + 1], wc = win[qd + 2];      // one address, three reads (the ring's mirror: no wrap)
             const unsigned lo = __builtin_amdgcn_alignbit(wb, wa, qs), hi = __builtin_amdgcn_alignbit(wc, wb, qs);
@@ -479,6 +507,10 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             // next[i] = i + bits consumed; a chain ends at a value >= 64: [128, 256) = a code the tables do not resolve (the literal /
             // length code itself or the distance code behind it), >= 256 = end of block (256 + the bit after it)
             const unsigned nxt = (unsigned)lane + step1 + (is_len ? B2_STEP(e2) : 0u);
+#ifdef B2_PROF
+            asm volatile("" :: "v"(nxt));
+            B2_MARK(0);
+#endif
             // what a symbol starting at this lane's bit would write — 1 byte (literal), its length (match), nothing (end of block) — and,
             // for a match, from how far back
             const unsigned l1 = e1 & 15, eb1 = (e1 >> 4) & 15;
@@ -487,6 +519,10 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             unsigned olraw = is_len ? mlen : ((e1 & B2_F_EOB) ? 0u : 1u);
             const unsigned l2 = e2 & 15, eb2 = (e2 >> 4) & 15, base2 = (e2 >> 8) & 0x7fff;
             unsigned dist = base2 + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, (step1 + l2) & 31), 0u, eb2);
+#ifdef B2_PROF
+            asm volatile("" :: "v"(dist), "v"(olraw));
+            B2_MARK(1);
+#endif
             // The true chain of symbol starts (scalar: one readlane per symbol).  A code longer than the LUTs (one symbol in ten on
             // BAM-shaped data) does not end the window: it is resolved right here by the scalar canonical walk, its lane is patched with
             // what the symbol writes, and the chain goes on behind it — the symbol's bytes leave with the window's other output instead of
@@ -496,7 +532,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             unsigned stop = 0;                                      // 2 = end of block
             for (;;) {
                 while (cur < 64) {
-                    chain |= 1ull << cur;
+                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(cur));      // chain |= 1 << cur in ONE scalar instruction (the scalar unit is shared by the CU's 32 waves)
                     cur = b2_rl(nxt, cur);
                 }
                 if (cur >= 256) {
@@ -510,7 +546,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 const unsigned w0 = b2_rfl(win[d]), w1 = b2_rfl(win[d + 1]), w2 = b2_rfl(win[d + 2]);
                 u64 v = ((u64)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
                 unsigned e = b2_rfl(lut_ll[(unsigned)v & ((1u << B2_TB_LL) - 1)]);
-                if (e == B2_ESC) e = b2_rfl(b2_long_code((unsigned)v, B2_TB_LL, B2_MODE_LL, sorted_ll, meta_ll));   // (a call's result counts as per-lane)
+                if (e == B2_ESC) e = b2_long_code((unsigned)v, B2_TB_LL, B2_MODE_LL, sorted_ll, meta_ll, lane);
                 if (e == B2_ESC) {
                     err = B2_E_SYMBOL;
                     break;
@@ -527,7 +563,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                     v >>= eb;
                     used += eb;
                     unsigned ed = b2_rfl(lut_d[(unsigned)v & ((1u << B2_TB_D) - 1)]);
-                    if (ed == B2_ESC) ed = b2_rfl(b2_long_code((unsigned)v, B2_TB_D, B2_MODE_DIST, sorted_d, meta_d));
+                    if (ed == B2_ESC) ed = b2_long_code((unsigned)v, B2_TB_D, B2_MODE_DIST, sorted_d, meta_d, lane);
                     if (ed == B2_ESC) {
                         err = B2_E_DIST;
                         break;
@@ -546,6 +582,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 if (stop == 2) break;
             }
             if (err != B2_OK) break;
+            B2_MARK(2);
             const unsigned ol = b2_sel(chain, olraw, 0u);           // off the chain: nothing
             const unsigned incl = b2_scan(ol);
             const unsigned tot = b2_rl(incl, 63);
@@ -555,6 +592,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 err = op + tot > isize ? B2_E_OVERRUN : B2_E_DIST;
                 break;
             }
+            B2_MARK(3);
 #ifndef B2_EXP_NOLIT   // B2_EXP_*: ablation switches (tools/build_variant.sh) behind the stage costs quoted in DESIGN.md 3.6
             if (ol == 1) dst[pos] = (unsigned char)litv;
 #endif
@@ -586,11 +624,14 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 unsigned char *const p_ = dst + pos;
                 const B2U128 v = *reinterpret_cast<const B2U128 *>(s_);
                 const unsigned tailw = reinterpret_cast<const B2U32 *>(s_ + mlen - 4)->v;
+                // every store unconditional: a dword the match does not reach is written as dword 0 once more, the tail always (it equals the
+                // last whole dword when the length is a multiple of four) — two selects per store instead of an exec-mask branch (three
+                // scalar instructions each, and the CU's one scalar unit is what this kernel runs out of first)
                 reinterpret_cast<B2U32 *>(p_)->v = v.w[0];
-                if (mlen >= 8) reinterpret_cast<B2U32 *>(p_ + 4)->v = v.w[1];
-                if (mlen >= 12) reinterpret_cast<B2U32 *>(p_ + 8)->v = v.w[2];
-                if (mlen >= 16) reinterpret_cast<B2U32 *>(p_ + 12)->v = v.w[3];
-                if (mlen & 3) reinterpret_cast<B2U32 *>(p_ + mlen - 4)->v = tailw;
+                reinterpret_cast<B2U32 *>(p_ + (mlen >= 8 ? 4u : 0u))->v = mlen >= 8 ? v.w[1] : v.w[0];
+                reinterpret_cast<B2U32 *>(p_ + (mlen >= 12 ? 8u : 0u))->v = mlen >= 12 ? v.w[2] : v.w[0];
+                reinterpret_cast<B2U32 *>(p_ + (mlen >= 16 ? 12u : 0u))->v = mlen >= 16 ? v.w[3] : v.w[0];
+                reinterpret_cast<B2U32 *>(p_ + mlen - 4)->v = tailw;
             }
 #endif
 #ifdef B2_STATS
@@ -614,21 +655,35 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 }
             }
 #endif
+#ifdef B2_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (the copies' stores are issued: charge their completion to the copies)
+            B2_MARK(4);
+#endif
 #if !B2_PIPE
             u64 mm = __ballot(copy && !par);
             while (mm) {                                            // the others in stream order (they may read each other's output)
                 const unsigned l = (unsigned)__builtin_ctzll(mm);
                 mm &= ~(1ull << l);
                 const unsigned len = b2_rl(mlen, l), dd = b2_rl(dist, l), p = b2_rl(pos, l), so = b2_rl(srco, l);
-                unsigned i = (unsigned)lane;
-                do {
-                    const unsigned j = dd >= len ? i : i % dd;      // a distance shorter than the match repeats its source
-                    if (i < len) dst[p + i] = dst[so + j];
-                    i += 64;
-                } while (i - (unsigned)lane < len);
+                if (dd >= len) {                                    // (uniform) source and destination do not overlap: a plain copy —
+                    for (unsigned i = (unsigned)lane; i < len; i += 64) dst[p + i] = dst[so + i];      // no per-lane division in the common case
+                } else {                                            // a distance shorter than the match repeats its source: byte i comes from i mod dd
+                    unsigned j = (unsigned)lane % dd;
+                    const unsigned step = 64u % dd;
+                    for (unsigned i = (unsigned)lane; i < len; i += 64) {
+                        dst[p + i] = dst[so + j];
+                        j += step;
+                        j -= j >= dd ? dd : 0u;
+                    }
+                }
             }
 #endif
             if (err != B2_OK) break;
+#ifdef B2_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            B2_MARK(5);
+            pf[8]++;
+#endif
             op += tot;
             bp += cur;
             if (bp > end_bit) {                                     // a valid block ends (EOB included) inside the payload
@@ -636,6 +691,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 break;
             }
             B2_ENSURE();
+            B2_MARK(6);
             if (err != B2_OK || stop == 2) break;
         }
 #if B2_PIPE
@@ -645,6 +701,11 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
     if (err == B2_OK && op != isize) err = B2_E_SIZE;
     if (err == B2_OK && bp > end_bit + 7) err = B2_E_INPUT;
     if (lane == 0) status[b] = err;
+#ifdef B2_PROF
+    B2_MARK(7);
+    if (lane == 0)
+        for (int k_ = 0; k_ < 9; k_++) atomicAdd(&b2_prof[k_], (unsigned long long)pf[k_]);
+#endif
     __builtin_amdgcn_wave_barrier();                          // (the next block's staging writes the ring this one may still be reading)
     }
 #undef B2_ENSURE
