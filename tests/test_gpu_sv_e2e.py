@@ -126,7 +126,8 @@ def _sv_rank(rank, world, port, q, argv, min_cut):
         tiddit_cluster.cluster_columns_device = spy
         cli.main(argv)
         q.put((rank, seen))
-        dist.destroy_process_group()
+        if dist.is_initialized():                  # (the CLI destroys the group it created)
+            dist.destroy_process_group()
     except BaseException:  # pragma: no cover
         import traceback
         q.put((rank, traceback.format_exc()))

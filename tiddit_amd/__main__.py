@@ -194,7 +194,8 @@ def run_sv(args, version):
         backend = os.environ.get("TIDDIT_DIST_BACKEND", "nccl")          # gloo: ranks sharing one GPU (tests)
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        if not dist.is_initialized():
+        own_group = not dist.is_initialized()
+        if own_group:
             dist.init_process_group(backend)
         rank = dist.get_rank()
     if rank == 0:
@@ -365,6 +366,9 @@ def run_sv(args, version):
             print("variant typing/filtering (tiddit_variant) is outside this build's scope; candidates written to {}.candidates.tab".format(prefix))
     if multi:
         dist.barrier()                                                   # every output file exists when any rank returns
+        if own_group:
+            # (a process that exits with its RCCL group alive can die in the group's watchdog thread while the HIP runtime unloads)
+            dist.destroy_process_group()
 
 
 def main(argv=None):
