@@ -84,7 +84,8 @@ extern "C" int tdt_debug_b2_stats(unsigned long long *out, int reset) {
 
 #ifdef B2_PROF   // measurement builds only (tools/inflate_prof.py): shader-clock cycles per phase of the window loop, summed over all waves
 __device__ unsigned long long b2_prof[16];    // 0 gather + LUT lookups, 1 per-lane lengths / distances, 2 chain walk (+ long codes), 3 prefix sum + checks,
-                                              // 4 literal store + own-lane copies (load, wait, stores), 5 replayed matches, 6 cursor + ring refill, 7 tables / headers, 8 windows
+                                              // 4 literal store + own-lane copies (load, wait, stores), 5 replayed matches, 6 cursor + ring refill, 7 tables / headers, 8 windows,
+                                              // 9 the hops of the chain walk alone (2 then holds the long-code path), 10 long codes resolved
 extern "C" int tdt_debug_b2_prof(unsigned long long *out, int reset) {
     if (reset) {
         unsigned long long z[16] = {0};
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
     unsigned err = B2_OK;
     unsigned op = 0;
 #ifdef B2_PROF
-    unsigned pf[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long pf_last = __builtin_readcyclecounter();
 #endif
 
@@ -535,6 +536,10 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                     asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(cur));      // chain |= 1 << cur in ONE scalar instruction (the scalar unit is shared by the CU's 32 waves)
                     cur = b2_rl(nxt, cur);
                 }
+#ifdef B2_PROF
+                B2_MARK(9);                                         // (the hops alone; what is left under mark 2 is the long-code path)
+                if (cur >= 128 && cur < 256) pf[10]++;
+#endif
                 if (cur >= 256) {
                     stop = 2;
                     cur -= 256;
@@ -620,18 +625,19 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             if (par && !wide)                                       // (a 3-byte match, or a source in the block's last bytes: plain byte copy)
                 for (unsigned k = 0; k < mlen; k++) dst[pos + k] = dst[srco + k];
             if (wide) {
-                const unsigned char *const s_ = dst + srco;
-                unsigned char *const p_ = dst + pos;
-                const B2U128 v = *reinterpret_cast<const B2U128 *>(s_);
-                const unsigned tailw = reinterpret_cast<const B2U32 *>(s_ + mlen - 4)->v;
+                // (every address is the block's base in a scalar pair + a 32-bit index in a vector register: formed as pointers first,
+                //  each store cost a 64-bit add and a zeroed high half on the vector unit, which is the busiest unit of this kernel)
+                const B2U128 v = *reinterpret_cast<const B2U128 *>(dst + srco);
+                const unsigned tailw = reinterpret_cast<const B2U32 *>(dst + (srco + mlen - 4u))->v;
                 // every store unconditional: a dword the match does not reach is written as dword 0 once more, the tail always (it equals the
                 // last whole dword when the length is a multiple of four) — two selects per store instead of an exec-mask branch (three
-                // scalar instructions each, and the CU's one scalar unit is what this kernel runs out of first)
-                reinterpret_cast<B2U32 *>(p_)->v = v.w[0];
-                reinterpret_cast<B2U32 *>(p_ + (mlen >= 8 ? 4u : 0u))->v = mlen >= 8 ? v.w[1] : v.w[0];
-                reinterpret_cast<B2U32 *>(p_ + (mlen >= 12 ? 8u : 0u))->v = mlen >= 12 ? v.w[2] : v.w[0];
-                reinterpret_cast<B2U32 *>(p_ + (mlen >= 16 ? 12u : 0u))->v = mlen >= 16 ? v.w[3] : v.w[0];
-                reinterpret_cast<B2U32 *>(p_ + mlen - 4)->v = tailw;
+                // scalar instructions each)
+                const bool g8 = mlen >= 8, g12 = mlen >= 12, g16 = mlen >= 16;
+                reinterpret_cast<B2U32 *>(dst + pos)->v = v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + (g8 ? 4u : 0u)))->v = g8 ? v.w[1] : v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + (g12 ? 8u : 0u)))->v = g12 ? v.w[2] : v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + (g16 ? 12u : 0u)))->v = g16 ? v.w[3] : v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + mlen - 4u))->v = tailw;
             }
 #endif
 #ifdef B2_STATS
@@ -704,7 +710,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
 #ifdef B2_PROF
     B2_MARK(7);
     if (lane == 0)
-        for (int k_ = 0; k_ < 9; k_++) atomicAdd(&b2_prof[k_], (unsigned long long)pf[k_]);
+        for (int k_ = 0; k_ < 12; k_++) atomicAdd(&b2_prof[k_], (unsigned long long)pf[k_]);
 #endif
     __builtin_amdgcn_wave_barrier();                          // (the next block's staging writes the ring this one may still be reading)
     }
