@@ -33,6 +33,9 @@
 #define B2_WAVES 4
 #endif
 #define B2_PARMAX 16                       // longest match a lane copies by itself (bytes); 32 with two loads was measured: slower
+#ifndef B2_BYTE_SPLIT
+#define B2_BYTE_SPLIT 0                    // 1: the byte path's loads before the wide path, its stores behind it (measurement variant)
+#endif
 #ifndef B2_PIPE
 #define B2_PIPE 0                          // 1: the copies pipelined over two windows (measured in round 4: 18.3 ms against 17.9, 22.4 against 21.7 —
 #endif                                     // the wait it moves is not what a window waits for; ten more live registers spill).  Kept as a variant.
@@ -622,8 +625,25 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 pd_tail = reinterpret_cast<const B2U32 *>(s_ + mlen - 4)->v;
             }
 #else
-            if (par && !wide)                                       // (a 3-byte match, or a source in the block's last bytes: plain byte copy)
-                for (unsigned k = 0; k < mlen; k++) dst[pos + k] = dst[srco + k];
+            // (a 3-byte match, or a source in the block's last bytes.  Its source lies before this window's output, so the three bytes every
+            //  match has are LOADED FIRST and stored together: one memory round trip; written as a plain byte loop the compiler, which
+            //  cannot see that, waited for every byte before storing it — three round trips for the commonest match of zlib level 1)
+#if B2_BYTE_SPLIT
+            unsigned char by0 = 0, by1 = 0, by2 = 0;
+            if (par && !wide) {                                     // the loads ride with the wide path's below: one wait serves both
+                by0 = dst[srco];
+                by1 = dst[srco + 1];
+                by2 = dst[srco + 2];
+            }
+#else
+            if (par && !wide) {
+                const unsigned char by0 = dst[srco], by1 = dst[srco + 1], by2 = dst[srco + 2];
+                dst[pos] = by0;
+                dst[pos + 1] = by1;
+                dst[pos + 2] = by2;
+                for (unsigned k = 3; k < mlen; k++) dst[pos + k] = dst[srco + k];
+            }
+#endif
             if (wide) {
                 // (every address is the block's base in a scalar pair + a 32-bit index in a vector register: formed as pointers first,
                 //  each store cost a 64-bit add and a zeroed high half on the vector unit, which is the busiest unit of this kernel)
@@ -639,6 +659,14 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 reinterpret_cast<B2U32 *>(dst + (pos + (g16 ? 12u : 0u)))->v = g16 ? v.w[3] : v.w[0];
                 reinterpret_cast<B2U32 *>(dst + (pos + mlen - 4u))->v = tailw;
             }
+#if B2_BYTE_SPLIT
+            if (par && !wide) {
+                dst[pos] = by0;
+                dst[pos + 1] = by1;
+                dst[pos + 2] = by2;
+                for (unsigned k = 3; k < mlen; k++) dst[pos + k] = dst[srco + k];
+            }
+#endif
 #endif
 #ifdef B2_STATS
             {
