@@ -33,8 +33,11 @@
 #define B2_WAVES 4
 #endif
 #define B2_PARMAX 16                       // longest match a lane copies by itself (bytes); 32 with two loads was measured: slower
-#ifndef B2_BYTE_SPLIT
-#define B2_BYTE_SPLIT 0                    // 1: the byte path's loads before the wide path, its stores behind it (measurement variant)
+#ifndef B2_PHASED
+#define B2_PHASED 0                        // 1: all loads of the window's independent copies first, one wait, then all their stores (measured in round 4:
+#endif                                     // 15.0 ms against 14.75 at level 6, 16.9 against 17.4 at level 1 — kept as a variant; B2_EARLYM adds the window's
+#ifndef B2_EARLYM                          // first long independent match to the phase: 15.05 / 17.25)
+#define B2_EARLYM 0
 #endif
 #ifndef B2_PIPE
 #define B2_PIPE 0                          // 1: the copies pipelined over two windows (measured in round 4: 18.3 ms against 17.9, 22.4 against 21.7 —
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 break;
             }
             B2_MARK(3);
-#ifndef B2_EXP_NOLIT   // B2_EXP_*: ablation switches (tools/build_variant.sh) behind the stage costs quoted in DESIGN.md 3.6
+#if !defined(B2_EXP_NOLIT) && !(B2_PHASED && !B2_PIPE)   // B2_EXP_*: ablation switches (tools/build_variant.sh) behind the stage costs quoted in DESIGN.md 3.6
             if (ol == 1) dst[pos] = (unsigned char)litv;
 #endif
             const unsigned srco = pos - dist;                       // first source byte of this lane's match
@@ -625,17 +628,63 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 pd_tail = reinterpret_cast<const B2U32 *>(s_ + mlen - 4)->v;
             }
 #else
-            // (a 3-byte match, or a source in the block's last bytes.  Its source lies before this window's output, so the three bytes every
-            //  match has are LOADED FIRST and stored together: one memory round trip; written as a plain byte loop the compiler, which
-            //  cannot see that, waited for every byte before storing it — three round trips for the commonest match of zlib level 1)
-#if B2_BYTE_SPLIT
+#if B2_PHASED
+            // Every copy whose source lies before this window's output is independent of the window's other copies, so ALL their loads are
+            // issued first and all their stores afterwards: the byte path (3-byte matches, block ends), the wide path, and the window's
+            // first match that is too long for its own lane but reads only earlier windows' output (three replayed matches in four) — ONE
+            // memory round trip where the three paths took one each, one after the other.  (The order matters for a second reason: a
+            // wave's memory operations return in order, so a wait for a load that has younger STORES behind it in the queue — the
+            // compiler cannot count them across exec regions and waits for everything — waits for their acknowledgements too, which is
+            // what made "loads early, stores late" for one path alone slower, twice.)
+            const bool bytep = par && !wide;
             unsigned char by0 = 0, by1 = 0, by2 = 0;
-            if (par && !wide) {                                     // the loads ride with the wide path's below: one wait serves both
+            B2U128 v = {{0, 0, 0, 0}};
+            unsigned tailw = 0;
+            unsigned e_len = 0, e_p = 0, e_lane = 0;
+            unsigned char e_v = 0;
+            if (bytep) {
                 by0 = dst[srco];
                 by1 = dst[srco + 1];
                 by2 = dst[srco + 2];
             }
+            if (wide) {
+                v = *reinterpret_cast<const B2U128 *>(dst + srco);
+                tailw = reinterpret_cast<const B2U32 *>(dst + (srco + mlen - 4u))->v;
+            }
+            {
+                const u64 mi = B2_EARLYM ? __ballot(copy && !par && srco + mlen <= op && mlen <= 64u) : 0ull;
+                if (mi) {
+                    e_lane = (unsigned)__builtin_ctzll(mi);
+                    e_len = b2_rl(mlen, e_lane);
+                    e_p = b2_rl(pos, e_lane);
+                    const unsigned so = b2_rl(srco, e_lane);
+                    if ((unsigned)lane < e_len) e_v = dst[so + (unsigned)lane];
+                }
+            }
+            // every load of the phase is back before the first store goes out (the builtin, not inline asm: the compiler's own wait-count
+            // pass sees it and places no further waits between the stores — placed by itself, each path's wait for ITS loads counts the
+            // stores of the path in front of it as well)
+            __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0), nothing else; unconditional, or the pass cannot rely on it
+            if (ol == 1) dst[pos] = (unsigned char)litv;            // (the literals too go out behind the wait, not in front of the loads)
+            if (e_len && (unsigned)lane < e_len) dst[e_p + (unsigned)lane] = e_v;
+            if (bytep) {
+                dst[pos] = by0;
+                dst[pos + 1] = by1;
+                dst[pos + 2] = by2;
+                for (unsigned k = 3; k < mlen; k++) dst[pos + k] = dst[srco + k];
+            }
+            if (wide) {
+                const bool g8 = mlen >= 8, g12 = mlen >= 12, g16 = mlen >= 16;
+                reinterpret_cast<B2U32 *>(dst + pos)->v = v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + (g8 ? 4u : 0u)))->v = g8 ? v.w[1] : v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + (g12 ? 8u : 0u)))->v = g12 ? v.w[2] : v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + (g16 ? 12u : 0u)))->v = g16 ? v.w[3] : v.w[0];
+                reinterpret_cast<B2U32 *>(dst + (pos + mlen - 4u))->v = tailw;
+            }
 #else
+            // (a 3-byte match, or a source in the block's last bytes.  Its source lies before this window's output, so the three bytes every
+            //  match has are LOADED FIRST and stored together: one memory round trip; written as a plain byte loop the compiler, which
+            //  cannot see that, waited for every byte before storing it — three round trips for the commonest match of zlib level 1)
             if (par && !wide) {
                 const unsigned char by0 = dst[srco], by1 = dst[srco + 1], by2 = dst[srco + 2];
                 dst[pos] = by0;
@@ -643,7 +692,6 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 dst[pos + 2] = by2;
                 for (unsigned k = 3; k < mlen; k++) dst[pos + k] = dst[srco + k];
             }
-#endif
             if (wide) {
                 // (every address is the block's base in a scalar pair + a 32-bit index in a vector register: formed as pointers first,
                 //  each store cost a 64-bit add and a zeroed high half on the vector unit, which is the busiest unit of this kernel)
@@ -658,13 +706,6 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 reinterpret_cast<B2U32 *>(dst + (pos + (g12 ? 8u : 0u)))->v = g12 ? v.w[2] : v.w[0];
                 reinterpret_cast<B2U32 *>(dst + (pos + (g16 ? 12u : 0u)))->v = g16 ? v.w[3] : v.w[0];
                 reinterpret_cast<B2U32 *>(dst + (pos + mlen - 4u))->v = tailw;
-            }
-#if B2_BYTE_SPLIT
-            if (par && !wide) {
-                dst[pos] = by0;
-                dst[pos + 1] = by1;
-                dst[pos + 2] = by2;
-                for (unsigned k = 3; k < mlen; k++) dst[pos + k] = dst[srco + k];
             }
 #endif
 #endif
@@ -695,6 +736,9 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
 #endif
 #if !B2_PIPE
             u64 mm = __ballot(copy && !par);
+#if B2_PHASED
+            if (e_len) mm &= ~(1ull << e_lane);
+#endif
             while (mm) {                                            // the others in stream order (they may read each other's output)
                 const unsigned l = (unsigned)__builtin_ctzll(mm);
                 mm &= ~(1ull << l);
