@@ -896,7 +896,7 @@ def main():
         ing = result.get("ingest")
         if ing:
             sections["ingest"] = {"ms": ing.get("ms_per_step"), "records_per_sec": ing.get("value"), "bam_MB_per_sec": ing.get("bam_MB_per_sec"),
-                                  "bound": "the CU's scalar unit and the round trips of the inflate kernel's match copies (DESIGN.md 3.6), not HBM: no fraction of the HBM roofline is claimed"}
+                                  "bound": "the inflate kernel's chain of dependent instructions per 64-bit window (vector ~60 %, scalar ~50 % busy, a wave issues one instruction per ~16 cycles) and the round trips of its match copies (DESIGN.md 3.6), not HBM: no fraction of the HBM roofline is claimed"}
             if "binning" in ing:
                 result["roofline"]["binning_ms_per_600M_reads"] = ing["binning"]["binning_ms_per_600M_reads"]
         sv = result.get("sv_e2e")
