@@ -6,19 +6,24 @@
 //   1. bgzf_inflate / bgzf_crc32 (tdt_inflate.hip) inflate the blocks behind the carried partial record;
 //   2. bam_find_records: the block_size chain is a serial pointer chase, so the stream is cut into 16 KiB segments and
 //      ONE LANE per segment looks for the first offset that passes the record sanity checks and whose chain runs
-//      cleanly to the end of the segment (what BAM split guessers do), recording first / exit / count;
+//      cleanly to the end of the segment (what BAM split guessers do), recording first / exit / count and, per record of that
+//      chain, where it starts (a 16-bit offset in the segment's row of `rel`);
 //   3. the host walks the segment table from the known first record: the chain is accepted only if every segment's
 //      guess equals the exit of its predecessor — then it is exactly the sequential decode, not a heuristic.  On any
 //      disagreement the batch is copied back once and the chain is chased serially on the host (still exact);
-//   4. bam_decode_fields: one lane per accepted segment re-walks its records and writes the same thirteen arrays as
-//      tdt_bam_decode (bam_endpos for `end`, the SA:Z offset, first/last CIGAR op, ...).
+//   4. bam_decode_fields: one WAVE per accepted segment, one lane per record (its start comes from `rel`), writes the same
+//      thirteen arrays as tdt_bam_decode (bam_endpos for `end`, the SA:Z offset, first/last CIGAR op, ...); after a host
+//      chase bam_decode_fields_serial walks the records of a segment with one lane instead.
 #include "tdt_common.h"
 #include <mutex>
 
 #include <algorithm>
 
+#ifndef ING_SEG
 #define ING_SEG 16384
+#endif
 #define ING_NONE 0xffffffffu
+#define ING_MAXREC ((ING_SEG + 35) / 36)      // a record is at least 4 + 32 bytes long
 
 __device__ __forceinline__ unsigned ld_u32(const unsigned char *p) {
     unsigned v;
@@ -69,7 +74,7 @@ __device__ __forceinline__ int rec_check(const unsigned char *buf, long long p, 
 // stops at the first such offset (reported as the segment's exit) and they are not counted.
 __global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__restrict__ buf, long long T, long long s0, long long limit,
                                                        int n_ref, int nseg, unsigned *__restrict__ first, unsigned *__restrict__ exitp,
-                                                       unsigned *__restrict__ count) {
+                                                       unsigned *__restrict__ count, unsigned short *__restrict__ rel) {
     const int g = blockIdx.x * 64 + threadIdx.x;
     if (g >= nseg) return;
     const long long lo = (long long)g * ING_SEG;
@@ -97,7 +102,9 @@ __global__ __launch_bounds__(64) void bam_find_records(const unsigned char *__re
         if (!done) {                                            // (B) its chain to the end of the segment
             long long q = p;
             unsigned n = 0;
-            while (rc == 0 && q < stop) {
+            unsigned short *const row = rel + (size_t)g * ING_MAXREC;   // where the records of this segment start, relative to it: the decode
+            while (rc == 0 && q < stop) {                               // kernel then takes a record per LANE (a later chain overwrites a failed one)
+                row[n] = (unsigned short)(q - lo);
                 q += 4 + (long long)bs;
                 n++;
                 if (q >= T) break;                              // the batch ends exactly on a record boundary
@@ -160,63 +167,81 @@ __device__ __forceinline__ long long aux_value_size(unsigned char t, const unsig
     }
 }
 
-__global__ __launch_bounds__(64) void bam_decode_fields(const unsigned char *__restrict__ buf, long long T, int nseg,
-                                                        const unsigned *__restrict__ first, const unsigned *__restrict__ base,
-                                                        const unsigned *__restrict__ count, IngestOut O) {
+// one record at byte p of the batch -> element i of the field arrays; returns its block_size
+__device__ __forceinline__ unsigned bam_decode_one(const unsigned char *__restrict__ buf, long long p, size_t i, const IngestOut &O) {
+    const unsigned bs = ld_u32(buf + p);
+    const unsigned char *r = buf + p + 4;
+    const int pos = (int)ld_u32(r + 4), lseq = (int)ld_u32(r + 16);
+    const unsigned l_name = r[8], n_cig = ld_u16(r + 12), fl = ld_u16(r + 14);
+    const unsigned char *cig = r + 32 + l_name;
+    long long rlen = 0;
+    for (unsigned j = 0; j < n_cig; j++) {
+        const unsigned cw = ld_u32(cig + 4 * j), op = cw & 0xf;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cw >> 4;   // M D N = X consume the reference
+    }
+    if ((fl & 0x4) || rlen == 0) rlen = 1;                                          // bam_endpos
+    const int tid_ = (int)ld_u32(r);
+    O.tid[i] = tid_;
+    O.pos[i] = pos;
+    O.end[i] = (int)(pos + rlen);
+    O.mapq[i] = r[9];
+    O.flag[i] = (uint16_t)fl;
+    if (O.bin.z) {
+        const int nb_ = (tid_ >= 0 && tid_ < O.bin.n_contigs) ? O.bin.d_nbins[tid_] : 0;          // unplaced reads: no bins (never pushed)
+        O.packed[i] = cov_bin_record(pos, (int)(pos + rlen), r[9], fl, nb_, O.bin.z, O.bin.magic, O.bin.shift, O.bin.mode1 != 0);
+    } else {
+        O.packed[i] = cov_pack_record(pos, (int)(pos + rlen), r[9], fl);
+    }
+    O.mate_tid[i] = (int)ld_u32(r + 20);
+    O.mate_pos[i] = (int)ld_u32(r + 24);
+    O.tlen[i] = (int)ld_u32(r + 28);
+    O.l_seq[i] = lseq;
+    O.cigar_first[i] = n_cig ? ld_u32(cig) : 0xffffffffu;
+    O.cigar_last[i] = n_cig ? ld_u32(cig + 4 * (n_cig - 1)) : 0xffffffffu;
+    O.rec_off[i] = (uint64_t)p;
+    long long found = -1;                                                           // SA:Z value offset (tiddit_signal.pyx:199)
+    const unsigned char *a = r + 32 + l_name + 4 * n_cig + ((size_t)lseq + 1) / 2 + (size_t)lseq, *aend = r + bs;
+    while (a + 3 <= aend) {
+        const unsigned char t = a[2];
+        const long long sz = aux_value_size(t, a + 3, aend);
+        if (sz < 0 || a + 3 + sz > aend) break;
+        if (a[0] == 'S' && a[1] == 'A' && t == 'Z') {
+            found = (long long)((a + 3) - buf);
+            break;
+        }
+        a += 3 + sz;
+    }
+    O.sa_off[i] = found;
+    return bs;
+}
+
+// A WAVE per segment, a LANE per record: bam_find_records left the start of every record of its segment's chain in `rel`, so the
+// records of a segment are decoded side by side and their fields leave in coalesced stores.  (One lane per segment walking its ~55
+// records — rounds 2-4 — was 1 250 waves of 64 dependent chains for a 1.3-GB batch: a sixth of the chip's wave slots, every load a
+// round trip nobody hid.)
+__global__ __launch_bounds__(256) void bam_decode_fields(const unsigned char *__restrict__ buf, long long T, int nseg,
+                                                         const unsigned *__restrict__ base, const unsigned *__restrict__ count,
+                                                         const unsigned short *__restrict__ rel, IngestOut O) {
+    const int g = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (g >= nseg) return;
+    const unsigned n = count[g], b = base[g];
+    if (b == ING_NONE || n == 0) return;
+    const long long lo = (long long)g * ING_SEG;
+    const unsigned short *const row = rel + (size_t)g * ING_MAXREC;
+    for (unsigned k = (unsigned)lane; k < n; k += 64) (void)bam_decode_one(buf, lo + row[k], (size_t)b + k, O);
+}
+
+// The same with a lane per segment walking its records: after a host chase (the segment table rebuilt on the host, no `rel` rows)
+__global__ __launch_bounds__(64) void bam_decode_fields_serial(const unsigned char *__restrict__ buf, long long T, int nseg,
+                                                               const unsigned *__restrict__ first, const unsigned *__restrict__ base,
+                                                               const unsigned *__restrict__ count, IngestOut O) {
     const int g = blockIdx.x * 64 + threadIdx.x;
     if (g >= nseg) return;
     const unsigned n = count[g];
     if (base[g] == ING_NONE || n == 0) return;
     long long p = first[g];
     size_t i = base[g];
-    for (unsigned k = 0; k < n; k++, i++) {
-        const unsigned bs = ld_u32(buf + p);
-        const unsigned char *r = buf + p + 4;
-        const int pos = (int)ld_u32(r + 4), lseq = (int)ld_u32(r + 16);
-        const unsigned l_name = r[8], n_cig = ld_u16(r + 12), fl = ld_u16(r + 14);
-        const unsigned char *cig = r + 32 + l_name;
-        long long rlen = 0;
-        for (unsigned j = 0; j < n_cig; j++) {
-            const unsigned cw = ld_u32(cig + 4 * j), op = cw & 0xf;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cw >> 4;   // M D N = X consume the reference
-        }
-        if ((fl & 0x4) || rlen == 0) rlen = 1;                                          // bam_endpos
-        O.tid[i] = (int)ld_u32(r);
-        O.pos[i] = pos;
-        O.end[i] = (int)(pos + rlen);
-        O.mapq[i] = r[9];
-        O.flag[i] = (uint16_t)fl;
-        {
-            const int tid_ = (int)ld_u32(r);
-            if (O.bin.z) {
-                const int nb_ = (tid_ >= 0 && tid_ < O.bin.n_contigs) ? O.bin.d_nbins[tid_] : 0;          // unplaced reads: no bins (never pushed)
-                O.packed[i] = cov_bin_record(pos, (int)(pos + rlen), r[9], fl, nb_, O.bin.z, O.bin.magic, O.bin.shift, O.bin.mode1 != 0);
-            } else {
-                O.packed[i] = cov_pack_record(pos, (int)(pos + rlen), r[9], fl);
-            }
-        }
-        O.mate_tid[i] = (int)ld_u32(r + 20);
-        O.mate_pos[i] = (int)ld_u32(r + 24);
-        O.tlen[i] = (int)ld_u32(r + 28);
-        O.l_seq[i] = lseq;
-        O.cigar_first[i] = n_cig ? ld_u32(cig) : 0xffffffffu;
-        O.cigar_last[i] = n_cig ? ld_u32(cig + 4 * (n_cig - 1)) : 0xffffffffu;
-        O.rec_off[i] = (uint64_t)p;
-        long long found = -1;                                                           // SA:Z value offset (tiddit_signal.pyx:199)
-        const unsigned char *a = r + 32 + l_name + 4 * n_cig + ((size_t)lseq + 1) / 2 + (size_t)lseq, *aend = r + bs;
-        while (a + 3 <= aend) {
-            const unsigned char t = a[2];
-            const long long sz = aux_value_size(t, a + 3, aend);
-            if (sz < 0 || a + 3 + sz > aend) break;
-            if (a[0] == 'S' && a[1] == 'A' && t == 'Z') {
-                found = (long long)((a + 3) - buf);
-                break;
-            }
-            a += 3 + sz;
-        }
-        O.sa_off[i] = found;
-        p += 4 + (long long)bs;
-    }
+    for (unsigned k = 0; k < n; k++, i++) p += 4 + (long long)bam_decode_one(buf, p, i, O);
 }
 
 // positions where tid changes (i = 0 included): the per-contig runs of a coordinate-sorted batch
@@ -626,8 +651,10 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     // ---- find the records: per-segment guesses on the device, chain check on the host
     const int nseg = (int)((T + ING_SEG - 1) / ING_SEG);
     const size_t segb = ((size_t)nseg * 4 + 255) & ~(size_t)255;
-    rc = ing_grow(g, g->seg, 4 * segb);
+    const size_t relb = ((size_t)nseg * ING_MAXREC * 2 + 255) & ~(size_t)255;
+    rc = ing_grow(g, g->seg, 4 * segb + relb);
     if (rc) return rc;
+    unsigned short *d_rel = (unsigned short *)((char *)g->seg.p + 4 * segb);
     unsigned *d_first = (unsigned *)g->seg.p, *d_exit = (unsigned *)((char *)g->seg.p + segb), *d_count = (unsigned *)((char *)g->seg.p + 2 * segb),
              *d_base = (unsigned *)((char *)g->seg.p + 3 * segb);
     if (g->pin.cap < 4 * segb + 65536) {
@@ -638,7 +665,7 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     unsigned *h_first = (unsigned *)g->pin.p, *h_exit = (unsigned *)((char *)g->pin.p + segb), *h_count = (unsigned *)((char *)g->pin.p + 2 * segb),
              *h_base = (unsigned *)((char *)g->pin.p + 3 * segb);
     hipLaunchKernelGGL(bam_find_records, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, unknown_start ? -1ll : (long long)skip,
-                       (long long)limit, g->n_ref, nseg, d_first, d_exit, d_count);
+                       (long long)limit, g->n_ref, nseg, d_first, d_exit, d_count, d_rel);
     TDT_CHECK_LAUNCH();
     if (g->tev[3]) (void)hipEventRecord(g->tev[3], st);
     TDT_HIP(hipMemcpyAsync(h_first, d_first, 3 * segb, hipMemcpyDeviceToHost, st));
@@ -764,7 +791,10 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         }
         g->t_chain_ms = ing_now_ms() - t_chain0;
         if (g->tev[4]) (void)hipEventRecord(g->tev[4], st);
-        hipLaunchKernelGGL(bam_decode_fields, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, nseg, d_first, d_base, d_count, O);
+        if (table_dirty)
+            hipLaunchKernelGGL(bam_decode_fields_serial, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, nseg, d_first, d_base, d_count, O);
+        else
+            hipLaunchKernelGGL(bam_decode_fields, dim3((nseg + 3) / 4), dim3(256), 0, st, d_out, (long long)T, nseg, d_base, d_count, d_rel, O);
         TDT_CHECK_LAUNCH();
         if (g->tev[5]) (void)hipEventRecord(g->tev[5], st);
         g->t_have_decode = g->tev[4] && g->tev[5];
