@@ -464,8 +464,14 @@ struct __attribute__((packed, aligned(1))) BzU128 {
     unsigned w[4];
 };
 
+// x^(8 * 1024 * 2^k) mod P for k = 0..5: the tree's multipliers for the segment length of every full BGZF block (65 280 bytes -> 1 024 per lane),
+// computed once on the host (tdt_bz_launch) instead of by 17 squarings in every wave
+struct CrcPowers {
+    unsigned pw[6];
+};
+
 __global__ __launch_bounds__(256) void bgzf_crc32(const BzDesc *__restrict__ blocks, int nblocks, const unsigned char *__restrict__ out,
-                                                  unsigned *__restrict__ status) {
+                                                  unsigned *__restrict__ status, CrcPowers P1024) {
     __shared__ unsigned table[4][256];                        // slicing-by-4: table[k][b] = CRC of byte b followed by k zero bytes
     {
         unsigned c = threadIdx.x;
@@ -491,17 +497,39 @@ __global__ __launch_bounds__(256) void bgzf_crc32(const BzDesc *__restrict__ blo
     const unsigned char *p = out + D.out_off;
     unsigned c = 0;
     const long long v0 = (long long)lane * seg - pad;
-    for (unsigned i = 0; i < seg; i += 16) {
+#define CRC_WORD(w_)                                                                                                  \
+    do {                                                                                                              \
+        c ^= (w_);                                                                                                    \
+        c = table[3][c & 0xff] ^ table[2][(c >> 8) & 0xff] ^ table[1][(c >> 16) & 0xff] ^ table[0][c >> 24];          \
+    } while (0)
+    unsigned i = 0;
+    while (i < seg) {
         const long long j = v0 + i;
-        if (j + 16 <= 0) continue;
+        if (j + 16 <= 0) {
+            i += 16;
+            continue;
+        }
+        if (j >= 0 && i + 128 <= seg) {
+            // 128 bytes at a time, the eight loads issued TOGETHER: the lanes of a wave read 1 KB apart, so one load instruction touches
+            // 64 cache lines and uses 16 bytes of each; with a load per 16 bytes processed the line had left the L1 (32 waves x 8 KB of
+            // such lines per CU) before the lane came back for its next 16 bytes, and every line crossed the L2 eight times
+            if (j == 0) c = 0xffffffffu;
+            BzU128 v[8];
+#pragma unroll
+            for (int g = 0; g < 8; g++) v[g] = *(const BzU128 *)(p + j + 16 * g);
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) CRC_WORD(v[g].w[k]);
+            }
+            i += 128;
+            continue;
+        }
         if (j >= 0) {
             if (j == 0) c = 0xffffffffu;
             const BzU128 v = *(const BzU128 *)(p + j);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                c ^= v.w[k];
-                c = table[3][c & 0xff] ^ table[2][(c >> 8) & 0xff] ^ table[1][(c >> 16) & 0xff] ^ table[0][c >> 24];
-            }
+            for (int k = 0; k < 4; k++) CRC_WORD(v.w[k]);
         } else {                                               // the group that contains data byte 0
             for (int k = 0; k < 16; k++) {
                 const long long jj = j + k;
@@ -510,22 +538,57 @@ __global__ __launch_bounds__(256) void bgzf_crc32(const BzDesc *__restrict__ blo
                 c = table[0][(c ^ p[jj]) & 0xff] ^ (c >> 8);
             }
         }
+        i += 16;
     }
-    // x^(8*seg) by square-and-multiply, then the tree: crc(A||B) = crc(A) * x^(8|B|) + crc(B)
-    unsigned pw = 0x80000000u, sq = 0x00800000u;              // 1 and x^8
-    for (unsigned e = seg; e; e >>= 1) {
-        if (e & 1) pw = crc_mulmod(pw, sq);
-        sq = crc_mulmod(sq, sq);
+#undef CRC_WORD
+    // the tree: crc(A||B) = crc(A) * x^(8|B|) + crc(B); its multipliers x^(8*seg*2^k) come from the host for seg = 1024 and from
+    // square-and-multiply otherwise (a file's last block, short blocks)
+    unsigned pw = 0x80000000u;
+    if (seg != 1024u) {
+        unsigned sq = 0x00800000u;                            // 1 and x^8
+        for (unsigned e = seg; e; e >>= 1) {
+            if (e & 1) pw = crc_mulmod(pw, sq);
+            sq = crc_mulmod(sq, sq);
+        }
     }
-    for (int d = 1; d < 64; d <<= 1) {
+    int k = 0;
+    for (int d = 1; d < 64; d <<= 1, k++) {
         const unsigned right = (unsigned)__shfl_down((int)c, d);
-        if ((lane & (2 * d - 1)) == 0) c = crc_mulmod(c, pw) ^ right;
-        pw = crc_mulmod(pw, pw);
+        const unsigned m = seg == 1024u ? P1024.pw[k] : pw;
+        if ((lane & (2 * d - 1)) == 0) c = crc_mulmod(c, m) ^ right;
+        if (seg != 1024u) pw = crc_mulmod(pw, pw);
     }
     if (lane == 0) {
         const unsigned crc = n ? ~c : 0u;
         if (crc != D.crc) status[b] = BZ_E_CRC;
     }
+}
+
+static unsigned crc_mulmod_host(unsigned a, unsigned b) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) {
+        r ^= (b & 0x80000000u) ? a : 0;
+        a = (a >> 1) ^ ((a & 1) ? 0xEDB88320u : 0);
+        b <<= 1;
+    }
+    return r;
+}
+
+static CrcPowers crc_powers_1024() {
+    static const CrcPowers P = [] {
+        CrcPowers q;
+        unsigned pw = 0x80000000u, sq = 0x00800000u;          // 1 and x^8
+        for (unsigned e = 1024; e; e >>= 1) {
+            if (e & 1) pw = crc_mulmod_host(pw, sq);
+            sq = crc_mulmod_host(sq, sq);
+        }
+        for (int k = 0; k < 6; k++) {
+            q.pw[k] = pw;
+            pw = crc_mulmod_host(pw, pw);
+        }
+        return q;
+    }();
+    return P;
 }
 
 __global__ void bgzf_status_reduce(const unsigned *__restrict__ status, int nblocks, unsigned *__restrict__ summary) {
@@ -558,7 +621,7 @@ int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blo
     else tdt_bz_launch_lanes(st, ctx->num_cu, d_comp, d_blocks, nblocks, d_out, d_status, d_summary + 2);
     TDT_CHECK_LAUNCH();
     if (check_crc) {
-        hipLaunchKernelGGL(bgzf_crc32, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, st, d_blocks, (int)nblocks, d_out, d_status);
+        hipLaunchKernelGGL(bgzf_crc32, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, st, d_blocks, (int)nblocks, d_out, d_status, crc_powers_1024());
         TDT_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(bgzf_status_reduce, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, d_status, (int)nblocks, d_summary);
