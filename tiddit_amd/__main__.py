@@ -287,6 +287,9 @@ def run_sv(args, version):
         else:
             start_gc()
     t = time.time()
+    # one process: the blocks of discordants / splits / clips are placed by a thread while the job goes on (tiddit_cluster takes the tables
+    # over, not the files); finish_writes() below waits for it.  TIDDIT_BACKGROUND_WRITES=0: written before tiddit_signal.main returns.
+    tiddit_signal.BACKGROUND_WRITES = (not multi) and os.environ.get("TIDDIT_BACKGROUND_WRITES", "1") != "0"
     with stage("tiddit: signal extraction + coverage"):
         signal_main = tiddit_signal.main_sharded if multi else tiddit_signal.main
         try:
@@ -295,6 +298,7 @@ def run_sv(args, version):
         finally:
             if gc_job is not None and gc_mode == "after":
                 tiddit_signal.AFTER_SCAN.remove(start_gc)
+            tiddit_signal.BACKGROUND_WRITES = False
             if gc_job is not None and sys.exc_info()[0] is not None and "thread" in gc_job:
                 gc_job["thread"].join()          # (the scan failed: no helper thread outlives the error)
     if rank == 0:
@@ -350,6 +354,11 @@ def run_sv(args, version):
         t = time.time()
         write_candidates(prefix + ".candidates.tab", contigs, sv_clusters)
         T["candidates table"] = time.time() - t
+    tiddit_signal.finish_writes()                                        # the signal files are complete from here on
+    if tiddit_signal.WRITE_SECONDS:
+        T["signal files placed (writer thread, beside ploidy and clustering)"] = tiddit_signal.WRITE_SECONDS["writer thread"]
+        T["  waited for the writer thread"] = tiddit_signal.WRITE_SECONDS["waited for it"]
+    if rank == 0:
         # Variant typing / filtering / the VCF (tiddit_variant.pyx, tiddit_vcf_header.py) are outside this build's scope.  When the
         # reference package itself is importable (it needs pysam) the candidates are handed to it, as the reference's driver does
         # (__main__.py:193-207), so that a full installation still ends with {prefix}.vcf.

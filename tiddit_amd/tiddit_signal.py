@@ -20,6 +20,7 @@ import concurrent.futures
 import itertools
 import os
 import re
+import threading
 import time
 
 import numpy
@@ -538,38 +539,88 @@ def _write_tables(scanned, merged, chromosomes, prefix, sample_id, group=None, o
     base = numpy.zeros((3, n), dtype=numpy.int64)                                                # where a contig's block starts in the three big files
     for w in range(3):
         base[w][kept] = numpy.cumsum(total[w][kept]) - total[w][kept]
-    for w, path in ((0, d_path), (1, s_path)):
-        todo = [t for t in kept if mine[w][t]]
-        if todo:
-            fd = os.open(path, os.O_WRONLY)
-            try:
-                for t in todo:
-                    merged.pwrite(w, t, fd, int(base[w][t] + before[rank][w][t]))
-            finally:
-                os.close(fd)
-    todo = [t for t in kept if mine[2][t]]
-    if todo:
-        fd_all = os.open(all_path, os.O_WRONLY)
-        try:
-            for t in todo:
-                scanned.pwrite(2, t, fd_all, int(base[2][t] + before[rank][2][t]))
-                fd = os.open(clip_path(t), os.O_WRONLY)
+
+    def place_blocks():
+        for w, path in ((0, d_path), (1, s_path)):
+            todo = [t for t in kept if mine[w][t]]
+            if todo:
+                fd = os.open(path, os.O_WRONLY)
                 try:
-                    scanned.pwrite(2, t, fd, int(before[rank][2][t]))
+                    for t in todo:
+                        merged.pwrite(w, t, fd, int(base[w][t] + before[rank][w][t]))
                 finally:
                     os.close(fd)
-        finally:
-            os.close(fd_all)
+        todo = [t for t in kept if mine[2][t]]
+        if todo:
+            fd_all = os.open(all_path, os.O_WRONLY)
+            try:
+                for t in todo:
+                    scanned.pwrite(2, t, fd_all, int(base[2][t] + before[rank][2][t]))
+                    fd = os.open(clip_path(t), os.O_WRONLY)
+                    try:
+                        scanned.pwrite(2, t, fd, int(before[rank][2][t]))
+                    finally:
+                        os.close(fd)
+            finally:
+                os.close(fd_all)
+
+    key = (os.path.abspath(d_path), os.path.abspath(s_path))
+    _forget_tables()
+    if BACKGROUND_WRITES and world == 1:
+        # The one-process `tiddit --sv` sets this: the text is formatted (merged.sizes above), the files exist at their final size, and
+        # the blocks are placed by a thread (pwrite in the library, no GIL) while the job goes on to the ploidy table and the clustering
+        # — which takes the TABLES over, not the files.  finish_writes() waits for it; until then the entry is marked pending.
+        job = {"seconds": 0.0}
+
+        def run():
+            t0 = time.time()
+            try:
+                place_blocks()
+                if scanned is not merged:
+                    scanned.close()
+            except BaseException as e:                          # re-raised by finish_writes()
+                job["error"] = e
+            job["seconds"] = time.time() - t0
+
+        job["thread"] = threading.Thread(target=run, name="tiddit-signal-writer")
+        WRITTEN_TABLES[key] = (None, None, merged, owner, job)
+        job["thread"].start()
+        return
+    place_blocks()
     if world > 1:
         dist.barrier(group)                                      # the files are complete when any rank returns
-    _forget_tables()
-    WRITTEN_TABLES[(os.path.abspath(d_path), os.path.abspath(s_path))] = (_file_stamp(d_path), _file_stamp(s_path), merged, owner)
+    WRITTEN_TABLES[key] = (_file_stamp(d_path), _file_stamp(s_path), merged, owner, None)
     if scanned is not merged:
         scanned.close()
 
 
+BACKGROUND_WRITES = False   # see _write_tables; a library caller of main() gets complete files on return
+WRITE_SECONDS = {}          # what the last finish_writes() found: seconds the writer thread ran, seconds the caller waited for it
+
+
+def finish_writes():
+    """Wait for the writer thread of a main() that ran with BACKGROUND_WRITES (a no-op otherwise): the three files are complete on
+    return, and the tables' hand-over entry carries their stamps like any other."""
+    WRITE_SECONDS.clear()
+    for key, ent in list(WRITTEN_TABLES.items()):
+        job = ent[4]
+        if job is None:
+            continue
+        t0 = time.time()
+        job["thread"].join()
+        WRITE_SECONDS["writer thread"] = job["seconds"]
+        WRITE_SECONDS["waited for it"] = time.time() - t0
+        if "error" in job:
+            ent[2].close()
+            del WRITTEN_TABLES[key]
+            raise job["error"]
+        WRITTEN_TABLES[key] = (_file_stamp(key[0]), _file_stamp(key[1]), ent[2], ent[3], None)
+
+
 def _forget_tables():
     for ent in WRITTEN_TABLES.values():
+        if ent[4] is not None:
+            ent[4]["thread"].join()
         ent[2].close()
     WRITTEN_TABLES.clear()
 
@@ -585,6 +636,8 @@ def written_tables(disc_path, split_path):
     ent = WRITTEN_TABLES.get((os.path.abspath(disc_path), os.path.abspath(split_path)))
     if ent is None:
         return None
+    if ent[4] is not None:
+        return ent[2]               # (this process is placing the blocks of exactly these tables right now: BACKGROUND_WRITES)
     try:
         if _file_stamp(disc_path) != ent[0] or _file_stamp(split_path) != ent[1]:
             return None
