@@ -53,6 +53,41 @@ def test_written_tables_are_forgotten_when_a_file_changes(tmp_path):
     assert u._h is None
 
 
+def test_background_writes_hand_the_tables_over_at_once_and_finish_with_the_same_files(tmp_path):
+    """what the one-process command line does (tiddit_signal.BACKGROUND_WRITES): the blocks are placed by a thread, the tables are handed
+    to tiddit_cluster while it runs, finish_writes() leaves the files of the synchronous writer and an entry with stamps"""
+    kept = [n for n, ln in CONTIGS if ln >= MIN_CONTIG]
+    t = small_tables()
+    t.add_clips(0, b">clipA|chr1|1000\nACGT\n")
+    ref_prefix = str(tmp_path / "sync")
+    tiddit_signal._write_tables(t, t, kept, ref_prefix, "S")
+    want = {k: open(ref_prefix + "_tiddit/" + k, "rb").read() for k in ("discordants_S.tab", "splits_S.tab", "clips_S.fa", "clips/chr1.fa")}
+    assert want["clips_S.fa"] == want["clips/chr1.fa"] and want["clips_S.fa"]
+    u = small_tables()
+    u.add_clips(0, b">clipA|chr1|1000\nACGT\n")
+    prefix = str(tmp_path / "bg")
+    paths = (prefix + "_tiddit/discordants_S.tab", prefix + "_tiddit/splits_S.tab")
+    tiddit_signal.BACKGROUND_WRITES = True
+    try:
+        tiddit_signal._write_tables(u, u, kept, prefix, "S")
+    finally:
+        tiddit_signal.BACKGROUND_WRITES = False
+    assert tiddit_signal.written_tables(*paths) is u                    # handed over while (or after) the thread runs, without a stamp
+    assert tiddit_cluster._handed_over(prefix, NAMES, dict(CONTIGS), ["S"], MIN_CONTIG, True)[0] is u
+    tiddit_signal.finish_writes()
+    assert set(tiddit_signal.WRITE_SECONDS) == {"writer thread", "waited for it"}
+    got = {k: open(prefix + "_tiddit/" + k, "rb").read() for k in want}
+    assert got == want
+    assert tiddit_signal.written_tables(*paths) is u and tiddit_signal.WRITTEN_TABLES[tuple(__import__("os").path.abspath(p) for p in paths)][0] is not None
+    with open(paths[0], "a") as f:                                      # stamped now: an edit drops the hand-over as ever
+        f.write("x\n")
+    assert tiddit_signal.written_tables(*paths) is None
+    tiddit_signal.finish_writes()                                       # nothing pending: a no-op
+    assert tiddit_signal.WRITE_SECONDS == {}
+    tiddit_signal._forget_tables()
+    assert u._h is None
+
+
 def test_quiet_gc_leaves_the_collector_as_it_found_it_and_only_the_cli_freezes():
     import gc
     from tiddit_amd.hostutil import quiet_gc, thaw
