@@ -69,6 +69,9 @@ typedef unsigned long long u64;
 struct __attribute__((packed, aligned(1))) B2U32 {
     unsigned v;
 };
+struct __attribute__((packed, aligned(1))) B2U16 {
+    unsigned short v;
+};
 struct __attribute__((packed, aligned(1))) B2U128 {
     unsigned w[4];
 };
@@ -686,10 +689,11 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             //  match has are LOADED FIRST and stored together: one memory round trip; written as a plain byte loop the compiler, which
             //  cannot see that, waited for every byte before storing it — three round trips for the commonest match of zlib level 1)
             if (par && !wide) {
-                const unsigned char by0 = dst[srco], by1 = dst[srco + 1], by2 = dst[srco + 2];
-                dst[pos] = by0;
-                dst[pos + 1] = by1;
-                dst[pos + 2] = by2;
+                // (ONE dword load — srco + 4 <= pos + 1 <= isize: the match's own three output bytes lie behind its source — and a 16-bit +
+                //  an 8-bit store: three memory instructions instead of six)
+                const unsigned w3 = reinterpret_cast<const B2U32 *>(dst + srco)->v;
+                reinterpret_cast<B2U16 *>(dst + pos)->v = (unsigned short)w3;
+                dst[pos + 2] = (unsigned char)(w3 >> 16);
                 for (unsigned k = 3; k < mlen; k++) dst[pos + k] = dst[srco + k];
             }
             if (wide) {
