@@ -266,3 +266,18 @@ def test_library_statistics_on_the_device_equal_the_host_loop(run):
             if n == P["n_reads_stats"]:
                 for k, v in fx["library"].items():
                     assert res[1][k] == v, (k, res[1][k], v)
+
+
+def test_switches_off_leave_the_same_files(run, tmp_path, monkeypatch):
+    """the one-process job places the signal files from a writer thread beside the ploidy table and the clustering (the default the `run`
+    fixture used); switched off — files written before tiddit_signal.main returns — every output is the same bytes"""
+    from tiddit_amd import __main__ as cli
+    fx, bam, fa, contigs, out = run
+    if fx["params"]["total_mb"] > 30:
+        pytest.skip("the 3-Mb and 24-Mb files are enough for this comparison")
+    monkeypatch.setenv("TIDDIT_BACKGROUND_WRITES", "0")
+    out2 = str(tmp_path / "seq")
+    cli.main(["--sv", "--bam", bam, "--ref", fa, "-o", out2, "--skip_assembly", "-s", str(fx["params"]["n_reads_stats"])])
+    for r in ["_tiddit/discordants_WGS.tab", "_tiddit/splits_WGS.tab", "_tiddit/clips_WGS.fa", ".ploidies.tab", ".candidates.tab"]:
+        a, b = open(out + r, "rb").read(), open(out2 + r, "rb").read()
+        assert a == b and a, r
