@@ -94,7 +94,7 @@ extern "C" int tdt_debug_b2_stats(unsigned long long *out, int reset) {
 #ifdef B2_PROF   // measurement builds only (tools/inflate_prof.py): shader-clock cycles per phase of the window loop, summed over all waves
 __device__ unsigned long long b2_prof[16];    // 0 gather + LUT lookups, 1 per-lane lengths / distances, 2 chain walk (+ long codes), 3 prefix sum + checks,
                                               // 4 literal store + own-lane copies (load, wait, stores), 5 replayed matches, 6 cursor + ring refill, 7 tables / headers, 8 windows,
-                                              // 9 the hops of the chain walk alone (2 then holds the long-code path), 10 long codes resolved
+                                              // 9 the hops of the chain walk alone (2 then holds the long-code path), 10 long codes resolved, 11 DEFLATE block header + tables (7 then: between windows)
 extern "C" int tdt_debug_b2_prof(unsigned long long *out, int reset) {
     if (reset) {
         unsigned long long z[16] = {0};
@@ -502,6 +502,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             break;
         }
         // ---- the symbols of this block, a window of 64 bit offsets at a time
+        B2_MARK(11);                                                  // (block header + code lengths + the two table builds)
         for (;;) {
             // every lane: the symbol that would start at bit bp + lane
             // (three dwords from the ring; every field but the distance's extra bits lies in the first 32 stream bits:

@@ -19,9 +19,11 @@ v = list(st)
 names = ["gather of the stream bits + the two LUT lookups (three dependent LDS round trips)", "per-lane lengths / distances (VALU)", "chain walk (scalar) + long codes",
          "prefix sum, positions, checks", "literal store + own-lane copies (load, wait, stores complete)", "replayed matches (load, store, complete)",
          "cursor, ring refill", "tables, block headers, between windows"]
-tot = float(sum(v[:8]) + v[9]) or 1.0
+tot = float(sum(v[:8]) + v[9] + v[11]) or 1.0
 print("rc", rc, "windows", v[8], "cycles per window %.0f (shader clock)" % (tot / max(1, v[8])))
 for n, c in zip(names, v[:8]):
     print("  %5.1f %%  %7.0f cycles/window  %s" % (100.0 * c / tot, c / max(1, v[8]), n))
 print("  %5.1f %%  %7.0f cycles/window  the hops of the chain walk alone (the line 'chain walk' above then holds only the long-code path: %.3f long codes per window, %.0f cycles each)"
       % (100.0 * v[9] / tot, v[9] / max(1, v[8]), v[10] / max(1, v[8]), v[2] / max(1, v[10])))
+print("  %5.1f %%  %7.0f cycles/window  DEFLATE block headers, code lengths and the two table builds (the line 'tables, block headers, between windows' above then holds only the rest)"
+      % (100.0 * v[11] / tot, v[11] / max(1, v[8])))
