@@ -19,6 +19,7 @@ buckets are split over the ranks, one BAM is read as byte-range shards with one 
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -293,6 +294,28 @@ def main():
     elif traffic is not None:
         traffic *= total_reads / float(job_reads)
 
+    # the yardstick beside the data sheet's peak: a plain streaming read of as many bytes as the headline launch's algorithmic traffic, from
+    # one buffer, one launch (tdt_calib_stream_read: four 16-byte loads in flight per lane, nothing written)
+    stream_read = None
+    try:
+        cal = torch.empty(int(alg_bytes_launch) // 8, dtype=torch.int64, device=dev)
+        cal.random_(0, 1 << 40)
+        torch.cuda.synchronize()
+        sweep = []
+        for wpc, blocked in ((2, 0), (3, 0), (8, 0), (8, 1), (64, 1)):
+            cb, cm = ctypes.c_double(0), ctypes.c_double(0)
+            _native.check(ctx.lib.tdt_calib_stream_read(ctx.handle, cal.data_ptr(), cal.numel() * 8, 10, wpc, blocked, ctypes.byref(cb), ctypes.byref(cm)))
+            sweep.append({"workgroups_per_cu": wpc, "walk": "blocked" if blocked else "grid-stride", "best_ms": cb.value, "mean_ms": cm.value,
+                          "GB_per_s": cal.numel() * 8 / (cm.value * 1e-3) / 1e9})
+        top = max(sweep, key=lambda r_: r_["GB_per_s"])
+        stream_read = {"bytes": cal.numel() * 8, "GB_per_s": top["GB_per_s"], "frac_of_peak": top["GB_per_s"] / HBM_PEAK_GBS, "best_config": top, "sweep": sweep,
+                       "note": "tdt_calib_stream_read: a read-only kernel (four 16-byte loads in flight per lane, nothing written) over one buffer of the "
+                               "headline launch's algorithmic bytes, mean of 10 launches per configuration, the best of five: what streaming this device's "
+                               "HBM reaches in practice; 'frac_of_stream_read' = achieved / this"}
+        del cal
+    except Exception as e:                                    # (a measurement aid: its absence never fails the bench)
+        stream_read = {"error": str(e)}
+
     result = {
         "metric": "cov bins/sec, 30x WGS synthetic (signals clustered/sec: see 'dbscan')",
         "value": job_bins / (t_cov / args.steps),
@@ -318,6 +341,8 @@ def main():
                      "frac_traffic": None if traffic is None else traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": kern_ms,
                      "median_launch_ms": kern_all[len(kern_all) // 2], "min_launch_ms": kern_all[0],
                      "algorithmic_bytes_per_launch": alg_bytes_launch,
+                     "stream_read": stream_read,
+                     "frac_of_stream_read": (achieved / stream_read["GB_per_s"]) if stream_read and "GB_per_s" in stream_read else None,
                      "bytes_model": "8 B/read (binned record) + 8 B/bin: what this launch's input layout holds",
                      "pack_binned_from_four_arrays_ms": bin_pack_ms,
                      "from_four_arrays_incl_pack": {"ms": bin_pack_ms + kern_ms, "frac": alg_bytes_4 / ((bin_pack_ms + kern_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -473,7 +498,6 @@ def main():
 
     # ---------------------------------------------------------------- clustering (configs[2]): one chr pair, one GPU
     if not args.no_dbscan and world == 1:
-        import ctypes
         n = args.dbscan_n
         pts = synth.gen_points(n, seed=synth.SEED)
         x = torch.from_numpy(pts[:, 0].astype(np.uint32).view(np.int32)).to(dev)
@@ -890,7 +914,9 @@ def main():
                 return None
             tr = rf.get("traffic")
             alg = rf.get("algorithmic_bytes_per_launch", rf.get("algorithmic_bytes_per_pass"))
-            return {"ms": rf.get(ms_key), "frac": rf.get("frac"), "traffic_ratio": None if tr is None or not alg else tr / alg}
+            sr = (result["roofline"].get("stream_read") or {}).get("GB_per_s")
+            return {"ms": rf.get(ms_key), "frac": rf.get("frac"), "traffic_ratio": None if tr is None or not alg else tr / alg,
+                    "frac_of_stream_read": None if not sr or rf.get("achieved") is None else rf["achieved"] / sr}
         sections = {"coverage_sv": compact(result.get("coverage_sv"), "avg_launch_ms"), "dbscan": compact(result.get("dbscan"), "avg_pass_ms"),
                     "gc": compact(result.get("gc"), "avg_launch_ms")}
         ing = result.get("ingest")
@@ -907,6 +933,8 @@ def main():
             f4 = result["four_array_layout"]
             result["roofline"]["contract"] = {"layout": "SURVEY 8(d): start i32, end i32, mapq u8, flag u16 - all of update_coverage in ONE launch, no packing pass",
                                               "ms": f4["avg_launch_ms"], "frac": f4["frac"], "frac_survey_8d_12B_per_read": f4["frac_survey_8d_12B_per_read"],
+                                              "frac_of_stream_read": (f4["frac"] * HBM_PEAK_GBS / result["roofline"]["stream_read"]["GB_per_s"])
+                                              if (result["roofline"].get("stream_read") or {}).get("GB_per_s") else None,
                                               "bins_per_sec": result["config"]["bins"] / (f4["avg_launch_ms"] * 1e-3)}
         print(json.dumps(result))
     if use_dist:
@@ -933,7 +961,6 @@ def shared_step(bucket_sizes, cluster_local, use_dist, group=None):
 
 
 def dbscan_shared(args, ctx, stream, dev, rank, world, use_dist, barrier, wire=None, rank_max=lambda x: x):
-    import ctypes
     import torch
     import torch.distributed as dist
     from tiddit_amd import _native, dist as tdist, synth

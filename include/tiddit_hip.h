@@ -405,6 +405,13 @@ int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle);
 int tdt_ingest_release(tdt_retained *handle);
 int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+/* Measurement aid (bench.py, tools/calib_stream.py): what a plain streaming read of `bytes` of device memory reaches on this device — every
+ * lane four 16-byte loads in flight, nothing written; `workgroups_per_cu` workgroups of 256 threads per CU walk the buffer grid-stride
+ * (blocked = 0) or each its own contiguous share (blocked = 1: the way cov_accumulate's workgroups own 256 KB of reads each); best and mean
+ * launch time over `reps` launches after one untimed pass (HIP events on the context's stream).  The roofline object of the bench quotes
+ * the best of a small sweep beside the data sheet's 8 TB/s. */
+int tdt_calib_stream_read(tdt_ctx *ctx, const void *d_buf, size_t bytes, int reps, int workgroups_per_cu, int blocked, double *best_ms,
+                          double *mean_ms);
 
 /* ---- alignment-record decode (host) ---------------------------------------------------------- *
  * Replaces the per-read pysam attribute access that feeds the path (read.reference_start,

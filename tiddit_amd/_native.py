@@ -115,6 +115,7 @@ SYMBOLS = {
     "tdt_ingest_arrays": (_i, [_P, _PP, ctypes.POINTER(_sz)]),
     "tdt_ingest_packed": (_i, [_P, _PP]),
     "tdt_ingest_bin_for": (_i, [_P, _P, ctypes.POINTER(_i)]),
+    "tdt_calib_stream_read": (_i, [_P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "tdt_ingest_timing": (_i, [_P, _P]),
     "tdt_ingest_retain": (_i, [_P, _PP]),
     "tdt_ingest_release": (_i, [_P]),

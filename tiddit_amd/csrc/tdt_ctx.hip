@@ -127,3 +127,70 @@ int tdt_pinned(tdt_ctx *c, int slot, size_t bytes, void **out) {
     return TDT_OK;
 }
 
+// ---- what a plain streaming read reaches on this device: the yardstick beside the 8 TB/s of the data sheet (bench.py's roofline object
+// quotes both).  Every lane keeps four 16-byte loads in flight over a grid-stride walk; the XOR of what it read decides a store that
+// never happens for real data, which is all that keeps the loads alive.
+// blocked = 1: workgroup b streams its own contiguous 1/gridDim.x of the buffer (4 KB per step); 0: grid-stride
+__global__ __launch_bounds__(256) void calib_stream_read(const uint4 *__restrict__ p, size_t n16, unsigned *__restrict__ sink, int blocked) {
+    size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (blocked) {
+        const size_t chunk = (n16 / gridDim.x) & ~(size_t)1023;       // whole 16-KB steps; the remainder is left unread (a measurement aid)
+        p += (size_t)blockIdx.x * chunk;
+        n16 = chunk;
+        stride = 256;
+        i = threadIdx.x;
+    }
+    uint4 a = {0, 0, 0, 0};
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+        a.x ^= v0.x ^ v1.x ^ v2.x ^ v3.x;
+        a.y ^= v0.y ^ v1.y ^ v2.y ^ v3.y;
+        a.z ^= v0.z ^ v1.z ^ v2.z ^ v3.z;
+        a.w ^= v0.w ^ v1.w ^ v2.w ^ v3.w;
+    }
+    for (; i < n16; i += stride) {
+        const uint4 v = p[i];
+        a.x ^= v.x;
+        a.y ^= v.y;
+        a.z ^= v.z;
+        a.w ^= v.w;
+    }
+    const unsigned x = a.x ^ a.y ^ a.z ^ a.w;
+    if (x == 0x9e3779b9u && a.x == 0x7f4a7c15u && a.y == 0xf39cc060u) sink[0] = x;
+}
+
+extern "C" int tdt_calib_stream_read(tdt_ctx *c, const void *d_buf, size_t bytes, int reps, int workgroups_per_cu, int blocked, double *best_ms,
+                                     double *mean_ms) {
+    if (!c || !d_buf || bytes < (1u << 20) || reps < 1 || workgroups_per_cu < 1 || workgroups_per_cu > 256 || !best_ms || !mean_ms ||
+        ((uintptr_t)d_buf & 15)) {
+        tdt_set_error("tdt_calib_stream_read: bad argument (a 16-byte aligned device buffer of at least 1 MiB, reps >= 1, 1..256 workgroups per CU)");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->device));
+    void *sink = nullptr;
+    int rc = tdt_scratch(c, 27, 256, &sink);
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    TDT_HIP(hipEventCreate(&e0));
+    TDT_HIP(hipEventCreate(&e1));
+    const unsigned grid = (unsigned)c->num_cu * (unsigned)workgroups_per_cu;      // (8 workgroups of four waves = eight waves per SIMD)
+    double best = 1e30, sum = 0;
+    for (int r = -1; r < reps; r++) {                              // (one untimed pass first)
+        TDT_HIP(hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL(calib_stream_read, dim3(grid), dim3(256), 0, c->stream, (const uint4 *)d_buf, bytes / 16, (unsigned *)sink, blocked ? 1 : 0);
+        TDT_HIP(hipEventRecord(e1, c->stream));
+        TDT_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        TDT_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 0) {
+            best = ms < best ? ms : best;
+            sum += ms;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *best_ms = best;
+    *mean_ms = sum / reps;
+    return TDT_OK;
+}
