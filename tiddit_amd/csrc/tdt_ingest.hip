@@ -4,10 +4,11 @@
 // The reference iterates `samfile.fetch(until_eof=True)` and reads one attribute at a time (__main__.py:229-240,
 // tiddit_signal.pyx:169-221); csrc/tdt_bam.hip does that walk in host C.  Here, per batch of blocks:
 //   1. bgzf_inflate / bgzf_crc32 (tdt_inflate.hip) inflate the blocks behind the carried partial record;
-//   2. bam_find_records: the block_size chain is a serial pointer chase, so the stream is cut into 16 KiB segments and
-//      ONE LANE per segment looks for the first offset that passes the record sanity checks and whose chain runs
-//      cleanly to the end of the segment (what BAM split guessers do), recording first / exit / count and, per record of that
-//      chain, where it starts (a 16-bit offset in the segment's row of `rel`);
+//   2. bam_find_first + bam_find_records: the block_size chain is a serial pointer chase, so the stream is cut into 16 KiB segments;
+//      a WAVE per segment tests its offsets 64 at a time for the first that passes the record sanity checks, then ONE LANE per
+//      segment follows the chain from there (trying the next candidate if it breaks) until it runs cleanly to the end of the
+//      segment (what BAM split guessers do), recording first / exit / count and, per record of that chain, where it starts (a
+//      16-bit offset in the segment's row of `rel`);
 //   3. the host walks the segment table from the known first record: the chain is accepted only if every segment's
 //      guess equals the exit of its predecessor — then it is exactly the sequential decode, not a heuristic.  On any
 //      disagreement the batch is copied back once and the chain is chased serially on the host (still exact);
