@@ -33,6 +33,9 @@
 #define B2_WAVES 4
 #endif
 #define B2_PARMAX 16                       // longest match a lane copies by itself (bytes); 32 with two loads was measured: slower
+#ifndef B2_HOP2
+#define B2_HOP2 1
+#endif
 #ifndef B2_PHASED
 #define B2_PHASED 0                        // 1: all loads of the window's independent copies first, one wait, then all their stores (measured in round 4:
 #endif                                     // 15.0 ms against 14.75 at level 6, 16.9 against 17.4 at level 1 — kept as a variant; B2_EARLYM adds the window's
@@ -518,6 +521,15 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             // next[i] = i + bits consumed; a chain ends at a value >= 64: [128, 256) = a code the tables do not resolve (the literal /
             // length code itself or the distance code behind it), >= 256 = end of block (256 + the bit after it)
             const unsigned nxt = (unsigned)lane + step1 + (is_len ? B2_STEP(e2) : 0u);
+#if B2_HOP2
+            // TWO symbols per hop of the chain walk: every lane also learns where the symbol BEHIND its own would end (one LDS permute:
+            // lane i reads next[next[i]]), and the walk reads both with one v_readlane — the scalar / vector hand-over, half of a hop's
+            // ≈ 185 cycles, is paid once per two symbols.  m1 = the lane one symbol ahead, 64 when that hop leaves the window;
+            // n2 = where the walk stands after two symbols (the exit value of whichever hop leaves the window first).
+            const unsigned m1 = nxt < 64u ? nxt : 64u;
+            const unsigned n2r = (unsigned)__builtin_amdgcn_ds_bpermute((int)(m1 << 2), (int)nxt);   // (m1 = 64 reads lane 0: not used)
+            const unsigned pack2 = m1 | ((nxt < 64u ? n2r : nxt) << 8);
+#endif
 #ifdef B2_PROF
             asm volatile("" :: "v"(nxt));
             B2_MARK(0);
@@ -543,8 +555,15 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             unsigned stop = 0;                                      // 2 = end of block
             for (;;) {
                 while (cur < 64) {
+#if B2_HOP2
+                    const unsigned p2 = b2_rl(pack2, cur);
+                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(cur));
+                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p2));       // bits 5:0 = m1 & 63: the next symbol's lane, or lane 0 — always on the
+                    cur = p2 >> 8;                                             // chain — when that hop leaves the window
+#else
                     asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(cur));      // chain |= 1 << cur in ONE scalar instruction (the scalar unit is shared by the CU's 32 waves)
                     cur = b2_rl(nxt, cur);
+#endif
                 }
 #ifdef B2_PROF
                 B2_MARK(9);                                         // (the hops alone; what is left under mark 2 is the long-code path)
