@@ -145,10 +145,33 @@ class SelectedReads:
 
     def __init__(self, ctx, meta, raw_end, raw):
         self.ctx, self.meta, self.raw_end, self.raw = ctx, meta, raw_end, raw
-        self.raw_bytes = raw.tobytes()                  # the selected records are ~1.5 % of the batch: RecordView slices this copy
         self.tid, self.pos, self.end, self.flag, self.mate_tid, self.action = (meta[k] for k in ("tid", "pos", "end", "flag", "mate_tid", "action"))
-        self.rec_off = numpy.concatenate([[0], raw_end[:-1]]).astype(numpy.uint64) if len(raw_end) else numpy.zeros(0, dtype=numpy.uint64)
-        self.sa_off = numpy.where(meta["sa_rel"] >= 0, self.rec_off.astype(numpy.int64) + meta["sa_rel"], -1)
+
+    # What only the per-record view needs (RecordView: the literal SA_analysis of an unusual tag, worker()'s row lists) is made when it
+    # is first asked for — the scan itself hands meta / raw_end / raw to the native tables as they are, and a bytes copy of every
+    # batch's selected records (tens of MB) sat on the scanning thread's path for nothing.
+    @property
+    def raw_bytes(self):
+        v = self.__dict__.get("_raw_bytes")
+        if v is None:
+            v = self.__dict__["_raw_bytes"] = self.raw.tobytes()      # RecordView slices this copy
+        return v
+
+    @property
+    def rec_off(self):
+        v = self.__dict__.get("_rec_off")
+        if v is None:
+            raw_end = self.raw_end
+            v = numpy.concatenate([[0], raw_end[:-1]]).astype(numpy.uint64) if len(raw_end) else numpy.zeros(0, dtype=numpy.uint64)
+            self.__dict__["_rec_off"] = v
+        return v
+
+    @property
+    def sa_off(self):
+        v = self.__dict__.get("_sa_off")
+        if v is None:
+            v = self.__dict__["_sa_off"] = numpy.where(self.meta["sa_rel"] >= 0, self.rec_off.astype(numpy.int64) + self.meta["sa_rel"], -1)
+        return v
 
     def __len__(self):
         return len(self.meta)
@@ -206,16 +229,31 @@ def split_rows_native(sel, which4, names, min_q, splits, lib=None):
             splits[chrom].append([chrom, sa_chr, qname, sp, bool(rev), ssp, bool(sam), rs, re_, gs, ge])
 
 
-def _device_scan(batch, contig_ok, min_q, max_ins, min_anchor_len, min_clip_len, ctx=None):
+_SEL_POOL = None            # pinned host buffers the scan loop's selected reads arrive in (three rotating sets: see _device_scan)
+
+
+def _device_scan(batch, contig_ok, min_q, max_ins, min_anchor_len, min_clip_len, ctx=None, slot=None):
+    """slot = 0 / 1 / 2: the three result arrays are views of PINNED buffers of that rotating set (the device-to-host copies are DMA
+    transfers, not staged through the runtime's bounce buffers) and stay valid until the set is used again — the scan loop, whose row
+    thread is one batch behind, passes batch number mod 3.  None: fresh numpy arrays."""
+    global _SEL_POOL
     ctx = ctx or _native.default_context()
     ok = numpy.ascontiguousarray(contig_ok, dtype=numpy.uint8)
     table = (ctypes.c_void_p * 14)(*[batch.dev[k] or None for k in _FIELD_ORDER])
     n_sel, raw_bytes = ctypes.c_size_t(0), ctypes.c_size_t(0)
     _native.check(ctx.lib.tdt_signal_scan(ctx.handle, table, len(batch), _native.ptr(ok), len(ok), int(min_q), int(max_ins), int(min_anchor_len),
                                           int(min_clip_len), ctypes.byref(n_sel), ctypes.byref(raw_bytes)))
-    meta = numpy.empty(n_sel.value, dtype=_META)
-    raw_end = numpy.empty(n_sel.value, dtype=numpy.uint32)
-    raw = numpy.empty(raw_bytes.value, dtype=numpy.uint8)
+    if slot is None:
+        meta = numpy.empty(n_sel.value, dtype=_META)
+        raw_end = numpy.empty(n_sel.value, dtype=numpy.uint32)
+        raw = numpy.empty(raw_bytes.value, dtype=numpy.uint8)
+    else:
+        if _SEL_POOL is None:
+            from .hostutil import PinnedPool
+            _SEL_POOL = PinnedPool()
+        meta = _SEL_POOL.take("meta%d" % slot, n_sel.value, _META)
+        raw_end = _SEL_POOL.take("end%d" % slot, n_sel.value, numpy.uint32)
+        raw = _SEL_POOL.take("raw%d" % slot, raw_bytes.value, numpy.uint8)
     if n_sel.value:
         _native.check(ctx.lib.tdt_signal_scan_result(ctx.handle, _native.ptr(meta), _native.ptr(raw_end), _native.ptr(raw)))
     return SelectedReads(ctx, meta, raw_end, raw)
@@ -306,6 +344,7 @@ def _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_le
 
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
     pending = None
+    n_batches = 0
     t0 = time.time()
 
     def all_batches():
@@ -327,7 +366,12 @@ def _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_le
                 t3 = time.time()
                 T["coverage push"] += t3 - t1
                 # the per-read chain of worker (:171-221) on the device; only the selected reads come back (fields + raw records)
-                sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
+                if os.environ.get("TIDDIT_SCAN_RESULT_PINNED", "1") != "0":
+                    sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len, slot=n_batches % 3)
+                else:                                           # (as before round 4's last step: pageable arrays, the per-record copies made at once)
+                    sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
+                    sel.raw_bytes, sel.sa_off
+                n_batches += 1
                 T["predicates + gather of the selected reads (device)"] += time.time() - t3
                 if pending is not None:
                     pending.result()                            # batches enter the tables in file order, one batch behind the device
