@@ -512,6 +512,8 @@ class DeviceBamReader:
         _native.check(self.ctx.lib.tdt_ingest_create(self.ctx.handle, len(self.references), ctypes.byref(h)))
         self._h = h
         self.host_chases = 0
+        self.reader_seconds = {"read": 0.0, "block scan": 0.0, "block table + copy issue": 0.0, "waited for the consumer": 0.0, "spans": 0,
+                               "consumer waited for a span": 0.0}
         import os
         import threading
         self._stop = threading.Event()
@@ -584,6 +586,7 @@ class DeviceBamReader:
                 k, carry = 0, np.zeros(0, dtype=np.uint8)
                 eof = False
                 read_ms, got = 0.0, 0
+                RS = self.reader_seconds                           # where the reader thread's time goes, summed over the spans
                 while True:
                     buf = bufs[k % 4]
                     have = len(carry)
@@ -607,20 +610,29 @@ class DeviceBamReader:
                         t_rd = time.perf_counter()
                         got = sum(pool.map(rd, range(0, want, piece)))
                         read_ms = 1e3 * (time.perf_counter() - t_rd)
+                        RS["read"] += read_ms * 1e-3
                         fo += got
                         have += got
                         eof = fo >= fsize
                     if have == 0:
                         break
+                    t_sc = time.perf_counter()
                     nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
                     _native.check(lib.tdt_bgzf_scan(_native.ptr(buf), have, 3 << 30, ctypes.byref(nb), ctypes.byref(consumed), ctypes.byref(produced)))
                     if nb.value == 0:
                         raise ValueError("truncated BGZF block at end of file" if eof else "BGZF block larger than the read window")
                     carry = buf[consumed.value:have].copy()
+                    t_pf = time.perf_counter()
+                    RS["block scan"] += t_pf - t_sc
                     # the PCIe copy of this span starts now, on the copy stream, behind whatever the device is doing for the span before it
                     # (the push of exactly this (pointer, length) then finds it on the device)
                     _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(buf), consumed.value))
-                    if not put((buf, consumed.value, fo - have, read_ms if not eof or got else 0.0)):
+                    t_put = time.perf_counter()
+                    RS["block table + copy issue"] += t_put - t_pf
+                    ok_put = put((buf, consumed.value, fo - have, read_ms if not eof or got else 0.0))
+                    RS["waited for the consumer"] += time.perf_counter() - t_put
+                    RS["spans"] += 1
+                    if not ok_put:
                         return
                     k += 1
                 put(None)
@@ -688,6 +700,7 @@ class DeviceBamReader:
             t_wait = time.perf_counter()
             cur = spans.next() if pending is False else pending
             wait_ms = 1e3 * (time.perf_counter() - t_wait)
+            self.reader_seconds["consumer waited for a span"] += wait_ms * 1e-3
             if cur is None:
                 break
             buf, consumed, abs0, read_ms = cur

@@ -437,6 +437,13 @@ def _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_le
         pool.shutdown(wait=True)                              # (also on an error: no row thread outlives the scan)
     if shard is not None:
         LAST_SEAM.update(first_off=reader.first_off, next_off=reader.next_off, empty=reader.first_off is None)
+    if getattr(reader, "reader_seconds", None):
+        READER_SECONDS.clear()
+        READER_SECONDS.update(reader.reader_seconds)             # (the statistics pass's share included when its reader was carried over)
+        if getattr(reader, "timings", None):                     # TIDDIT_INGEST_TIMING=1: the pushes' own stage times, summed
+            for k_ in ("h2d_ms", "inflate_crc_ms", "find_records_ms", "chain_check_ms", "decode_ms", "push_wall_ms", "block_table_ms"):
+                READER_SECONDS["push: " + k_[:-3] + " (s)"] = sum(t_[k_] for t_ in reader.timings) * 1e-3
+            READER_SECONDS["pushes"] = len(reader.timings)
     reader.close()
     chromosomes = [n for n, ok in zip(names, big) if ok]
     if reduce_bins is None:
@@ -471,6 +478,7 @@ STAGE_SECONDS = {}          # wall seconds of the last main(), stage by stage
 SCAN_SECONDS = {}           # ... and of the last scan pass, by what the host waited for
 LAST_SEAM = {}              # seam offsets of the last sharded scan pass (dist.check_seams)
 AFTER_SCAN = []             # callables main() invokes once the file has been scanned, before the tables are written (host-only work from there on)
+READER_SECONDS = {}         # the reader thread of the last scan: seconds reading, scanning BGZF headers, building tables, waiting — and the consumer's waits
 WRITTEN_TABLES = {}         # (discordants path, splits path) -> stamps + the native tables the last main() wrote them from (tiddit_cluster takes them over)
 
 

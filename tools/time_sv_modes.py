@@ -29,5 +29,8 @@ for rep in range(-1, reps):                       # rep -1: the file's first rea
             "(first pass) " if rep < 0 else "", switch, v, rep, wall, T["library statistics"], T["signal extraction + coverage"],
             T.get("  scan (ingest, coverage, predicates, signal tables)", 0), T.get("    ingest (inflate + decode, device)", 0),
             T["GC bins"], T["ploidy (masked medians)"], T["clustering"]), flush=True)
+        from tiddit_amd import tiddit_signal
+        if tiddit_signal.READER_SECONDS:
+            print("      reader thread:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in tiddit_signal.READER_SECONDS.items()}, flush=True)
         if rep < 0:
             break
