@@ -563,7 +563,10 @@ class DeviceBamReader:
         if span_pool is None:
             from .hostutil import PinnedPool
             span_pool = PinnedPool()
-        bufs = [span_pool.take("span%d" % i, chunk + (2 << 20), np.uint8) for i in range(4)]
+        # four rotating pinned span buffers; the first is pinned here, the others by the reader thread when it first needs them (after its
+        # first tdt_ingest_prefetch, which binds the thread to the context's device): pinning all four up front (1.8 GB) was 0.2-0.3 s
+        # in front of a process's first span, and the device had nothing to do meanwhile
+        bufs = [span_pool.take("span0", chunk + (2 << 20), np.uint8), None, None, None]
         q = queue.Queue(maxsize=1)
         stop = self._stop
         ramp = __import__("os").environ.get("TIDDIT_INGEST_RAMP", "0") == "1"      # measured: short first spans lose (0.14-0.16 s of statistics against 0.13)
@@ -588,6 +591,8 @@ class DeviceBamReader:
                 read_ms, got = 0.0, 0
                 RS = self.reader_seconds                           # where the reader thread's time goes, summed over the spans
                 while True:
+                    if bufs[k % 4] is None:
+                        bufs[k % 4] = span_pool.take("span%d" % (k % 4), chunk + (2 << 20), np.uint8)
                     buf = bufs[k % 4]
                     have = len(carry)
                     buf[:have] = carry
