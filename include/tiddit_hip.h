@@ -279,6 +279,10 @@ int tdt_sigtab_regroup_result(void *t, int32_t *cand4, int32_t *startA, int32_t 
  * (equal for odd counts) — numpy.median is their mean.  Radix select on the device, no sort. */
 int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t *gc, const int64_t *seg_off, int nseg, double *lower,
                        double *upper, int64_t *count);
+/* The same for data in n_parts separate host arrays (determine_ploidy's per-contig arrays): results 0 .. n_parts-1 are the parts' medians,
+ * result n_parts the median over all of them; every part is copied to the device from where it lies. */
+int tdt_masked_medians_parts(tdt_ctx *ctx, const double *const *cov_parts, const int8_t *const *gc_parts, const int64_t *part_len, int n_parts,
+                             double *lower, double *upper, int64_t *count);
 
 /* ---- library statistics on the device (tiddit_stats.statistics, tiddit_stats.py:5-78) ------------------------- *
  * tdt_stats_push_device takes the decoded field arrays of one ingest batch (device pointers) and applies the sampling loop (:17-47):

@@ -97,6 +97,7 @@ SYMBOLS = {
     "tdt_sigtab_regroup": (_i, [_P, _P, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "tdt_sigtab_regroup_result": (_i, [_P] * 11),
     "tdt_masked_medians": (_i, [_P, _P, _P, _P, _i, _P, _P, _P]),
+    "tdt_masked_medians_parts": (_i, [_P, _P, _P, _P, _i, _P, _P, _P]),
     "tdt_segment_means": (_i, [_P, _P, _P, _i64, _P, _P, _P, _sz, _P, _P]),
     "tdt_segment_means_device": (_i, [_P, _P, _P, _P, _P, _P, _sz, _P, _P]),
     "tdt_region_counts": (_i, [_P] * 9 + [_sz, _i, _i64, _P, _P, _P, _sz, _i, _i64, _P]),

@@ -91,28 +91,11 @@ __global__ __launch_bounds__(256) void med_pick(int pass, MedState *__restrict__
     }
 }
 
-extern "C" int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t *gc, const int64_t *seg_off, int nseg,
-                                  double *lower, double *upper, int64_t *count) {
-    if (!ctx || nseg < 1 || !seg_off || !lower || !upper || !count) {
-        tdt_set_error("tdt_masked_medians: bad argument");
-        return TDT_E_ARG;
-    }
-    long long total = 0, longest = 0;
-    for (int s = 0; s < nseg; s++) {
-        if (seg_off[2 * s] < 0 || seg_off[2 * s + 1] < seg_off[2 * s]) {
-            tdt_set_error("tdt_masked_medians: bad segment %d", s);
-            return TDT_E_ARG;
-        }
-        total = std::max<long long>(total, seg_off[2 * s + 1]);
-        longest = std::max<long long>(longest, seg_off[2 * s + 1] - seg_off[2 * s]);
-    }
-    if (total && (!cov || !gc)) {
-        tdt_set_error("tdt_masked_medians: null data");
-        return TDT_E_ARG;
-    }
+// the selection itself, data staged by `stage(dcov, dgc, stream)`: n elements, nseg segments [seg_off[2s], seg_off[2s+1])
+template <class Stage>
+static int med_run(tdt_ctx *ctx, size_t n, const int64_t *seg_off, int nseg, long long longest, Stage stage, double *lower, double *upper, int64_t *count) {
     TDT_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const size_t n = (size_t)total;
     void *d = nullptr;
     const size_t a8 = (n * 8 + 255) & ~(size_t)255, a1 = (n + 255) & ~(size_t)255;
     const size_t so = ((size_t)nseg * 16 + 255) & ~(size_t)255, ss = ((size_t)nseg * sizeof(MedState) + 255) & ~(size_t)255;
@@ -126,8 +109,8 @@ extern "C" int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t 
     MedState *dstate = (MedState *)p; p += ss;
     unsigned *dhist = (unsigned *)p;
     if (n) {
-        TDT_HIP(hipMemcpyAsync(dcov, cov, n * 8, hipMemcpyHostToDevice, st));
-        TDT_HIP(hipMemcpyAsync(dgc, gc, n, hipMemcpyHostToDevice, st));
+        rc = stage(dcov, dgc, st);
+        if (rc) return rc;
     }
     TDT_HIP(hipMemcpyAsync(doff, seg_off, (size_t)nseg * 16, hipMemcpyHostToDevice, st));
     TDT_HIP(hipMemsetAsync(dstate, 0, (size_t)nseg * sizeof(MedState), st));
@@ -148,4 +131,65 @@ extern "C" int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t 
         memcpy(&upper[s], &hs[s].prefix[1], 8);
     }
     return TDT_OK;
+}
+
+extern "C" int tdt_masked_medians(tdt_ctx *ctx, const double *cov, const int8_t *gc, const int64_t *seg_off, int nseg,
+                                  double *lower, double *upper, int64_t *count) {
+    if (!ctx || nseg < 1 || !seg_off || !lower || !upper || !count) {
+        tdt_set_error("tdt_masked_medians: bad argument");
+        return TDT_E_ARG;
+    }
+    long long total = 0, longest = 0;
+    for (int s = 0; s < nseg; s++) {
+        if (seg_off[2 * s] < 0 || seg_off[2 * s + 1] < seg_off[2 * s]) {
+            tdt_set_error("tdt_masked_medians: bad segment %d", s);
+            return TDT_E_ARG;
+        }
+        total = std::max<long long>(total, seg_off[2 * s + 1]);
+        longest = std::max<long long>(longest, seg_off[2 * s + 1] - seg_off[2 * s]);
+    }
+    if (total && (!cov || !gc)) {
+        tdt_set_error("tdt_masked_medians: null data");
+        return TDT_E_ARG;
+    }
+    const size_t n = (size_t)total;
+    return med_run(ctx, n, seg_off, nseg, longest, [&](double *dcov, signed char *dgc, hipStream_t st) -> int {
+        TDT_HIP(hipMemcpyAsync(dcov, cov, n * 8, hipMemcpyHostToDevice, st));
+        TDT_HIP(hipMemcpyAsync(dgc, gc, n, hipMemcpyHostToDevice, st));
+        return TDT_OK;
+    }, lower, upper, count);
+}
+
+// The same for data that lies in `n_parts` separate host arrays (determine_ploidy's per-contig coverage and GC arrays): the medians of
+// every part and, as result n_parts, of all parts together — each part is copied to the device from where it lies (joining 60 M
+// float64 bins on the host first was two thirds of the ploidy stage of a human-sized job).
+extern "C" int tdt_masked_medians_parts(tdt_ctx *ctx, const double *const *cov_parts, const int8_t *const *gc_parts, const int64_t *part_len,
+                                        int n_parts, double *lower, double *upper, int64_t *count) {
+    if (!ctx || n_parts < 0 || (n_parts && (!cov_parts || !gc_parts || !part_len)) || !lower || !upper || !count) {
+        tdt_set_error("tdt_masked_medians_parts: bad argument");
+        return TDT_E_ARG;
+    }
+    std::vector<int64_t> seg((size_t)(n_parts + 1) * 2);
+    long long o = 0, longest = 0;
+    for (int s = 0; s < n_parts; s++) {
+        if (part_len[s] < 0 || (part_len[s] && (!cov_parts[s] || !gc_parts[s]))) {
+            tdt_set_error("tdt_masked_medians_parts: bad part %d", s);
+            return TDT_E_ARG;
+        }
+        seg[2 * (size_t)s] = o;
+        seg[2 * (size_t)s + 1] = o + part_len[s];
+        o += part_len[s];
+    }
+    seg[2 * (size_t)n_parts] = 0;
+    seg[2 * (size_t)n_parts + 1] = o;
+    longest = o;
+    const size_t n = (size_t)o;
+    return med_run(ctx, n, seg.data(), n_parts + 1, longest, [&](double *dcov, signed char *dgc, hipStream_t st) -> int {
+        for (int s = 0; s < n_parts; s++) {
+            if (!part_len[s]) continue;
+            TDT_HIP(hipMemcpyAsync(dcov + seg[2 * (size_t)s], cov_parts[s], (size_t)part_len[s] * 8, hipMemcpyHostToDevice, st));
+            TDT_HIP(hipMemcpyAsync(dgc + seg[2 * (size_t)s], gc_parts[s], (size_t)part_len[s], hipMemcpyHostToDevice, st));
+        }
+        return TDT_OK;
+    }, lower, upper, count);
 }

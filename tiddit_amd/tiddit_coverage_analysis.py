@@ -11,25 +11,26 @@ from . import _native
 def masked_medians(pairs, ctx=None):
     """pairs: list of (coverage float64[], gc int8[]) -> (list of per-pair medians, median over all pairs).
     median of { cov[i] : cov[i] > 0 and gc[i] != -1 }; nan for an empty selection (numpy.median([]))."""
+    import ctypes
     ctx = ctx or _native.default_context()
-    covs, gcs, off, o = [], [], [], 0
+    covs, gcs = [], []
     for cov, gc in pairs:
         n = len(cov)
         if len(gc) < n:
             raise IndexError("gc array shorter than its coverage array")     # the reference indexes gc[chromosome][i]
         covs.append(numpy.ascontiguousarray(cov, dtype=numpy.float64))
         gcs.append(numpy.ascontiguousarray(gc[:n], dtype=numpy.int8))
-        off += [o, o + n]
-        o += n
-    off += [0, o]
-    cov_all = numpy.concatenate(covs) if covs else numpy.zeros(0)
-    gc_all = numpy.concatenate(gcs) if gcs else numpy.zeros(0, dtype=numpy.int8)
-    seg = numpy.array(off, dtype=numpy.int64)
-    nseg = len(seg) // 2
+    # every contig's arrays go to the device from where they lie (tdt_masked_medians_parts): joining them on the host first was a
+    # 0.5-GB copy for a human genome's 60 M bins
+    k = len(covs)
+    nseg = k + 1
+    cov_ptrs = (ctypes.c_void_p * max(k, 1))(*[c_.ctypes.data for c_ in covs])
+    gc_ptrs = (ctypes.c_void_p * max(k, 1))(*[g_.ctypes.data for g_ in gcs])
+    lens = numpy.array([len(c_) for c_ in covs], dtype=numpy.int64)
     lower, upper = numpy.empty(nseg), numpy.empty(nseg)
     count = numpy.empty(nseg, dtype=numpy.int64)
-    _native.check(ctx.lib.tdt_masked_medians(ctx.handle, _native.ptr(cov_all), _native.ptr(gc_all), _native.ptr(seg), nseg,
-                                             _native.ptr(lower), _native.ptr(upper), _native.ptr(count)))
+    _native.check(ctx.lib.tdt_masked_medians_parts(ctx.handle, cov_ptrs, gc_ptrs, _native.ptr(lens) if k else None, k,
+                                                   _native.ptr(lower), _native.ptr(upper), _native.ptr(count)))
     med = [numpy.mean([lower[s], upper[s]]) if count[s] else numpy.nan for s in range(nseg)]
     return med[:-1], med[-1]
 
