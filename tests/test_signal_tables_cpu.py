@@ -114,3 +114,19 @@ def test_quiet_gc_leaves_the_collector_as_it_found_it_and_only_the_cli_freezes()
         assert not gc.isenabled() and gc.get_freeze_count() == 0
     finally:
         gc.enable()
+
+
+def test_selected_reads_make_their_per_record_views_on_demand():
+    """SelectedReads (what the device scan returns per batch): raw_bytes / rec_off / sa_off are only needed by RecordView; they are made
+    when first asked for, once, and say what the eager code said"""
+    meta = np.zeros(3, dtype=tiddit_signal._META)
+    meta["tid"], meta["pos"], meta["sa_rel"] = [0, 0, 1], [10, 20, 30], [-1, 40, 7]
+    raw_end = np.array([100, 250, 300], dtype=np.uint32)
+    raw = (np.arange(300) % 251).astype(np.uint8)
+    sel = tiddit_signal.SelectedReads(None, meta, raw_end, raw)
+    assert not any(k in sel.__dict__ for k in ("_raw_bytes", "_rec_off", "_sa_off")) and len(sel) == 3
+    assert sel.rec_off.tolist() == [0, 100, 250] and sel.rec_off.dtype == np.uint64
+    assert sel.sa_off.tolist() == [-1, 140, 257]
+    assert sel.raw_bytes == raw.tobytes() and sel.raw_bytes is sel.raw_bytes and sel.rec_off is sel.rec_off
+    empty = tiddit_signal.SelectedReads(None, meta[:0], raw_end[:0], raw[:0])
+    assert len(empty.rec_off) == 0 and len(empty.sa_off) == 0 and empty.raw_bytes == b""
