@@ -195,18 +195,23 @@ def test_bench_runs_every_section_on_two_ranks_sharing_the_gpu(tmp_path):
     s.close()
     small = ["--steps", "2", "--warmup", "1", "--contigs", "4", "--contig-len", "8000000", "--dbscan-n", "300000", "--gc-len", "50000000",
              "--sv-mb", "3", "--ingest-mb", "1", "--no-next", "--no-cpu-baseline"]
-    env = dict(os.environ, TIDDIT_BENCH_SHARE_GPU="1", TIDDIT_BENCH_TMP=str(tmp_path))
+    detail = str(tmp_path / "detail.json")
+    env = dict(os.environ, TIDDIT_BENCH_SHARE_GPU="1", TIDDIT_BENCH_TMP=str(tmp_path), TIDDIT_BENCH_DETAIL=detail)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2"] + small, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(line) <= 5000 and len([l for l in out.stdout.splitlines() if l.startswith("{")]) == 1      # the driver keeps a bounded tail of stdout
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["unit"] == "bins/s"
     for k in ("metric", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
     for section in ("coverage_sv", "dbscan_shared", "gc", "ingest", "sv_e2e"):
         assert section in d, section
-    assert "2 byte-range shards" in d["ingest"]["config"]["workload"] and "ONE job on 2 ranks" in d["sv_e2e"]["config"]["workload"]
+    assert set(d["roofline"]["sections"]) >= {"coverage_sv", "gc", "ingest", "sv_e2e"}
+    full = json.loads(open(detail).read())                       # the detailed record of the same run
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and set(d) - {"detail"} <= set(full)
+    assert "2 byte-range shards" in full["ingest"]["config"]["workload"] and "ONE job on 2 ranks" in full["sv_e2e"]["config"]["workload"]
     one = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + small + ["--no-gc", "--no-ingest", "--no-dbscan", "--no-cov-sv"],
                          env=dict(os.environ, TIDDIT_BENCH_TMP=str(tmp_path)), capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]

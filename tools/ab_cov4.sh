@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of coverage builds: packed and four-array 500-bp launches and the 50-bp launch: tools/ab_cov4.sh [<variant> ...]
-run() { python bench.py --no-dbscan --no-gc --no-ingest --no-next --no-cpu-baseline --no-sv-e2e --steps 20 --warmup 3 2>/dev/null | python -c "
+run() { python bench.py --full-line --no-dbscan --no-gc --no-ingest --no-next --no-cpu-baseline --no-sv-e2e --steps 20 --warmup 3 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r,v,f=d['roofline'],d['coverage_sv']['roofline'],d['four_array_layout']

@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of coverage kernel builds at 500-bp and 50-bp bins: tools/ab_cov_sv.sh [<variant> ...]  (variants/lib_<name>.so vs the in-tree library;
 # TIDDIT_COV_MODE=0 forces the run-merged flavour at 50 bp).  Prints mean/median/min launch times of 20 steps, three rounds, builds interleaved.
-run() { python bench.py --no-dbscan --no-gc --no-ingest --no-next --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | python -c "
+run() { python bench.py --full-line --no-dbscan --no-gc --no-ingest --no-next --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r,v=d['roofline'],d['coverage_sv']['roofline']

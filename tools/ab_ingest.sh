@@ -6,7 +6,7 @@ ARGS="--no-gc --no-next --no-cov-sv --no-dbscan --no-sv-e2e --no-cpu-baseline --
 one() {
   local label=$1 lib=$2
   if [ -n "$lib" ]; then export TIDDIT_HIP_LIB=$lib; else unset TIDDIT_HIP_LIB; fi
-  python /root/repo/bench.py $ARGS 2>/dev/null | tail -1 | python -c "
+  python /root/repo/bench.py --full-line $ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())['ingest']
 s=d['per_batch']['span_448MB']['sum_ms']

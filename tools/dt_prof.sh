@@ -5,7 +5,7 @@ cd $R
 TIDDIT_HIP_LIB=$R/variants/lib_${1:-prof}.so python - <<'PY'
 import sys, ctypes, atexit
 import torch  # before the library: one HIP runtime in the process
-sys.argv = ["bench.py", "--no-gc", "--no-ingest", "--no-next", "--no-cov-sv", "--no-sv-e2e", "--no-cpu-baseline", "--steps", "30", "--warmup", "5", "--contigs", "1"]
+sys.argv = ["bench.py", "--full-line", "--no-gc", "--no-ingest", "--no-next", "--no-cov-sv", "--no-sv-e2e", "--no-cpu-baseline", "--steps", "30", "--warmup", "5", "--contigs", "1"]
 import bench
 from tiddit_amd import _native
 lib = ctypes.CDLL(_native.SO_PATH)

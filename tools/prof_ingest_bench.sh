@@ -8,14 +8,14 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--no-gc --no-next --no-cov-sv --no-dbscan --no-sv-e2e --no-cpu-baseline --contigs 1"
-python $R/bench.py $ARGS > $OUT/run.json 2> $OUT/run.err          # writes the BAM, warms the page cache
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py $ARGS > $OUT/trace.log 2>&1
+python $R/bench.py --full-line $ARGS > $OUT/run.json 2> $OUT/run.err          # writes the BAM, warms the page cache
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $R/bench.py --full-line $ARGS > $OUT/trace.log 2>&1
 i=0
 for PMC in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -o p -- python $R/bench.py $ARGS > $OUT/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc$i -o p -- python $R/bench.py --full-line $ARGS > $OUT/pmc$i.log 2>&1
 done
 grep -E "Name|bgzf_|bam_|sig_" $OUT/trace/t_kernel_stats.csv > $OUT/ingest_kernel_stats.csv
 ( echo "# rocprofv3 --pmc passes over bench.py's ingest section (one counter group per run, kernel-trace only), mean per launch";

@@ -3,6 +3,6 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for v in "$@"; do
   if [ "$v" = "base" ]; then unset TIDDIT_HIP_LIB; else export TIDDIT_HIP_LIB=$PWD/variants/lib_$v.so; fi
-  python bench.py --steps 5 --warmup 2 --no-dbscan --no-gc --cpu-contigs 1 2>/dev/null | python -c "
+  python bench.py --full-line --steps 5 --warmup 2 --no-dbscan --no-gc --cpu-contigs 1 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'launch_ms', round(d['roofline']['avg_launch_ms'],4), 'GB/s', round(d['roofline']['achieved'],1), 'step_ms', round(d['ms_per_step'],3), 'parity', d.get('parity_checked'))"
 done
