@@ -408,6 +408,13 @@ typedef struct tdt_retained tdt_retained;
 int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle);
 int tdt_ingest_release(tdt_retained *handle);
 int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
+/* The readers' device buffers (hundreds of MB to GB each) are kept in a per-device cache between readers and retained batches instead
+ * of going back to the driver (bounded: a quarter of the device's memory, at most 64 GB; TIDDIT_INGEST_CACHE_MB=<n> sets it, 0 switches
+ * it off).  The library returns the cache to the driver by itself when any of its own device allocations fails and when the device's
+ * last context is destroyed; an application that shares the device with other allocators (PyTorch, RCCL) calls this between jobs.
+ * *released (may be NULL) = bytes handed back.  No counterpart in the reference (htslib keeps its buffers on the host). */
+int tdt_device_cache_flush(tdt_ctx *ctx, uint64_t *released);
+uint64_t tdt_device_cache_bytes(tdt_ctx *ctx);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 /* Measurement aid (bench.py, tools/calib_stream.py): what a plain streaming read of `bytes` of device memory reaches on this device — every
  * lane four 16-byte loads in flight, nothing written; `workgroups_per_cu` workgroups of 256 threads per CU walk the buffer grid-stride

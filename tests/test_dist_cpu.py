@@ -399,6 +399,29 @@ def _sv_tables_worker(rank, world, port, q, bam, fixture, outdir):
             res["summary"] = cluster_oracle.summary(cand)
         else:
             assert cand is None
+        # ONE rank loses its tables (as if its files had been touched): the native-vs-text choice is agreed on by all ranks (the two
+        # branches run different collectives), so EVERY rank parses the text now, and rank 0 still returns the same candidates
+        dist.barrier()
+        if rank == world - 1:
+            tiddit_signal._forget_tables()
+
+        def all_buckets_here(buckets, epsilon, m, **kw):
+            import oracle
+            out = []
+            for b in buckets:
+                order = np.argsort(b[:, 0], kind="stable")
+                lab = np.empty(len(b))
+                lab[order] = oracle.dbscan_main(b[order], epsilon, m)
+                out.append(lab)
+            return out
+        tiddit_cluster.cluster_buckets_sharded = all_buckets_here
+        again = tiddit_cluster.main_sharded(prefix, rd.references, dict(zip(rd.references, rd.lengths)), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"],
+                                            max_ins, P["min_contig"], True, P["min_reads"])
+        res["text_stages"] = sorted(tiddit_cluster.STAGE_SECONDS)
+        if rank == 0:
+            res["text_canonical"] = cluster_oracle.canonical(again)
+        else:
+            assert again is None
         q.put((rank, res))
     except Exception:  # pragma: no cover
         import traceback
@@ -443,6 +466,8 @@ def test_sv_signal_tables_on_n_ranks_gloo_world2_and_3(tmp_path):
         rows = [res[r]["rows"] for r in range(world)]
         assert all(x > 0 for x in rows) and max(rows) < sum(rows)
         assert all("candidates to rank 0" in res[r]["stages"] and "parse .tab" not in res[r]["stages"] for r in range(world))
+        assert all("parse .tab" in res[r]["text_stages"] and "candidates to rank 0" not in res[r]["text_stages"] for r in range(world))
+        assert res[0]["text_canonical"] == res[0]["canonical"]
 
 
 def _a2a_worker(rank, world, port, q):

@@ -721,3 +721,37 @@ def test_device_ingest_random_legal_records(ctx, tmp_path, seed):
         if k not in ("rec_off", "sa_off"):
             assert np.array_equal(want[k], got[k]), k
     assert sa_w == sa_g and runs_ok and hc == 0
+
+
+def test_device_buffer_cache_is_bounded_flushed_and_can_be_switched_off(ctx, bams, tmp_path):
+    """the readers' device buffers go to a per-device cache when a reader closes (GB-sized hipFree / hipMalloc bursts cost 10-40 ms each):
+    a second reader takes them from there, tdt_device_cache_flush hands them back to the driver, and with TIDDIT_INGEST_CACHE_MB=0 (read
+    once per process, hence the child) nothing is ever held"""
+    import ctypes
+    import subprocess
+    import sys
+    lib = ctx.lib
+    _native.check(lib.tdt_device_cache_flush(ctx.handle, None))
+    assert lib.tdt_device_cache_bytes(ctx.handle) == 0
+    want, _, _, _, _ = _device_records(bams[1], ctx, 2_000_000)
+    held = lib.tdt_device_cache_bytes(ctx.handle)
+    assert held >= 1 << 20                                         # the closed reader's buffers
+    got, _, _, _, _ = _device_records(bams[1], ctx, 2_000_000)     # ... serve the next reader (a buffer that had to grow leaves its old block behind)
+    assert held <= lib.tdt_device_cache_bytes(ctx.handle) <= 2 * held
+    held = lib.tdt_device_cache_bytes(ctx.handle)
+    assert all(np.array_equal(want[k], got[k]) for k in FIELDS if k not in ("rec_off", "sa_off"))
+    import torch
+    free0, total = torch.cuda.mem_get_info()
+    assert held <= total // 4                                      # the bound: a quarter of the device at most
+    released = ctypes.c_uint64(0)
+    _native.check(lib.tdt_device_cache_flush(ctx.handle, ctypes.byref(released)))
+    assert released.value == held and lib.tdt_device_cache_bytes(ctx.handle) == 0
+    assert torch.cuda.mem_get_info()[0] >= free0 + held // 2       # the driver has the memory back
+    code = ("import sys; sys.path.insert(0, %r); from tiddit_amd import _native, bamio\n"
+            "c = _native.default_context()\n"
+            "r = bamio.DeviceBamReader(%r, ctx=c, chunk=2000000); n = sum(len(b) for b in r.batches()); r.close()\n"
+            "print(n, c.lib.tdt_device_cache_bytes(c.handle))") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bams[1])
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TIDDIT_INGEST_CACHE_MB="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n, cached = map(int, out.stdout.split()[-2:])
+    assert n == len(want["pos"]) and cached == 0

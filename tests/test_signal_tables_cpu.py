@@ -88,6 +88,55 @@ def test_background_writes_hand_the_tables_over_at_once_and_finish_with_the_same
     assert u._h is None
 
 
+def test_a_declined_hand_over_waits_for_the_writer_thread_before_the_text_is_parsed(tmp_path, monkeypatch):
+    """BACKGROUND_WRITES: the files exist at their final size while a thread is still placing their blocks.  When tiddit_cluster.main of
+    the same process does NOT take the tables over (here: another contig length than the tables were made for) it parses the text — it
+    must first wait for that thread, or it reads zero-filled / partial lines"""
+    import threading
+    import time
+    import oracle
+    kept = [n for n, ln in CONTIGS if ln >= MIN_CONTIG]
+
+    def buckets_by_oracle(buckets, epsilon, m, **kw):
+        out = []
+        for b in buckets:
+            order = np.argsort(b[:, 0], kind="stable")
+            lab = np.empty(len(b))
+            lab[order] = oracle.dbscan_main(b[order], epsilon, m)
+            out.append(lab)
+        return out
+    monkeypatch.setattr(tiddit_cluster, "cluster_buckets", buckets_by_oracle)
+    other = dict(CONTIGS, chr2=31000)                                  # declines the hand-over (tiddit_cluster._handed_over)
+    args = (NAMES, other, ["S"], False, 100, 2, 1000, MIN_CONTIG, True, 2)
+    t = small_tables()
+    ref_prefix = str(tmp_path / "sync")
+    tiddit_signal._write_tables(t, t, kept, ref_prefix, "S")
+    want = tiddit_cluster.main(ref_prefix, *args)
+    assert "parse .tab" in tiddit_cluster.STAGE_SECONDS and want["chr1"]["chr1"]
+    u = small_tables()
+    started = threading.Event()
+    real = u.pwrite
+
+    def slow_pwrite(*a):
+        started.set()
+        time.sleep(0.3)
+        return real(*a)
+    u.pwrite = slow_pwrite
+    prefix = str(tmp_path / "bg")
+    tiddit_signal.BACKGROUND_WRITES = True
+    try:
+        tiddit_signal._write_tables(u, u, kept, prefix, "S")
+    finally:
+        tiddit_signal.BACKGROUND_WRITES = False
+    assert started.wait(5)
+    ent = next(iter(tiddit_signal.WRITTEN_TABLES.values()))
+    assert ent[4] is not None and ent[4]["thread"].is_alive()          # the blocks are not placed yet
+    got = tiddit_cluster.main(prefix, *args)
+    assert "parse .tab" in tiddit_cluster.STAGE_SECONDS
+    assert not ent[4]["thread"].is_alive() and got == want
+    tiddit_signal._forget_tables()
+
+
 def test_quiet_gc_leaves_the_collector_as_it_found_it_and_only_the_cli_freezes():
     import gc
     from tiddit_amd.hostutil import quiet_gc, thaw

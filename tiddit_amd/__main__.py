@@ -233,10 +233,14 @@ def run_sv(args, version):
                 library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=overlap, shard=(0, world) if overlap else None)
                 blob = pickle.dumps(library, protocol=4)
                 host = numpy.zeros(8192, dtype=numpy.uint8)
-                host[:4] = numpy.array([len(blob)], dtype="<u4").view(numpy.uint8)
-                host[4:4 + len(blob)] = numpy.frombuffer(blob, dtype=numpy.uint8)
+                big = len(blob) > host.size - 4               # (never seen: a dozen numbers) -> marker here, the object by itself below
+                host[:4] = numpy.array([0xffffffff if big else len(blob)], dtype="<u4").view(numpy.uint8)
+                if not big:
+                    host[4:4 + len(blob)] = numpy.frombuffer(blob, dtype=numpy.uint8)
                 wire.copy_(torch.from_numpy(host))
                 dist.broadcast(wire, 0)
+                if big:
+                    tdist.broadcast_object(library, 0)
             else:
                 work = dist.broadcast(wire, 0, async_op=True)
                 held = 0
@@ -245,7 +249,8 @@ def run_sv(args, version):
                                            chunk=int(os.environ.get("TIDDIT_INGEST_CHUNK", str(448 << 20))))
                 work.wait()
                 host = wire.cpu().numpy()
-                library = pickle.loads(host[4:4 + int(host[:4].view("<u4")[0])].tobytes())
+                size = int(host[:4].view("<u4")[0])
+                library = tdist.broadcast_object(None, 0) if size == 0xffffffff else pickle.loads(host[4:4 + size].tobytes())
                 STAGE_NOTES["batches ingested beside rank 0's statistics"] = held
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
     T["library statistics"] = time.time() - t

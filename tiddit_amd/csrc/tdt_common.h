@@ -51,6 +51,11 @@ struct tdt_ctx {
     void *scan_meta = nullptr, *scan_size = nullptr, *scan_bytes = nullptr;
 };
 
+// Device allocations of the library outside the ingest's own buffers: hipMalloc, and where that fails once more after the ingest's
+// buffer cache (tdt_ingest.hip) has gone back to the driver — the cache must never be what makes another allocator fail.
+hipError_t tdt_dev_malloc(void **p, size_t bytes);
+size_t tdt_dev_cache_flush(int device);      // device < 0: every device; returns the bytes released (callers hold no cached pointer)
+size_t tdt_dev_cache_held(int device);
 int tdt_scratch(tdt_ctx *ctx, int slot, size_t bytes, void **out);
 int tdt_pinned(tdt_ctx *ctx, int slot, size_t bytes, void **out);
 

@@ -162,6 +162,25 @@ __device__ __forceinline__ void wave_scan2_u64(unsigned long long &a0, unsigned 
     a1 = ((unsigned long long)h1 << 32) | l1;
 }
 
+// four 32-bit values at once (each DPP read is three instructions behind the write of its register): the window resolve of MODE 1
+#define COV_SCAN4I_STEP(CTRL)                                                                   \
+    asm volatile("v_add_u32_dpp %0, %0, %0 " CTRL "\n\t"                                        \
+                 "v_add_u32_dpp %1, %1, %1 " CTRL "\n\t"                                        \
+                 "v_add_u32_dpp %2, %2, %2 " CTRL "\n\t"                                        \
+                 "v_add_u32_dpp %3, %3, %3 " CTRL                                                \
+                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3))
+
+__device__ __forceinline__ void wave_scan4_i32(int &p0, int &p1, int &p2, int &p3) {
+    asm volatile("s_nop 1" ::: "memory");
+    COV_SCAN4I_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN4I_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN4I_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN4I_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
+    COV_SCAN4I_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    COV_SCAN4I_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::: "memory");
+}
+
 // 16 bytes at an LDS byte address held in a register (ds_read_b128, no generic-pointer arithmetic)
 __device__ __forceinline__ ulonglong2 cov_lds_read128(unsigned addr) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -316,12 +335,15 @@ __global__ void cov_pack_binned(const int32_t *__restrict__ start, const int32_t
 #define COV_MIN_WAVES4 3                           // ... MODE 0 fed from four arrays: at 4 it spills 14 registers to scratch
 #endif
 #ifndef COV_MIN_WAVES1
-#define COV_MIN_WAVES1 4                           // ... MODE 1
+#define COV_MIN_WAVES1 6                           // ... MODE 1 on 8-byte records (80 registers, nothing spilled; the one-pass window resolve of round 5 would take 81)
+#endif
+#ifndef COV_MIN_WAVES1_4
+#define COV_MIN_WAVES1_4 4                         // ... MODE 1 fed from four arrays (at 6 it spills 5 registers)
 #endif
 // REC: the record layout of the stream — 0: four arrays (start, end, mapq, flag), 1: 8-byte packed records (cov_pack_record),
 //      2: 8-byte BINNED records (cov_bin_record: first bin, table indices and shape precomputed for this histogram's bin size)
 template <bool LDS_LUT, int MODE, bool Z1, int RPL, int REC>
-__global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? COV_MIN_WAVES : COV_MIN_WAVES4)) void cov_accumulate(CovParams P) {
+__global__ __launch_bounds__(COV_THREADS, MODE == 1 ? (REC ? COV_MIN_WAVES1 : COV_MIN_WAVES1_4) : (REC ? COV_MIN_WAVES : COV_MIN_WAVES4)) void cov_accumulate(CovParams P) {
     constexpr bool PACKED = REC != 0;                  // 8-byte records in I.packed
     extern __shared__ __attribute__((aligned(16))) unsigned long long smem[];
     // everything lives in the dynamic region (a static __shared__ in front of it would shift its
@@ -332,7 +354,9 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
     constexpr int TILE = COV_THREADS * RPL;            // reads per workgroup step
     int *s_wsum = reinterpret_cast<int *>(smem);
     int *s_tbin = s_wsum + 4;                          // [COV_READS_PER_BLOCK / TILE] <= 16 entries
-    unsigned long long *win = smem + 12;
+    // (MODE 1: 32 more ints in front of the window — the per-(row, wave) difference totals of the window resolve)
+    int *s_rtot = reinterpret_cast<int *>(smem + 12);
+    unsigned long long *win = smem + 12 + (MODE == 1 ? 16 : 0);
     unsigned long long *lutS = win + WIN + (MODE == 1 ? COV_SPARES1 : 2);
 
     const int tid = threadIdx.x;
@@ -362,6 +386,11 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
         else return cov_load<RPL>(I, idx, r1);
     };
     auto cur = load_tile(r0 + (unsigned long long)tid * RPL);
+#ifdef COV_PF2           // measurement variant: two tiles in flight per wave instead of one (MODE 1)
+    constexpr bool PF2 = MODE == 1;
+    auto ahead = cur;
+    if (PF2 && r0 + TILE < r1) ahead = load_tile(r0 + TILE + (unsigned long long)tid * RPL);
+#endif
 
     for (int i = tid; i < WIN + 2; i += COV_THREADS) win[i] = 0;
     if (LDS_LUT) {
@@ -439,6 +468,66 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
     // spill the LDS window to the accumulators (coalesced 64-bit global atomics, zero bins skipped) and clear it
     auto spill = [&]() {
         __syncthreads();
+#if !defined(COV_M1_SPILL_R4)
+        if constexpr (MODE == 1) {
+            // ONE pass resolves the difference counts and spills (round 5; COV_M1_SPILL_R4 keeps round 4's two passes for A/B runs).
+            // Thread t owns the words t, t + 256, ... (row k = words [256 k, 256 k + 256)): every LDS access of the pass is a wave's
+            // contiguous 512 bytes (round 4 gave a thread eight CONSECUTIVE words — a 64-byte lane stride, four lanes per bank — read them
+            // twice and wrote them twice).  The prefix over the window = per row a wave scan (the eight rows' 16-bit difference counts
+            // packed two to a register: a workgroup holds at most 2^14 reads, so no partial sum leaves [-2^14, 2^14] and the fields never
+            // borrow beyond what the extraction undoes) + the 32 (row, wave) totals, scanned by every wave for itself.
+            constexpr int PER = WIN / COV_THREADS;
+            static_assert(PER == 8 && COV_THREADS == 256, "the packed resolve is written for eight rows of 256 words");
+            unsigned long long w[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) w[k] = win[k * COV_THREADS + tid];
+            int pk[PER / 2];
+#pragma unroll
+            for (int j = 0; j < PER / 2; j++)
+                pk[j] = (int)((long long)w[2 * j] >> COV_DBIT) + (int)((unsigned)((long long)w[2 * j + 1] >> COV_DBIT) << 16);
+            wave_scan4_i32(pk[0], pk[1], pk[2], pk[3]);
+            int incl[PER];
+#pragma unroll
+            for (int j = 0; j < PER / 2; j++) {
+                incl[2 * j] = (int)(short)(pk[j] & 0xffff);
+                incl[2 * j + 1] = (pk[j] - incl[2 * j]) >> 16;
+            }
+            const int wv = tid >> 6;
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < PER; k++) s_rtot[k * 4 + wv] = incl[k];
+            }
+            __syncthreads();
+            int tot = lane < 4 * PER ? s_rtot[lane] : 0, z1 = 0, z2 = 0, z3 = 0;
+            const int own = tot;
+            wave_scan4_i32(tot, z1, z2, z3);
+            const int excl = tot - own;                       // lane 4 k + v: the differences in front of row k's share of wave v
+            const unsigned sh = (unsigned)__builtin_ctzll(P.one);
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int run = incl[k] + __builtin_amdgcn_readlane(excl, k * 4 + wv);
+                const unsigned long long v = (w[k] & COV_LOWMASK) + ((unsigned long long)(long long)run << sh);
+                const int i = k * COV_THREADS + tid;
+                if (w[k]) win[i] = 0;
+                if (v) {
+#ifdef COV_M1X_NOSPILL   // measurement variant: what the 60 M global atomics of the 50-bp flavour cost
+                    if (v == 0x1234567ull)
+#endif
+#if defined(COV_M1X_SPILLKIND) && COV_M1X_SPILLKIND == 1      // MEASUREMENT ONLY (races at the borders): plain load / add / store
+                    if (base + i <= last_bin) I.acc[base + i] += v;
+#elif defined(COV_M1X_SPILLKIND) && COV_M1X_SPILLKIND == 2    // MEASUREMENT ONLY: atomics executed in the XCD's own L2 (workgroup scope)
+                    if (base + i <= last_bin) __hip_atomic_fetch_add(&I.acc[base + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif defined(COV_M1X_SPILLKIND) && COV_M1X_SPILLKIND == 3    // MEASUREMENT ONLY: stores
+                    if (base + i <= last_bin) I.acc[base + i] = v;
+#else
+                    if (base + i <= last_bin) atomicAdd(&I.acc[base + i], v);
+#endif
+                }
+            }
+            __syncthreads();                                  // (s_rtot is rewritten by the next spill, the window by the next tile)
+            return;
+        }
+#endif
         if (MODE == 1) {
             // resolve the difference counts: thread t owns window entries [PER*t, PER*t + PER)
             constexpr int PER = WIN / COV_THREADS;
@@ -465,6 +554,9 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
         for (int i = tid; i < WIN; i += COV_THREADS) {
             const unsigned long long v = win[i];
             if (v) {
+#ifdef COV_M1X_NOSPILL
+                if (MODE != 1 || v == 0x1234567ull)
+#endif
                 if (base + i <= last_bin) atomicAdd(&I.acc[base + i], v);
                 win[i] = 0;
             }
@@ -477,8 +569,16 @@ __global__ __launch_bounds__(COV_THREADS, MODE == 1 ? COV_MIN_WAVES1 : (REC ? CO
 
     for (unsigned long long t0 = r0; t0 < r1; t0 += TILE) {
         // software prefetch: the next tile's loads are in flight while this one is reduced
+#ifdef COV_PF2
+        auto nxt = cur;
+        if constexpr (PF2) {
+            nxt = ahead;
+            if (t0 + 2 * TILE < r1) ahead = load_tile(t0 + 2 * TILE + (unsigned long long)tid * RPL);
+        } else if (t0 + TILE < r1) nxt = load_tile(t0 + TILE + (unsigned long long)tid * RPL);
+#else
         auto nxt = cur;
         if (t0 + TILE < r1) nxt = load_tile(t0 + TILE + (unsigned long long)tid * RPL);
+#endif
 
         // window re-base (block-uniform): when this tile's last read starts near the window's end the window is spilled
         // and moved to the previous tile's last read, so sparse streams / small bins stay on the LDS path
@@ -1082,13 +1182,13 @@ extern "C" int tdt_cov_create(tdt_ctx *ctx, const int64_t *contig_len, int n_con
         tdt_cov_destroy(c);
         return TDT_E_HIP;
     };
-    if ((e = hipMalloc((void **)&c->d_acc, (size_t)(total > 0 ? total : 1) * 8)) != hipSuccess) return fail("hipMalloc(acc)");
-    if ((e = hipMalloc((void **)&c->d_lut_main, lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut)");
-    if ((e = hipMalloc((void **)&c->d_lut_end, (size_t)n_contigs * lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut_end)");
-    if ((e = hipMalloc((void **)&c->d_status, COV_STATUS_BYTES)) != hipSuccess) return fail("hipMalloc(status)");
+    if ((e = tdt_dev_malloc((void **)&c->d_acc, (size_t)(total > 0 ? total : 1) * 8)) != hipSuccess) return fail("hipMalloc(acc)");
+    if ((e = tdt_dev_malloc((void **)&c->d_lut_main, lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut)");
+    if ((e = tdt_dev_malloc((void **)&c->d_lut_end, (size_t)n_contigs * lut_n * 8)) != hipSuccess) return fail("hipMalloc(lut_end)");
+    if ((e = tdt_dev_malloc((void **)&c->d_status, COV_STATUS_BYTES)) != hipSuccess) return fail("hipMalloc(status)");
     {
         std::vector<int> nb32(c->nbins.begin(), c->nbins.end());
-        if ((e = hipMalloc((void **)&c->d_nbins, (size_t)n_contigs * 4)) != hipSuccess) return fail("hipMalloc(nbins)");
+        if ((e = tdt_dev_malloc((void **)&c->d_nbins, (size_t)n_contigs * 4)) != hipSuccess) return fail("hipMalloc(nbins)");
         if ((e = hipMemcpy(c->d_nbins, nb32.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(nbins)");
     }
     c->d_kept = (unsigned long long *)((char *)c->d_status + 128);
@@ -1185,7 +1285,7 @@ static int cov_launch_items(tdt_cov *c, const CovItem &single, const CovItem *d_
     P.m15 = c->m15;
     P.k15 = c->k15;
     const bool lds_lut = c->bin_size + 1 <= COV_LUT_LDS_MAX;
-    const size_t lds = 96 + ((size_t)(small ? COV_WIN1 + COV_SPARES1 : COV_WIN + 2)) * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0) +
+    const size_t lds = 96 + (small ? 128 : 0) + ((size_t)(small ? COV_WIN1 + COV_SPARES1 : COV_WIN + 2)) * 8 + (lds_lut ? 2 * ((size_t)c->bin_size + 1) * 8 : 0) +
                        (small ? (3 * ((size_t)c->bin_size + 1) + 1) * 8 : 0) + ((!small && lds_lut && c->shift >= 0) ? 4 * ((size_t)c->bin_size + 1) * 8 : 0);
     // small bins: few reads share a bin, a read covers several -> difference-pair kernel
     const bool packed = single.packed != nullptr;
@@ -1412,7 +1512,7 @@ extern "C" int tdt_cov_push(tdt_cov *c, int tid, const int32_t *start, const int
         c->next_slot ^= 1;
         if (!c->h_stage[s]) {
             TDT_HIP(hipHostMalloc(&c->h_stage[s], slot_bytes, hipHostMallocDefault));
-            TDT_HIP(hipMalloc(&c->d_stage[s], slot_bytes));
+            TDT_HIP(tdt_dev_malloc(&c->d_stage[s], slot_bytes));
         }
         if (c->slot_used[s]) TDT_HIP(hipEventSynchronize(c->slot_ev[s]));
         char *h = (char *)c->h_stage[s];

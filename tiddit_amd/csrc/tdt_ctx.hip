@@ -1,7 +1,10 @@
 // Context, error reporting and scratch memory for libtiddit_hip.so.
 #include "tdt_common.h"
 
+#include <atomic>
+
 static thread_local char g_err[1024] = "";
+static std::atomic<int> live_contexts[64];
 
 void tdt_set_error(const char *fmt, ...) {
     va_list ap;
@@ -41,9 +44,10 @@ extern "C" int tdt_ctx_create(int device, tdt_ctx **out) {
     TDT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     TDT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) TDT_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
-    TDT_HIP(hipMalloc((void **)&c->d_async_err, 64));
+    TDT_HIP(tdt_dev_malloc((void **)&c->d_async_err, 64));
     TDT_HIP(hipMemset(c->d_async_err, 0, 64));
     c->stream = c->own_stream;
+    if (device < 64) live_contexts[device]++;
     *out = c;
     return TDT_OK;
 }
@@ -62,7 +66,21 @@ extern "C" void tdt_ctx_destroy(tdt_ctx *c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    // the device's last context takes the ingest's cached buffers with it
+    if (c->device < 64 && --live_contexts[c->device] == 0) (void)tdt_dev_cache_flush(c->device);
     delete c;
+}
+
+hipError_t tdt_dev_malloc(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (tdt_dev_cache_flush(dev) == 0) return e;        // nothing of ours was in the way
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
 }
 
 extern "C" int tdt_ctx_sync(tdt_ctx *c) {
@@ -97,8 +115,7 @@ int tdt_scratch(tdt_ctx *c, int slot, size_t bytes, void **out) {
         b.p = nullptr;
         b.cap = 0;
         size_t want = bytes + bytes / 4 + 4096;
-        if (hipMalloc(&b.p, want) != hipSuccess) {
-            (void)hipGetLastError();
+        if (tdt_dev_malloc(&b.p, want) != hipSuccess) {
             tdt_set_error("device allocation of %zu bytes failed", want);
             return TDT_E_NOMEM;
         }

@@ -337,18 +337,47 @@ static double ing_now_ms() {
 // hundreds of megabytes to gigabytes, `tiddit --sv` keeps seven batches of the statistics pass (tdt_ingest_retain: a fresh 1.7-GB
 // output buffer and a fresh 0.4-GB array block each) and frees them a moment later, and every pass over a file opens a reader.  GB-sized
 // hipMalloc / hipFree calls take 10-40 ms apiece when the driver has to map or unmap the range, and they came in bursts: the
-// statistics stage of a 240-Mb job measured 0.13 s or 0.5-0.7 s from one run to the next.  Bounded (TDT_ING_CACHE_MAX bytes per
-// device); a request takes the smallest cached buffer that is large enough and at most twice the size.
+// statistics stage of a 240-Mb job measured 0.13 s or 0.5-0.7 s from one run to the next.
+// Bounded PER DEVICE: a quarter of the device's memory, at most 64 GB (TIDDIT_INGEST_CACHE_MB overrides, 0 switches the cache off);
+// a request takes the smallest cached buffer that is large enough and at most twice the size.  The cache is never what makes an
+// allocation fail: every device allocation of the library goes through tdt_dev_malloc, which returns the cache to the driver
+// (tdt_dev_cache_flush, also behind the ABI as tdt_device_cache_flush) and tries again; the last context of a device to be destroyed
+// flushes it too.
 namespace {
 struct IngCached {
     void *p;
     size_t cap;
     int device;
 };
+enum { ING_MAX_DEV = 64 };
 std::mutex ing_cache_mu;
 std::vector<IngCached> ing_cache;
-size_t ing_cache_bytes = 0;
-const size_t TDT_ING_CACHE_MAX = (size_t)64 << 30;
+size_t ing_cache_bytes[ING_MAX_DEV] = {};
+size_t ing_cache_limit[ING_MAX_DEV] = {};
+bool ing_cache_limit_known[ING_MAX_DEV] = {};
+
+// (lock held; the caller has made `device` current)
+size_t ing_limit(int device) {
+    if (device < 0 || device >= ING_MAX_DEV) return 0;
+    if (!ing_cache_limit_known[device]) {
+        size_t lim = (size_t)64 << 30;
+        const char *e = getenv("TIDDIT_INGEST_CACHE_MB");
+        if (e && *e) {
+            lim = (size_t)strtoull(e, nullptr, 10) << 20;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                if (total_b / 4 < lim) lim = total_b / 4;
+            } else {
+                (void)hipGetLastError();
+                lim = 0;
+            }
+        }
+        ing_cache_limit[device] = lim;
+        ing_cache_limit_known[device] = true;
+    }
+    return ing_cache_limit[device];
+}
 
 void *ing_dev_alloc(int device, size_t cap, size_t *got_cap) {
     {
@@ -361,27 +390,13 @@ void *ing_dev_alloc(int device, size_t cap, size_t *got_cap) {
         if (best >= 0) {
             const IngCached c = ing_cache[(size_t)best];
             ing_cache.erase(ing_cache.begin() + best);
-            ing_cache_bytes -= c.cap;
+            ing_cache_bytes[device] -= c.cap;
             *got_cap = c.cap;
             return c.p;
         }
     }
     void *p = nullptr;
-    if (hipMalloc(&p, cap) != hipSuccess) {
-        (void)hipGetLastError();
-        // the cache may be what is in the way: give it back and try once more
-        std::vector<IngCached> drop;
-        {
-            std::lock_guard<std::mutex> lock(ing_cache_mu);
-            drop.swap(ing_cache);
-            ing_cache_bytes = 0;
-        }
-        for (auto &c : drop) (void)hipFree(c.p);
-        if (hipMalloc(&p, cap) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-    }
+    if (tdt_dev_malloc(&p, cap) != hipSuccess) return nullptr;       // (has already tried again behind a flush)
     *got_cap = cap;
     return p;
 }
@@ -390,15 +405,60 @@ void ing_dev_free(int device, void *p, size_t cap) {
     if (!p) return;
     {
         std::lock_guard<std::mutex> lock(ing_cache_mu);
-        if (cap >= (1u << 20) && ing_cache_bytes + cap <= TDT_ING_CACHE_MAX) {
+        if (device >= 0 && device < ING_MAX_DEV && cap >= (1u << 20) && ing_cache_bytes[device] + cap <= ing_limit(device)) {
             ing_cache.push_back(IngCached{p, cap, device});
-            ing_cache_bytes += cap;
+            ing_cache_bytes[device] += cap;
             return;
         }
     }
     (void)hipFree(p);
 }
 }  // namespace
+
+size_t tdt_dev_cache_flush(int device) {
+    std::vector<IngCached> drop;
+    {
+        std::lock_guard<std::mutex> lock(ing_cache_mu);
+        std::vector<IngCached> keep;
+        for (auto &c : ing_cache) (device < 0 || c.device == device ? drop : keep).push_back(c);
+        ing_cache.swap(keep);
+        for (auto &c : drop) ing_cache_bytes[c.device] -= c.cap;
+    }
+    size_t released = 0;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (auto &c : drop) {
+        (void)hipSetDevice(c.device);
+        (void)hipFree(c.p);
+        released += c.cap;
+    }
+    if (!drop.empty() && cur >= 0) (void)hipSetDevice(cur);
+    return released;
+}
+
+size_t tdt_dev_cache_held(int device) {
+    std::lock_guard<std::mutex> lock(ing_cache_mu);
+    size_t n = 0;
+    for (int d = 0; d < ING_MAX_DEV; d++)
+        if (device < 0 || d == device) n += ing_cache_bytes[d];
+    return n;
+}
+
+// Return the cached device buffers of the context's device to the driver (*released = their bytes, may be NULL).  The library does
+// this by itself when one of its allocations fails; an application that shares the device with other allocators calls it between jobs.
+extern "C" int tdt_device_cache_flush(tdt_ctx *ctx, uint64_t *released) {
+    if (!ctx) {
+        tdt_set_error("tdt_device_cache_flush: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(ctx->device));
+    TDT_HIP(hipStreamSynchronize(ctx->stream));
+    TDT_HIP(hipStreamSynchronize(ctx->copy_stream));
+    const size_t n = tdt_dev_cache_flush(ctx->device);
+    if (released) *released = (uint64_t)n;
+    return TDT_OK;
+}
+extern "C" uint64_t tdt_device_cache_bytes(tdt_ctx *ctx) { return ctx ? (uint64_t)tdt_dev_cache_held(ctx->device) : 0; }
 
 static int ing_grow(tdt_ingest *g, tdt_buf &b, size_t bytes, bool keep = false) {
     if (b.cap >= bytes) return TDT_OK;
@@ -948,7 +1008,10 @@ extern "C" int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle) {
 extern "C" int tdt_ingest_release(tdt_retained *r) {
     if (!r) return TDT_OK;
     (void)hipSetDevice(r->ctx->device);
+    // (hipFree used to wait for the whole device; a buffer that goes to the cache is handed to its next user as it is, so every
+    // stream of the context that can have touched it is drained here)
     (void)hipStreamSynchronize(r->ctx->stream);
+    (void)hipStreamSynchronize(r->ctx->copy_stream);
     ing_dev_free(r->ctx->device, r->out, r->out_cap);
     ing_dev_free(r->ctx->device, r->soa, r->soa_cap);
     delete r;

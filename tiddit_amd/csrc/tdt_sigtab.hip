@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -181,7 +182,10 @@ struct tdt_sigtab {
     std::vector<uint32_t> snext;             // splits: next row of the same fragment (the `+=` of :282 as a chain)
     size_t d_merged = 0, s_merged = 0;
     int32_t d_last = -1, s_last = -1;
-    bool d_ordered = true, s_ordered = true, dirty = false;
+    bool d_ordered = true, s_ordered = true, dirty = false, finalized = false;
+    // finalize() / format() are reached from two threads of one job (the writer thread's pwrite and the clustering's cluster_table):
+    // they are idempotent once done, and the first caller does the work under this lock
+    std::recursive_mutex mu;
     std::unordered_map<uint64_t, uint32_t> pair_of;
     std::vector<std::unique_ptr<PairTab>> pairs;
     PairTab *last_pair = nullptr;
@@ -271,7 +275,9 @@ struct tdt_sigtab {
         return TDT_OK;
     }
     int merge_new() {
+        std::lock_guard<std::recursive_mutex> hold(mu);
         formatted = false;
+        finalized = false;
         dirty = true;
         if (d_ordered)
             for (; d_merged < dlog.size(); d_merged++) {
@@ -294,7 +300,8 @@ struct tdt_sigtab {
         s_last = tid;
     }
     int finalize() {
-        if (!dirty && !order.empty()) return TDT_OK;
+        std::lock_guard<std::recursive_mutex> hold(mu);
+        if (!dirty && finalized) return TDT_OK;            // (a table without pairs is final too: `order` stays empty)
         if (dlog.size() > 0xfffffff0ull || slog.size() > 0xfffffff0ull) {
             tdt_set_error("signal tables: more than 2^32 rows");
             return TDT_E_UNSUPPORTED;
@@ -328,6 +335,7 @@ struct tdt_sigtab {
             return pairs[x]->a != pairs[y]->a ? pairs[x]->a < pairs[y]->a : pairs[x]->b < pairs[y]->b;
         });
         dirty = false;
+        finalized = true;
         formatted = false;
         return TDT_OK;
     }
@@ -400,6 +408,7 @@ struct tdt_sigtab {
         }
     }
     int format() {
+        std::lock_guard<std::recursive_mutex> hold(mu);
         int rc = finalize();
         if (rc) return rc;
         if (formatted) return TDT_OK;

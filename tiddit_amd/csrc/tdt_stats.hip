@@ -149,7 +149,7 @@ extern "C" int tdt_stats_create(tdt_ctx *ctx, int64_t n_reads, int min_mapq, int
     s->min_mapq = min_mapq;
     s->max_ins_len = max_ins_len;
     s->cap = (size_t)n_reads + 1;
-    if (hipMalloc((void **)&s->d_state, sizeof(StState)) != hipSuccess || hipMalloc((void **)&s->d_ins, s->cap * 4) != hipSuccess) {
+    if (tdt_dev_malloc((void **)&s->d_state, sizeof(StState)) != hipSuccess || tdt_dev_malloc((void **)&s->d_ins, s->cap * 4) != hipSuccess) {
         (void)hipGetLastError();
         if (s->d_state) (void)hipFree(s->d_state);
         delete s;

@@ -417,12 +417,35 @@ def _is_sharded():
         return False
 
 
-def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=False):
+def _agree_native(native):
+    """the native-vs-text choice of an N-rank job must come out the same on every rank (the two branches run different collectives):
+    one int, all-reduced with MIN"""
+    import torch
+    import torch.distributed as _dist
+    from .dist import _wire_device
+    flag = torch.tensor([1 if native else 0], dtype=torch.int32, device=_wire_device(None))
+    _dist.all_reduce(flag, op=_dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=False,
+          sharded=False):
+    """`sharded` is the caller's statement, not a look at global state: plain main() is ONE process's call and never enters a
+    collective, whatever torch.distributed group its host application has initialised; main_sharded() is every rank's call."""
+    import sys
     import time
     STAGE_SECONDS.clear()
-    sharded = _is_sharded()
     tables, owner = _handed_over(prefix, chromosomes, contig_length, samples, min_contig, skip_assembly)
-    if tables is not None and (owner is not None) == sharded:
+    native = tables is not None and (owner is not None) == sharded
+    if sharded:
+        native = _agree_native(native)
+    if not native:
+        # the text is about to be parsed: a writer thread of THIS process (tiddit_signal.BACKGROUND_WRITES) may still be placing the
+        # blocks of exactly these files, which already exist at their final size
+        ts = sys.modules.get(__package__ + ".tiddit_signal")
+        if ts is not None:
+            ts.finish_writes()
+    if native:
         candidates = _native_candidates(tables, samples[0], is_mp, epsilon, m, min_contig, STAGE_SECONDS)
         t0 = time.time()
         _finish_candidates(candidates, is_mp, min_reads)
@@ -518,4 +541,5 @@ def main_sharded(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m,
     from elsewhere every rank parses the text, the buckets are clustered where :func:`cluster_buckets_sharded` puts them and rank 0
     regroups."""
     with quiet_gc():
-        return _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=True)
+        return _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_ins_len, min_contig, skip_assembly, min_reads, root_only=True,
+                     sharded=_is_sharded())
