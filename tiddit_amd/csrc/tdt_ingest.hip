@@ -562,8 +562,11 @@ extern "C" int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t le
     }
     if (slot->t0) (void)hipEventRecord(slot->t0, ctx->copy_stream);
     TDT_HIP(hipMemcpyAsync(slot->buf.p, comp, len, hipMemcpyHostToDevice, ctx->copy_stream));
-    TDT_HIP(hipMemsetAsync((char *)slot->buf.p + len, 0, comp_pad - len, ctx->copy_stream));
+    // (the closing event sits BEHIND THE COPY, in front of the pad's memset: the memset is a kernel, and while the persistent waves of the
+    // previous span's inflate kernel hold every slot of the chip it waits for that kernel to end — rounds 3-4 recorded the event behind it
+    // and reported "h2d" sums of 1.65-1.73 s for a 3-Gb job whose 54 GB cross PCIe in 1.0 s; tools/time_h2d_contention.py)
     if (slot->t1) (void)hipEventRecord(slot->t1, ctx->copy_stream);
+    TDT_HIP(hipMemsetAsync((char *)slot->buf.p + len, 0, comp_pad - len, ctx->copy_stream));
     // the block table (a serial hop over the span's block headers: 3.6 ms per 260 MB) is built here, off the pushing thread's path, and
     // follows the span onto the device
     slot->blocks.clear();
