@@ -141,6 +141,26 @@ def test_cli_sv_skip_assembly_end_to_end(sv_bam, tmp_path):
     assert plo[0] == "Chromosome\tPloidy\tPloidy_rounded\tMean_coverage" and len(plo) >= 4
 
 
+def test_cli_sv_error_behind_the_scan_leaves_no_helper_thread(sv_bam, tmp_path, monkeypatch):
+    """the one-process `tiddit --sv` places its signal files from a writer thread beside the ploidy table and the clustering: when one of
+    those stages raises, the error reaches the caller, the writer thread has been joined and the files it was placing are complete"""
+    import threading
+    from tiddit_amd import __main__ as cli, tiddit_cluster
+    bam, fa, info, d = sv_bam
+    out = str(tmp_path / "ok")
+    cli.main(["--sv", "--bam", bam, "--ref", fa, "-o", out, "--skip_assembly", "--min_contig", "5000"])
+    want = {k: open(out + "_tiddit/" + k, "rb").read() for k in ("discordants_SYN.tab", "splits_SYN.tab", "clips_SYN.fa")}
+
+    def boom(*a, **k):
+        raise RuntimeError("clustering failed")
+    monkeypatch.setattr(tiddit_cluster, "main", boom)
+    out2 = str(tmp_path / "bad")
+    with pytest.raises(RuntimeError, match="clustering failed"):
+        cli.main(["--sv", "--bam", bam, "--ref", fa, "-o", out2, "--skip_assembly", "--min_contig", "5000"])
+    assert not [t for t in threading.enumerate() if t.name in ("tiddit-signal-writer", "tiddit-gc")]
+    assert {k: open(out2 + "_tiddit/" + k, "rb").read() for k in want} == want
+
+
 def test_region_counts_vs_literal_loop(sv_bam):
     """tiddit_variant.get_region's loop (row §8(f)3): one wavefront per candidate vs the per-read restatement"""
     from tiddit_amd import tiddit_region

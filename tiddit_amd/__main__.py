@@ -311,6 +311,26 @@ def run_sv(args, version):
         print(t - time.time())
     T["signal extraction + coverage"] = time.time() - t
     T.update({"  " + k: v for k, v in tiddit_signal.STAGE_SECONDS.items()})
+    try:
+        _after_scan(args, prefix, rank, multi, T, gc_job, start_gc if gc_job is not None else None, chromosomes, contigs, contig_length, samples,
+                    library, coverage_data, bam_header, max_ins_len, min_mapq, sample_id, version, contig_number, own_group if multi else False)
+    except BaseException:
+        # no helper thread outlives the error: the writer thread of BACKGROUND_WRITES is joined (its own error, if any, is not the one to report)
+        try:
+            tiddit_signal.finish_writes()
+        except BaseException:
+            pass
+        raise
+
+
+def _after_scan(args, prefix, rank, multi, T, gc_job, start_gc, chromosomes, contigs, contig_length, samples, library, coverage_data, bam_header,
+                max_ins_len, min_mapq, sample_id, version, contig_number, own_group):
+    """run_sv behind the BAM scan: GC bins, ploidy table, clustering, candidates table, the signal files complete"""
+    from . import tiddit_cluster, tiddit_coverage_analysis, tiddit_gc, tiddit_signal
+    from .trace import stage
+    if multi:
+        import torch.distributed as dist
+        from . import dist as tdist
     t = time.time()
     gc_dictionary = None
     with stage("tiddit: GC bins"):
