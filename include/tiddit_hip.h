@@ -415,6 +415,9 @@ int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
  * *released (may be NULL) = bytes handed back.  No counterpart in the reference (htslib keeps its buffers on the host). */
 int tdt_device_cache_flush(tdt_ctx *ctx, uint64_t *released);
 uint64_t tdt_device_cache_bytes(tdt_ctx *ctx);
+/* Test hook: the next n device allocations of the library are refused once, as if the driver were out of memory, and take the
+ * library's own way out (the cache goes back to the driver, the allocation is tried again).  n = 0: off. */
+void tdt_debug_fail_next_malloc(int n);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 /* Measurement aid (bench.py, tools/calib_stream.py): what a plain streaming read of `bytes` of device memory reaches on this device — every
  * lane four 16-byte loads in flight, nothing written; `workgroups_per_cu` workgroups of 256 threads per CU walk the buffer grid-stride

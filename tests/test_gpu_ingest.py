@@ -747,6 +747,15 @@ def test_device_buffer_cache_is_bounded_flushed_and_can_be_switched_off(ctx, bam
     _native.check(lib.tdt_device_cache_flush(ctx.handle, ctypes.byref(released)))
     assert released.value == held and lib.tdt_device_cache_bytes(ctx.handle) == 0
     assert torch.cuda.mem_get_info()[0] >= free0                   # (the driver has the memory back; how much of it shows as free at once is the runtime's business)
+    # an allocation of the library that the driver refuses takes the cache with it and succeeds on the second try
+    _device_records(bams[1], ctx, 2_000_000)
+    assert lib.tdt_device_cache_bytes(ctx.handle) >= 1 << 20
+    lib.tdt_debug_fail_next_malloc(1)
+    from tiddit_amd import tiddit_coverage
+    h = tiddit_coverage.CoverageHistogram([("c", 1_000_000)], 50, ctx=ctx)        # (its accumulators come from tdt_dev_malloc)
+    assert lib.tdt_device_cache_bytes(ctx.handle) == 0
+    h.close()
+    lib.tdt_debug_fail_next_malloc(0)
     code = ("import sys; sys.path.insert(0, %r); from tiddit_amd import _native, bamio\n"
             "c = _native.default_context()\n"
             "r = bamio.DeviceBamReader(%r, ctx=c, chunk=2000000); n = sum(len(b) for b in r.batches()); r.close()\n"

@@ -125,6 +125,7 @@ SYMBOLS = {
     "tdt_copy_to_host": (_i, [_P, _P, _P, _sz]),
     "tdt_device_cache_flush": (_i, [_P, ctypes.POINTER(ctypes.c_uint64)]),
     "tdt_device_cache_bytes": (ctypes.c_uint64, [_P]),
+    "tdt_debug_fail_next_malloc": (None, [ctypes.c_int]),
     "tdt_stats_create": (_i, [_P, _i64, _i, _i64, _PP]),
     "tdt_stats_destroy": (_i, [_P]),
     "tdt_stats_push_device": (_i, [_P] * 9 + [_sz, ctypes.POINTER(_i)]),

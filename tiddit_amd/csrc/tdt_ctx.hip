@@ -71,8 +71,17 @@ extern "C" void tdt_ctx_destroy(tdt_ctx *c) {
     delete c;
 }
 
+// test hook: the next `n` device allocations of the library behave as if the driver had refused them once (the retry behind the
+// cache flush is what a test then observes); 0 switches it off
+static std::atomic<int> fail_next_malloc{0};
+extern "C" void tdt_debug_fail_next_malloc(int n) { fail_next_malloc = n > 0 ? n : 0; }
+
 hipError_t tdt_dev_malloc(void **p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = hipErrorOutOfMemory;
+    int pending = fail_next_malloc.load();
+    while (pending > 0 && !fail_next_malloc.compare_exchange_weak(pending, pending - 1)) {
+    }
+    if (pending <= 0) e = hipMalloc(p, bytes);
     if (e == hipSuccess) return e;
     (void)hipGetLastError();
     int dev = -1;
