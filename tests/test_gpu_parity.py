@@ -746,12 +746,12 @@ def test_candidate_means_follow_define_variant(ctx):
                     assert same(g["avg_a"], avg_a) and same(g["avg_b"], avg_b) and same(g["covM"], covM), (chrA, chrB, cid, g, avg_a, avg_b, covM)
 
 
-@pytest.mark.parametrize("case", ["sparse", "deep", "long_sorted", "contig_end", "tiny_bins", "bin128", "forced_run_merged"])
+@pytest.mark.parametrize("case", ["sparse", "deep", "long_sorted", "contig_end", "tiny_bins", "bin128", "forced_run_merged", "pile_up"])
 def test_coverage_small_bin_flavour_corners(cov, case, monkeypatch):
     """the difference-pair flavour of cov_accumulate (bins <= 128 bp): streams that re-base the LDS window all the time, many
     reads per bin, sorted reads far longer than the register path takes, reads piled on the contig's last bins, 2-bp and
     128-bp bins; and the run-merged flavour forced onto 50-bp bins — all bit-identical to the per-read oracle"""
-    rng = np.random.default_rng(["sparse", "deep", "long_sorted", "contig_end", "tiny_bins", "bin128", "forced_run_merged"].index(case) + 40)
+    rng = np.random.default_rng(["sparse", "deep", "long_sorted", "contig_end", "tiny_bins", "bin128", "forced_run_merged", "pile_up"].index(case) + 40)
     z, q = 50, 5
     if case == "sparse":            # 0.2x: a tile of 1024 reads spans far more than the window
         LN, n = 40_000_000, 60_000
@@ -769,6 +769,11 @@ def test_coverage_small_bin_flavour_corners(cov, case, monkeypatch):
         LN, n = 1_000_037, 500_000
         start = np.sort(rng.integers(LN - 20_000, LN - 1, n))
         span = rng.integers(1, 3000, n)
+    elif case == "pile_up":         # whole workgroups (16 384 reads) of IDENTICAL reads: every +1 of a window on one word, every -1 on another —
+        LN = 2_000_000              # the difference counts at the edge of the 16-bit fields the window resolve packs and scans
+        pos = np.repeat(np.array([1_000, 1_049, 7_777, 500_025, 500_026, 1_999_700]), [16_384 * 3, 16_384, 40_000, 16_384 * 2 + 5, 16_383, 20_000])
+        span = np.repeat(np.array([150, 101, 12_000, 149, 51, 299]), [16_384 * 3, 16_384, 40_000, 16_384 * 2 + 5, 16_383, 20_000])
+        n, start = len(pos), pos
     elif case == "tiny_bins":
         z, LN, n = 2, 300_001, 400_000
         start = np.sort(rng.integers(0, LN - 1, n))
@@ -785,6 +790,9 @@ def test_coverage_small_bin_flavour_corners(cov, case, monkeypatch):
     end = np.minimum(start + span, LN)
     mapq = rng.integers(0, 61, n).astype(np.uint8)
     flag = np.where(rng.random(n) < 0.05, 0x400, 0).astype(np.uint16) | np.where(rng.random(n) < 0.02, 0x4, 0).astype(np.uint16)
+    if case == "pile_up":           # (nothing filtered: the counts must reach 2^14)
+        mapq[:] = 60
+        flag[:] = 0
     want, kept = oracle.coverage_stream(start, end, mapq, flag, LN, z, q)
     h = cov.CoverageHistogram([("c", LN)], z)
     h.push("c", start, end, mapq, flag, q)
