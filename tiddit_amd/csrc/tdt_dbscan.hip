@@ -29,6 +29,29 @@ int tdt_radix_sort_pairs(tdt_ctx *ctx, unsigned long long *keys, unsigned *vals,
                          size_t n, unsigned long long bitmask, unsigned long long **out_keys, unsigned **out_vals);   // tdt_sort.hip
 
 // largest b in [0, nb) with boff[b] <= i
+__device__ __forceinline__ int db_bucket(const int *__restrict__ boff, int nb, int i);
+// The bucket of position i when the wave's lanes hold positions inside [first, last] (first / last the same in every lane): the search
+// is done ONCE, on the scalar unit, for `first`; a wave of 64-128 consecutive positions almost never contains a bucket boundary (300
+// buckets in 10 M signals), and then one more scalar load settles it.  Lanes of a wave that does contain boundaries step forward from
+// the first position's bucket.  (Per-lane binary searches — nine dependent vector loads per point — were what dbt_finish took 33 us for
+// where the one-bucket dbt_finish1 takes 14.)
+__device__ __forceinline__ int db_bucket_wave(const int *__restrict__ boff, int nb, int first, int last, int i) {
+    if (nb == 1) return 0;
+#ifdef DB_BUCKET_PERLANE   // measurement variant: every lane searches for itself, as before round 5
+    return db_bucket(boff, nb, i);
+#endif
+    const int f = __builtin_amdgcn_readfirstlane(first), l = __builtin_amdgcn_readfirstlane(last);
+    int lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (boff[mid] <= f) lo = mid;
+        else hi = mid;
+    }
+    int b = lo;
+    if (lo + 1 < nb && boff[lo + 1] <= l)                  // (wave-uniform) a boundary inside the wave's range
+        while (b + 1 < nb && boff[b + 1] <= i) b++;
+    return b;
+}
 __device__ __forceinline__ int db_bucket(const int *__restrict__ boff, int nb, int i) {
     if (nb == 1) return 0;
     int lo = 0, hi = nb;
@@ -941,8 +964,9 @@ extern "C" int tdt_sort_dbscan_ex(tdt_ctx *ctx, const int64_t *posA, const int64
 __global__ __launch_bounds__(DB_THREADS) void sd_make_keys(const unsigned *__restrict__ x, int n, const int *__restrict__ boff, int nb,
                                                            unsigned long long *__restrict__ key, unsigned *__restrict__ val) {
     const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    const int w0 = i & ~63;                                        // the wave's 64 consecutive positions
     if (i >= n) return;
-    key[i] = ((unsigned long long)(unsigned)db_bucket(boff, nb, i) << 32) | x[i];   // stable sort => ties keep signal order
+    key[i] = ((unsigned long long)(unsigned)db_bucket_wave(boff, nb, w0, min(w0 + 63, n - 1), i) << 32) | x[i];   // stable sort => ties keep signal order
     val[i] = (unsigned)i;
 }
 
@@ -1111,8 +1135,9 @@ extern "C" int tdt_sort_dbscan_ex(tdt_ctx *ctx, const int64_t *posA, const int64
 __global__ __launch_bounds__(DB_THREADS) void sc_make_keys(const int *__restrict__ a, int n, const int *__restrict__ boff, int nb,
                                                            unsigned long long *__restrict__ key, unsigned *__restrict__ val) {
     const int i = blockIdx.x * DB_THREADS + threadIdx.x;
+    const int w0 = i & ~63;                                        // the wave's 64 consecutive positions
     if (i >= n) return;
-    key[i] = ((unsigned long long)(unsigned)db_bucket(boff, nb, i) << 32) | ((unsigned)a[i] ^ 0x80000000u);   // order of signed values
+    key[i] = ((unsigned long long)(unsigned)db_bucket_wave(boff, nb, w0, min(w0 + 63, n - 1), i) << 32) | ((unsigned)a[i] ^ 0x80000000u);   // order of signed values
     val[i] = (unsigned)i;
 }
 

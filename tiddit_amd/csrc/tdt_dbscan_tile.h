@@ -630,7 +630,8 @@ __global__ __launch_bounds__(256) void dbt_finish(const unsigned short *__restri
             const int i = (int)(i0 + k);
             const int t = i / DT_T - (int)((c[k] & DT_C_PREV) != 0);
             const unsigned v = c[k] & DT_C_INDEX;
-            const int b = db_bucket(boff, nb, i);
+            const long long wf = (long long)blockIdx.x * 1024 + h * 512 + (threadIdx.x & ~63) * 2;     // the wave's 128 consecutive positions
+            const int b = db_bucket_wave(boff, nb, (int)wf, (int)min(wf + 127, (long long)n - 1), i);
             const unsigned rb = runbase[b];
             if (c[k] & DT_C_EXTRA) id[k] = (double)((long long)(runbase[b + 1] - rb) - 1 + (long long)(preE[t] + v - extbase[b]));
             else id[k] = (double)(preR[t] + v - rb);
