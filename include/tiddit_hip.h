@@ -397,6 +397,13 @@ int tdt_ingest_packed(tdt_ingest *g, const uint64_t **d_packed);
 /* From the next push on the reader writes BINNED records for `cov` (NULL: the generic packed records again) into the column
  * tdt_ingest_packed returns; *binned = 1 when it does (0: that histogram's bin size has no binned form, the column stays generic). */
 int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned);
+/* Enqueue the FIRST HALF of the next span's push — its copy (or the prefetched one), the carried partial record, the inflate + CRC
+ * kernels — on the context's stream, behind the kernels the caller has already launched on the current batch, without waiting for anything:
+ * the device goes from the current batch's consumers straight into the next span's inflate while the host collects their results.  The
+ * current batch's raw bytes are overwritten by it: after this call only work enqueued BEFORE it may still read them (the field arrays stay
+ * valid until the push itself).  The next tdt_ingest_push / _push_bounded must be for exactly this (pointer, length); tdt_ingest_retain is
+ * refused in between.  (htslib's reader threads decompress ahead of the consumer in the same way.) */
+int tdt_ingest_push_ahead(tdt_ingest *g, const uint8_t *comp, size_t len);
 /* Keep the current batch beyond the next push: its device buffers (everything tdt_ingest_arrays / tdt_ingest_packed returned) move into
  * *handle and stay valid until tdt_ingest_release; the reader continues with fresh buffers.  Used by `tiddit --sv` to scan the batches its
  * library statistics were sampled from without reading and inflating them a second time. */

@@ -764,3 +764,55 @@ def test_device_buffer_cache_is_bounded_flushed_and_can_be_switched_off(ctx, bam
     assert out.returncode == 0, out.stderr[-2000:]
     n, cached = map(int, out.stdout.split()[-2:])
     assert n == len(want["pos"]) and cached == 0
+
+
+@pytest.mark.parametrize("chunk", [300_000, 2_000_000])
+def test_inflate_ahead_gives_the_same_batches(ctx, bams, chunk):
+    """DeviceBamReader.ahead(): the first half of the next span's push (carried record, inflate + CRC) is enqueued behind the current batch's
+    consumers; the field arrays of every batch equal the plain reader's, the current batch's arrays stay readable after the call, its raw
+    bytes are given up, and a span can only be started once"""
+    want, _, _, nb, _ = _device_records(bams[1], ctx, chunk)
+    r = bamio.DeviceBamReader(bams[1], ctx=ctx, chunk=chunk)
+    cols = {k: [] for k in FIELDS}
+    started = 0
+    for b in r.batches():
+        first = b.pos[:4].copy()                                       # (a host copy made BEFORE the call)
+        ok = r.ahead()
+        started += bool(ok)
+        assert r.ahead() is False                                      # one span ahead at most
+        if ok:
+            with pytest.raises(RuntimeError, match="raw bytes were given up"):
+                b.raw
+        for k in FIELDS:
+            if k not in ("rec_off", "sa_off"):
+                cols[k].append(getattr(b, k))                          # ... the field arrays are copied AFTER it
+        assert np.array_equal(first, cols["pos"][-1][:4])
+    assert r.spans_ahead == started and (started >= nb // 2 or nb <= 2)      # (the reader thread does not always have the next span yet)
+    r.close()
+    for k in cols:
+        if k not in ("rec_off", "sa_off"):                             # (batch-relative)
+            assert np.array_equal(np.concatenate(cols[k]), want[k]), k
+
+
+def test_inflate_ahead_misuse_is_refused(ctx, bams):
+    """a push for another span than the one started ahead, a second start, and retaining the batch under the inflate are errors"""
+    import ctypes
+    lib = ctx.lib
+    r = bamio.DeviceBamReader(bams[1], ctx=ctx, chunk=300_000)
+    it = r.batches()
+    b = next(it)
+    assert len(b) > 0
+    for _ in range(200):                                               # until the reader thread has the next span
+        if r.ahead():
+            break
+        import time
+        time.sleep(0.01)
+    assert r.spans_ahead == 1
+    rh = ctypes.c_void_p()
+    assert lib.tdt_ingest_retain(r._h, ctypes.byref(rh)) != 0 and b"inflating over this batch" in lib.tdt_last_error()
+    buf = np.zeros(64, dtype=np.uint8)
+    n = ctypes.c_size_t(0)
+    assert lib.tdt_ingest_push(r._h, _native.ptr(buf), 64, 0, ctypes.byref(n)) != 0
+    assert b"another span was started" in lib.tdt_last_error()
+    it.close()
+    r.close()

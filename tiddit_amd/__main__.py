@@ -92,6 +92,7 @@ def run_cov(args):
         for b in reader.batches():
             if isinstance(b, DeviceBatch):
                 hist.push_device_batch(b, args.q)
+                reader.ahead()                   # (the launch reads the batch's coverage records, not its raw bytes: the next span's inflate may follow it)
                 continue
             tid = b.tid
             edges = numpy.flatnonzero(numpy.diff(tid)) + 1

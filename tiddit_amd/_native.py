@@ -113,6 +113,7 @@ SYMBOLS = {
     "tdt_ingest_push": (_i, [_P, _P, _sz, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_push_bounded": (_i, [_P, _P, _sz, _sz, _sz, ctypes.POINTER(_sz), ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "tdt_ingest_prefetch": (_i, [_P, _P, _sz]),
+    "tdt_ingest_push_ahead": (_i, [_P, _P, _sz]),
     "tdt_ingest_arrays": (_i, [_P, _PP, ctypes.POINTER(_sz)]),
     "tdt_ingest_packed": (_i, [_P, _PP]),
     "tdt_ingest_bin_for": (_i, [_P, _P, ctypes.POINTER(_i)]),

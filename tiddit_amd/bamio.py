@@ -9,6 +9,7 @@ the raw record bytes with :class:`RecordView`.  ``BamWriter`` produces small coo
 tests and synthetic configs.  Semantics follow the SAM/BAM spec v1; ``end`` is htslib ``bam_endpos``.
 """
 import ctypes
+import os
 import struct
 import time
 import zlib
@@ -384,6 +385,8 @@ class DeviceBatch:
             if not self._live:
                 raise RuntimeError("DeviceBatch used after the reader moved on to the next batch")
             if name == "raw":
+                if getattr(self, "_raw_gone", False):
+                    raise RuntimeError("the batch's raw bytes were given up (DeviceBamReader.ahead()): the next span inflates over them")
                 a = np.empty(self._raw_len, dtype=np.uint8)
             elif name == "packed":
                 a = np.empty(self._n, dtype=np.uint64)
@@ -512,6 +515,8 @@ class DeviceBamReader:
         _native.check(self.ctx.lib.tdt_ingest_create(self.ctx.handle, len(self.references), ctypes.byref(h)))
         self._h = h
         self.host_chases = 0
+        self._gen = None                 # the running batches() generator's state (ahead())
+        self.spans_ahead = 0             # spans whose inflate was enqueued by ahead()
         self.reader_seconds = {"read": 0.0, "block scan": 0.0, "block table + copy issue": 0.0, "waited for the consumer": 0.0, "spans": 0,
                                "consumer waited for a span": 0.0}
         import os
@@ -698,18 +703,48 @@ class DeviceBamReader:
         finally:
             spans.close()
 
+    def ahead(self):
+        """Called by a consumer of ``batches()`` when it has LAUNCHED everything that reads the current batch's raw bytes on the device:
+        the next span — if the reader thread has it — is taken now and the first half of its push (carried record, inflate + CRC kernels)
+        is enqueued behind those launches (``tdt_ingest_push_ahead``), so that the device runs on into it while the host collects the
+        current batch's results.  From here on only what was enqueued before may read ``batch.dev["raw"]``; the field arrays stay valid
+        until the generator is advanced.  -> whether a span was started.  (Not with ``retain``: a kept batch owns its output buffer.)"""
+        st = self._gen
+        if st is None or self.retain or st["ahead"] or os.environ.get("TIDDIT_INGEST_AHEAD", "1") == "0":
+            return False
+        if st["pending"] is False:
+            st["pending"] = st["spans"].poll()
+        item = st["pending"]
+        if item is False or item is None:
+            return False
+        buf, consumed = item[0], item[1]
+        _native.check(self.ctx.lib.tdt_ingest_push_ahead(self._h, _native.ptr(buf), consumed))
+        st["ahead"] = True
+        if st.get("batch") is not None and not getattr(st["batch"], "_retained", None):
+            st["batch"]._raw_gone = True                      # (a retained batch owns its buffers: nothing inflates over them)
+        self.spans_ahead += 1
+        return True
+
     def _batches(self, spans, lib, ctx, nothing):
         prev, first = None, True
-        pending = False                                             # False: span k+1 not looked at yet; None: end of the range
+        # pending — False: span k+1 not looked at yet; None: end of the range; else the span itself.  (On the reader: ahead() looks at it.)
+        st = self._gen = {"pending": False, "spans": spans, "ahead": False}
+        try:
+            yield from self._batches_loop(st, spans, lib, ctx, nothing, prev, first)
+        finally:
+            self._gen = None
+
+    def _batches_loop(self, st, spans, lib, ctx, nothing, prev, first):
         while True:
             t_wait = time.perf_counter()
-            cur = spans.next() if pending is False else pending
+            cur = spans.next() if st["pending"] is False else st["pending"]
             wait_ms = 1e3 * (time.perf_counter() - t_wait)
             self.reader_seconds["consumer waited for a span"] += wait_ms * 1e-3
             if cur is None:
                 break
             buf, consumed, abs0, read_ms = cur
-            pending = spans.poll()                                  # span k+1 already read?  (its PCIe copy was started by the reader thread)
+            st["ahead"] = False                                     # (a span started by ahead() is this one: its push finishes below)
+            st["pending"] = spans.poll()                            # span k+1 already read?  (its PCIe copy was started by the reader thread)
             if prev is not None and not getattr(prev, "_retained", None):
                 prev._live = False
             n = ctypes.c_size_t(0)
@@ -771,7 +806,7 @@ class DeviceBamReader:
                 rh = ctypes.c_void_p()
                 _native.check(lib.tdt_ingest_retain(self._h, ctypes.byref(rh)))
                 b._retained = rh
-            prev = b
+            prev = st["batch"] = b
             yield b
         c, hc = ctypes.c_size_t(0), ctypes.c_size_t(0)
         _native.check(lib.tdt_ingest_carry(self._h, ctypes.byref(c), ctypes.byref(hc)))

@@ -38,6 +38,7 @@ struct tdt_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;    // stream in use (own_stream or an adopted one)
     hipStream_t copy_stream = nullptr;
+    hipStream_t back_stream = nullptr;   // device-to-host copies that must not queue behind the launch stream's next kernels (tdt_signal_scan_result)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int num_cu = 256;
     tdt_buf scratch[TDT_NSCRATCH];

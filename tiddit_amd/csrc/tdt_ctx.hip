@@ -43,6 +43,7 @@ extern "C" int tdt_ctx_create(int device, tdt_ctx **out) {
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     TDT_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     TDT_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    TDT_HIP(hipStreamCreateWithFlags(&c->back_stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) TDT_HIP(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     TDT_HIP(tdt_dev_malloc((void **)&c->d_async_err, 64));
     TDT_HIP(hipMemset(c->d_async_err, 0, 64));
@@ -57,6 +58,7 @@ extern "C" void tdt_ctx_destroy(tdt_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->copy_stream);
+    if (c->back_stream) (void)hipStreamSynchronize(c->back_stream);
     if (c->d_async_err) (void)hipFree(c->d_async_err);
     for (auto &b : c->scratch)
         if (b.p) (void)hipFree(b.p);
@@ -66,6 +68,7 @@ extern "C" void tdt_ctx_destroy(tdt_ctx *c) {
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->back_stream) (void)hipStreamDestroy(c->back_stream);
     // the device's last context takes the ingest's cached buffers with it
     if (c->device < 64 && --live_contexts[c->device] == 0) (void)tdt_dev_cache_flush(c->device);
     delete c;

@@ -325,6 +325,16 @@ struct tdt_ingest {
     hipEvent_t tev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0-1 h2d, 1-2 inflate+crc, 2-3 find, 4-5 decode, 6-7 prefetch copy
     double t_table_ms = 0, t_chain_ms = 0, t_wall_ms = 0;
     bool t_prefetched = false, t_have_decode = false;
+    // The first half of a push — the span's copy, its block table and the inflate + CRC kernels — can be ENQUEUED AHEAD
+    // (tdt_ingest_push_ahead) behind the kernels that still read the current batch; the push of exactly that span then starts at the wait
+    // for its status word.  What the second half needs from the first:
+    struct Begun {
+        bool valid = false;
+        const uint8_t *comp = nullptr;
+        size_t len = 0, produced = 0, carry = 0, T = 0, nb = 0;
+        unsigned *d_status = nullptr;
+    } begun;
+    unsigned *h_summary = nullptr;                 // pinned: {first failed block, failed blocks} of the batch being inflated
 };
 
 static double ing_now_ms() {
@@ -497,6 +507,12 @@ extern "C" int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out) {
             (void)hipGetLastError();
             e = nullptr;
         }
+    if (hipHostMalloc((void **)&g->h_summary, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        delete g;
+        tdt_set_error("tdt_ingest_create: pinned allocation failed");
+        return TDT_E_NOMEM;
+    }
     *out = g;
     return TDT_OK;
 }
@@ -518,6 +534,7 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
     for (tdt_buf *b : {&g->comp, &g->pf[0].buf, &g->pf[1].buf, &g->pf[2].buf, &g->pf[0].table, &g->pf[1].table, &g->pf[2].table, &g->table, &g->out, &g->seg, &g->soa})
         ing_dev_free(g->ctx->device, b->p, b->cap);                  // (both streams are idle: synchronised above)
     if (g->pin.p) (void)hipHostFree(g->pin.p);
+    if (g->h_summary) (void)hipHostFree(g->h_summary);
     delete g;
     return TDT_OK;
 }
@@ -627,16 +644,10 @@ extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_
     return rc;
 }
 
-static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records, size_t *first_off,
-                    size_t *next_off) {
-    const bool unknown_start = skip == (size_t)-1;
-    if (unknown_start && g->carry) {
-        tdt_set_error("tdt_ingest_push_bounded: an unknown start is only possible on a fresh stream");
-        return TDT_E_ARG;
-    }
-    if (unknown_start) skip = 0;
-    if (first_off) *first_off = (size_t)-1;
-    if (next_off) *next_off = (size_t)-1;
+// First half of a push: the span's bytes and block table on the device (taken from the prefetch slot that holds them, or copied here),
+// the carried partial record at the front of the output, the inflate + CRC kernels and the copy of their status word — all ENQUEUED on the
+// launch stream, nothing waited for.  Leaves g->begun for ing_push.
+static int ing_push_begin(tdt_ingest *g, const uint8_t *comp, size_t len) {
     tdt_ctx *ctx = g->ctx;
     TDT_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -678,6 +689,8 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     if (rc) return rc;
     unsigned char *d_out = (unsigned char *)g->out.p;
     const size_t nb = blocks.size();
+    unsigned *d_status = nullptr;
+    g->h_summary[0] = g->h_summary[1] = 0;
     if (nb) {
         const size_t comp_pad = (len + 4096 + 255) & ~(size_t)255;
         rc = ing_grow(g, g->comp, comp_pad);
@@ -686,7 +699,8 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         rc = ing_grow(g, g->table, tab + stb + 256);
         if (rc) return rc;
         BzDesc *d_blocks = (BzDesc *)g->table.p;
-        unsigned *d_status = (unsigned *)((char *)g->table.p + tab), *d_summary = (unsigned *)((char *)d_status + stb);
+        d_status = (unsigned *)((char *)g->table.p + tab);
+        unsigned *d_summary = (unsigned *)((char *)d_status + stb);
         if (table_on_device && hit && hit->table.cap < tab + stb + 256) table_on_device = false;       // (cannot happen: sized alike)
         if (g->tev[0]) (void)hipEventRecord(g->tev[0], st);
         bool was_hit = false;
@@ -717,17 +731,80 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         }
         if (g->tev[1]) (void)hipEventRecord(g->tev[1], st);
         unsigned char *d_comp = (unsigned char *)g->comp.p;
-        if (!(was_hit && table_on_device)) TDT_HIP(hipMemcpyAsync(d_blocks, blocks.data(), nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
+        if (!(was_hit && table_on_device)) {
+            // (the table's host copy must outlive the asynchronous transfer: it is staged through the launch stream's own pinned block)
+            void *h_tab = nullptr;
+            rc = tdt_pinned(ctx, 3, nb * sizeof(BzDesc), &h_tab);
+            if (rc) return rc;
+            memcpy(h_tab, blocks.data(), nb * sizeof(BzDesc));
+            TDT_HIP(hipMemcpyAsync(d_blocks, h_tab, nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
+        }
         rc = tdt_bz_launch(ctx, d_comp, d_blocks, nb, d_out + carry, true, d_status, d_summary);
         if (rc) return rc;
         if (g->tev[2]) (void)hipEventRecord(g->tev[2], st);
-        unsigned summary[2] = {0, 0};
-        TDT_HIP(hipMemcpyAsync(summary, d_summary, 8, hipMemcpyDeviceToHost, st));
+        TDT_HIP(hipMemcpyAsync(g->h_summary, d_summary, 8, hipMemcpyDeviceToHost, st));
+    }
+    g->begun.valid = true;
+    g->begun.comp = comp;
+    g->begun.len = len;
+    g->begun.produced = produced;
+    g->begun.carry = carry;
+    g->begun.T = T;
+    g->begun.nb = nb;
+    g->begun.d_status = d_status;
+    return TDT_OK;
+}
+
+// Enqueue the first half of the NEXT span's push behind whatever the launch stream holds — the caller has launched every kernel that
+// reads the current batch (its raw bytes are overwritten by this span's output: after this call only what was enqueued before it may
+// still read them) — so that the device goes from the current batch's consumers straight into the next span's inflate kernel while
+// the host collects results.  The following tdt_ingest_push / _bounded must be for exactly this (pointer, length).
+extern "C" int tdt_ingest_push_ahead(tdt_ingest *g, const uint8_t *comp, size_t len) {
+    if (!g || !comp || !len) {
+        tdt_set_error("tdt_ingest_push_ahead: bad argument");
+        return TDT_E_ARG;
+    }
+    if (g->failed || g->begun.valid) {
+        tdt_set_error(g->failed ? "tdt_ingest_push_ahead: an earlier push on this stream failed" : "tdt_ingest_push_ahead: a span is already inflating ahead");
+        return TDT_E_ARG;
+    }
+    const int rc = ing_push_begin(g, comp, len);
+    if (rc != TDT_OK) g->failed = true;
+    return rc;
+}
+
+static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records, size_t *first_off,
+                    size_t *next_off) {
+    const bool unknown_start = skip == (size_t)-1;
+    if (unknown_start && (g->carry || g->begun.valid)) {
+        tdt_set_error("tdt_ingest_push_bounded: an unknown start is only possible on a fresh stream");
+        return TDT_E_ARG;
+    }
+    if (unknown_start) skip = 0;
+    if (first_off) *first_off = (size_t)-1;
+    if (next_off) *next_off = (size_t)-1;
+    tdt_ctx *ctx = g->ctx;
+    TDT_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = TDT_OK;
+    if (g->begun.valid) {
+        if (g->begun.comp != comp || g->begun.len != len) {
+            tdt_set_error("tdt_ingest_push: another span was started with tdt_ingest_push_ahead");
+            return TDT_E_ARG;
+        }
+    } else {
+        rc = ing_push_begin(g, comp, len);
+        if (rc) return rc;
+    }
+    g->begun.valid = false;
+    const size_t produced = g->begun.produced, carry = g->begun.carry, T = g->begun.T, nb = g->begun.nb;
+    unsigned char *d_out = (unsigned char *)g->out.p;
+    if (nb) {
         TDT_HIP(hipStreamSynchronize(st));
-        if (summary[1]) {
+        if (g->h_summary[1]) {
             unsigned code = 0;
-            TDT_HIP(hipMemcpy(&code, d_status + summary[0], 4, hipMemcpyDeviceToHost));
-            tdt_set_error("tdt_ingest_push: %u of %zu BGZF blocks failed; first is block %u: %s", summary[1], nb, summary[0], tdt_bz_err_name(code));
+            TDT_HIP(hipMemcpy(&code, g->begun.d_status + g->h_summary[0], 4, hipMemcpyDeviceToHost));
+            tdt_set_error("tdt_ingest_push: %u of %zu BGZF blocks failed; first is block %u: %s", g->h_summary[1], nb, g->h_summary[0], tdt_bz_err_name(code));
             return TDT_E_ARG;
         }
     }
@@ -979,8 +1056,9 @@ extern "C" int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle) {
         return TDT_E_ARG;
     }
     *handle = nullptr;
-    if (g->failed) {
-        tdt_set_error("tdt_ingest_retain: the stream is in an error state");
+    if (g->failed || g->begun.valid) {
+        tdt_set_error(g->failed ? "tdt_ingest_retain: the stream is in an error state"
+                                : "tdt_ingest_retain: the next span is already inflating over this batch (tdt_ingest_push_ahead)");
         return TDT_E_ARG;
     }
     TDT_HIP(hipSetDevice(g->ctx->device));

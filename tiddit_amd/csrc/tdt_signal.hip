@@ -346,6 +346,9 @@ extern "C" int tdt_signal_scan(tdt_ctx *ctx, const void *const *d_arrays14, size
     if (rc) return rc;
     hipLaunchKernelGGL(sig_gather_bytes, dim3(m), dim3(64), 0, st, (const unsigned *)d_idx, m, d_rec_off, (const unsigned *)d_size, d_raw, (uint8_t *)scr3);
     TDT_CHECK_LAUNCH();
+    // everything that reads the batch is enqueued: the caller may start the next span's inflate behind it (tdt_ingest_push_ahead); the
+    // result copies wait for THIS point, on a stream of their own
+    TDT_HIP(hipEventRecord(ctx->ev[1], st));
     ctx->scan_n_sel = (size_t)m;
     ctx->scan_raw_bytes = total;
     ctx->scan_meta = d_meta;
@@ -363,8 +366,11 @@ extern "C" int tdt_signal_scan_result(tdt_ctx *ctx, void *meta24, uint32_t *raw_
     }
     if (!ctx->scan_n_sel) return TDT_OK;
     TDT_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    // the copies run on the context's return stream behind the scan's last kernel — not on the launch stream, where the next span's
+    // inflate kernel (enqueued ahead by the caller, ~12 ms) may already stand between that kernel and them
+    hipStream_t st = ctx->back_stream;
     static_assert(sizeof(ScanMeta) == 28, "ScanMeta layout");
+    TDT_HIP(hipStreamWaitEvent(st, ctx->ev[1], 0));
     TDT_HIP(hipMemcpyAsync(meta24, ctx->scan_meta, ctx->scan_n_sel * sizeof(ScanMeta), hipMemcpyDeviceToHost, st));
     TDT_HIP(hipMemcpyAsync(raw_end, ctx->scan_size, ctx->scan_n_sel * 4, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipMemcpyAsync(raw, ctx->scan_bytes, ctx->scan_raw_bytes, hipMemcpyDeviceToHost, st));

@@ -134,6 +134,7 @@ def coverage_sharded(bam_file_name, bin_size, min_q, group=None, ctx=None, chunk
     n = 0
     for b in reader.batches():
         hist.push_device_batch(b, min_q)
+        reader.ahead()                           # the next span's inflate follows the launch (which reads coverage records, not raw bytes)
         n += len(b)
     empty = reader.first_off is None
     first_off, next_off = reader.first_off, reader.next_off

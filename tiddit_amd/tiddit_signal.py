@@ -232,10 +232,11 @@ def split_rows_native(sel, which4, names, min_q, splits, lib=None):
 _SEL_POOL = None            # pinned host buffers the scan loop's selected reads arrive in (three rotating sets: see _device_scan)
 
 
-def _device_scan(batch, contig_ok, min_q, max_ins, min_anchor_len, min_clip_len, ctx=None, slot=None):
+def _device_scan(batch, contig_ok, min_q, max_ins, min_anchor_len, min_clip_len, ctx=None, slot=None, launched=None):
     """slot = 0 / 1 / 2: the three result arrays are views of PINNED buffers of that rotating set (the device-to-host copies are DMA
     transfers, not staged through the runtime's bounce buffers) and stay valid until the set is used again — the scan loop, whose row
-    thread is one batch behind, passes batch number mod 3.  None: fresh numpy arrays."""
+    thread is one batch behind, passes batch number mod 3.  None: fresh numpy arrays.  launched(): called when every kernel that reads
+    the batch has been enqueued and before the results are waited for (the scan loop starts the next span's inflate there)."""
     global _SEL_POOL
     ctx = ctx or _native.default_context()
     ok = numpy.ascontiguousarray(contig_ok, dtype=numpy.uint8)
@@ -243,6 +244,8 @@ def _device_scan(batch, contig_ok, min_q, max_ins, min_anchor_len, min_clip_len,
     n_sel, raw_bytes = ctypes.c_size_t(0), ctypes.c_size_t(0)
     _native.check(ctx.lib.tdt_signal_scan(ctx.handle, table, len(batch), _native.ptr(ok), len(ok), int(min_q), int(max_ins), int(min_anchor_len),
                                           int(min_clip_len), ctypes.byref(n_sel), ctypes.byref(raw_bytes)))
+    if launched is not None:
+        launched()
     if slot is None:
         meta = numpy.empty(n_sel.value, dtype=_META)
         raw_end = numpy.empty(n_sel.value, dtype=numpy.uint32)
@@ -366,8 +369,11 @@ def _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_le
                 t3 = time.time()
                 T["coverage push"] += t3 - t1
                 # the per-read chain of worker (:171-221) on the device; only the selected reads come back (fields + raw records)
+                # (once the scan's kernels are enqueued nothing will read the batch's raw bytes again: the next span's inflate is started
+                #  behind them — DeviceBamReader.ahead() — and runs while this thread waits for the selected reads and hands them on)
+                ahead = getattr(reader, "ahead", None)
                 if os.environ.get("TIDDIT_SCAN_RESULT_PINNED", "1") != "0":
-                    sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len, slot=n_batches % 3)
+                    sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len, slot=n_batches % 3, launched=ahead)
                 else:                                           # (as before round 4's last step: pageable arrays, the per-record copies made at once)
                     sel = _device_scan(b, big, min_q, max_ins, min_anchor_len, min_clip_len)
                     sel.raw_bytes, sel.sa_off
