@@ -16,7 +16,9 @@ buckets are split over the ranks, one BAM is read as byte-range shards with one 
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line: the COMPACT record of the run (<= LINE_BUDGET bytes: the contract's keys, the whole `roofline` object with every
+section's fractions, `cpu_baseline`, the sections' headline figures); the detailed record goes to gpurun_out/bench_detail_n<N>.json
+($TIDDIT_BENCH_DETAIL) and to stdout only with --full-line.
 """
 import argparse
 import ctypes
