@@ -1050,8 +1050,20 @@ def emit(result, args):
     except OSError as e:
         detail = "not written: %s" % e
     if getattr(args, "full_line", False):
+        try:
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(result), flush=True)
         return
+    # whatever native libraries still hold in C stdio buffers (RCCL's start-up banner is written through libc's stdout and would
+    # otherwise be flushed at exit, BEHIND the JSON line) goes out first: the record is the last line of stdout
+    try:
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     line = compact_line(result)
     line["detail"] = detail
     text = json.dumps(line)
