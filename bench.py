@@ -330,6 +330,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: coverage histogram, %d contigs x %d bp (%.2f Gb), %dx 150-bp sorted "
                                "stream, %d-bp bins, q>=%d filter; contigs split over the %d rank(s)" % (C_all, L, C_all * L / 1e9, args.depth, z, args.min_q, world),
                    "reads": job_reads, "bins": job_bins, "reads_rank0": total_reads, "bins_rank0": total_bins, "launches_per_step": 3,
+                   "layout_short": "8-byte BINNED records in HBM as the ingest kernel writes them (DESIGN 3.1): `value` prices the ACCUMULATE stage of "
+                                   "ingest -> accumulate; roofline.contract_* is SURVEY 8(d)'s four arrays in one launch",
                    "layout": "8-byte BINNED records in HBM (first_bin << 2 | shape, filter byte, the two table indices of tiddit_coverage.pyx:53-63: "
                              "csrc/tdt_cov_record.h cov_bin_record) — what the ingest kernel writes when the reader is bound to this histogram "
                              "(DeviceBamReader.bin_for): the division and the bin split are done once where the record is made.  "
@@ -971,25 +973,38 @@ def compact_line(result):
     line.update(_pick(result, ("dtype", "data", "reads_per_sec")))
     cfg = result.get("config") or {}
     line["config"] = _pick(cfg, ("workload", "reads", "bins", "launches_per_step"), 170)
-    line["config"]["layout"] = "8-byte BINNED records in HBM, written by the ingest kernel bound to the histogram (DESIGN 3.1); roofline.contract = the four arrays of SURVEY 8(d)"
+    if cfg.get("layout_short"):                                  # (what the run itself says its input layout was — nothing is asserted here)
+        line["config"]["layout"] = _short(cfg["layout_short"], 240)
     rf = result.get("roofline") or {}
     r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "avg_launch_ms", "median_launch_ms",
                    "min_launch_ms", "algorithmic_bytes_per_launch", "frac_of_stream_read", "bytes_model", "pack_binned_from_four_arrays_ms",
                    "binning_ms_per_600M_reads"), 80)
     if "traffic" not in r:
         r["traffic"] = None
-    r["traffic_source"] = "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of the committed build, gfx950 corrections"
+    if r["traffic"] is not None and rf.get("traffic_source"):    # (only a run that found a matching profiles/traffic.json quotes it)
+        r["traffic_source"] = _short(rf["traffic_source"], 200)
     sr = rf.get("stream_read")
     if sr:
         r["stream_read"] = _pick(sr, ("GB_per_s", "frac_of_peak", "bytes"))
     if rf.get("from_four_arrays_incl_pack"):
         r["from_four_arrays_incl_pack"] = _pick(rf["from_four_arrays_incl_pack"], ("ms", "frac"))
     if rf.get("contract"):
-        r["contract"] = _pick(rf["contract"], ("ms", "frac", "frac_survey_8d_12B_per_read", "frac_of_stream_read", "bins_per_sec"))
-        r["contract"]["layout"] = "SURVEY 8(d) four arrays, one launch, no packing pass"
+        r["contract"] = _pick(rf["contract"], ("ms", "frac", "frac_survey_8d_12B_per_read", "frac_of_stream_read", "bins_per_sec", "layout"), 130)
+        # the same as scalar keys of `roofline`: the driver's parser keeps scalars only
+        r.update({"contract_" + k: _short(v) for k, v in rf["contract"].items() if k in ("ms", "frac", "bins_per_sec", "frac_of_stream_read") and v is not None})
+    if sr and sr.get("GB_per_s") is not None:
+        r["stream_read_GBps"] = _short(sr["GB_per_s"])
     secs = {}
     for k, v in (rf.get("sections") or {}).items():
         secs[k] = {kk: _short(vv) for kk, vv in v.items() if kk != "bound" and vv is not None}
+    for sec, key in (("coverage_sv", "cov_sv"), ("dbscan", "dbscan"), ("gc", "gc")):
+        if secs.get(sec, {}).get("frac") is not None:
+            r[key + "_frac"] = secs[sec]["frac"]
+            r[key + "_ms"] = secs[sec].get("ms")
+    if secs.get("ingest", {}).get("records_per_sec") is not None:
+        r["ingest_records_per_sec"] = secs["ingest"]["records_per_sec"]
+    if secs.get("sv_e2e", {}).get("wall_s") is not None:
+        r["sv_e2e_wall_s"] = secs["sv_e2e"]["wall_s"]
     r["sections"] = secs
     line["roofline"] = r
     cb = result.get("cpu_baseline")

@@ -41,6 +41,10 @@ typedef struct tdt_cov tdt_cov;
 
 /* ---- context ------------------------------------------------------------------------------ */
 int tdt_version(void);
+/* The measurement macros the library was compiled with, space separated ("" = the product build).  Ablation builds (tools/build_variant.sh)
+ * exist to price parts of a kernel and may compute wrong results; tiddit_amd._native refuses to load a library that reports any unless
+ * TIDDIT_ALLOW_VARIANT=1. */
+const char *tdt_build_flags(void);
 const char *tdt_last_error(void);
 int tdt_device_count(int *count);
 int tdt_ctx_create(int device, tdt_ctx **out);
@@ -423,7 +427,8 @@ int tdt_ingest_carry(tdt_ingest *g, size_t *bytes, size_t *host_chases);
 int tdt_device_cache_flush(tdt_ctx *ctx, uint64_t *released);
 uint64_t tdt_device_cache_bytes(tdt_ctx *ctx);
 /* Test hook: the next n device allocations of the library are refused once, as if the driver were out of memory, and take the
- * library's own way out (the cache goes back to the driver, the allocation is tried again).  n = 0: off. */
+ * library's own way out (the cache goes back to the driver, the allocation is tried again — also when the cache held nothing, so the
+ * hook never turns an allocation into a failure).  n = 0: off. */
 void tdt_debug_fail_next_malloc(int n);
 int tdt_copy_to_host(tdt_ctx *ctx, void *dst, const void *d_src, size_t bytes);
 /* Measurement aid (bench.py, tools/calib_stream.py): what a plain streaming read of `bytes` of device memory reaches on this device — every

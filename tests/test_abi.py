@@ -32,6 +32,37 @@ def test_header_symbols_exported(native):
     assert lib.tdt_version() >= 100
 
 
+def test_in_tree_build_is_not_a_measurement_build(native):
+    """tdt_build_flags: the product library was compiled with none of the ablation / tunable macros of tools/build_variant.sh"""
+    assert native.load().tdt_build_flags() == b""
+
+
+def test_measurement_build_is_refused_unless_allowed(tmp_path):
+    """a library compiled with an ablation macro reports it and tiddit_amd._native refuses to load it (TIDDIT_ALLOW_VARIANT=1 overrides):
+    built here from the in-tree objects with ONE translation unit recompiled under a tunable (-DRS_ROUNDS=8)"""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(REPO, "tiddit_amd", "csrc")
+    objs = sorted(f for f in os.listdir(csrc) if f.endswith(".o"))
+    if not os.path.exists(hipcc) or "tdt_sort.o" not in objs:
+        pytest.skip("no hipcc / no in-tree objects")
+    var = str(tmp_path / "tdt_sort_var.o")
+    so = str(tmp_path / "lib_var.so")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-DRS_ROUNDS=8", "-I" + os.path.join(REPO, "include"), "-c",
+                    os.path.join(csrc, "tdt_sort.hip"), "-o", var], check=True, capture_output=True, timeout=600)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(csrc, o) for o in objs if o != "tdt_sort.o"] + [var, "-o", so, "-lz", "-lpthread", "-ldl"],
+                   check=True, capture_output=True, timeout=600)
+    code = "import sys; sys.path.insert(0, %r); from tiddit_amd import _native; print(_native.load().tdt_build_flags().decode())" % REPO
+    env = dict(os.environ, TIDDIT_HIP_LIB=so)
+    env.pop("TIDDIT_ALLOW_VARIANT", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "measurement macros (RS_ROUNDS)" in out.stderr
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, TIDDIT_ALLOW_VARIANT="1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.split()[-1] == "RS_ROUNDS"
+
+
 def test_every_reference_citation_in_header():
     hdr = open(os.path.join(REPO, "include", "tiddit_hip.h")).read()
     for ref in ("tiddit_coverage.pyx:10-21", "tiddit_coverage.pyx:48-74", "__main__.py:229-242", "tiddit_signal.pyx:169-182",

@@ -54,7 +54,33 @@ def test_compact_line_of_every_committed_record(bench, capsys, tmp_path, monkeyp
             assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
         for sec, v in (d["roofline"].get("sections") or {}).items():
             assert sec in rf["sections"], (name, sec)
+        # what the driver's parser keeps are the SCALAR keys of `roofline`: the contract launch and the sections' fractions are there too
+        if d["roofline"].get("contract"):
+            assert rf["contract_frac"] == pytest.approx(d["roofline"]["contract"]["frac"], rel=1e-5) and rf["contract_ms"] > 0 and rf["contract_bins_per_sec"] > 0
+        for sec, key in (("coverage_sv", "cov_sv_frac"), ("dbscan", "dbscan_frac"), ("gc", "gc_frac")):
+            if (d["roofline"].get("sections") or {}).get(sec):
+                assert rf[key] == pytest.approx(d["roofline"]["sections"][sec]["frac"], rel=1e-5), (name, key)
+        if (d["roofline"].get("stream_read") or {}).get("GB_per_s"):
+            assert rf["stream_read_GBps"] == pytest.approx(d["roofline"]["stream_read"]["GB_per_s"], rel=1e-5)
+        # provenance is quoted only when the run has it
+        assert ("traffic_source" in rf) == (rf["traffic"] is not None and bool(d["roofline"].get("traffic_source")))
+        assert ("layout" in line["config"]) == bool(d["config"].get("layout_short"))
         assert json.loads(open(str(tmp_path / name)).read()) == d         # the detailed record travels beside the line
+
+
+def test_compact_line_quotes_no_provenance_the_run_does_not_have(bench, capsys, tmp_path, monkeypatch):
+    """a record whose run found no matching profiles/traffic.json (traffic None) and that names no input layout prints neither"""
+    name, d = _records()[-1]
+    d = json.loads(json.dumps(d))
+    d["roofline"]["traffic"] = None
+    d["config"].pop("layout_short", None)
+    monkeypatch.setenv("TIDDIT_BENCH_DETAIL", str(tmp_path / "d.json"))
+
+    class A:
+        full_line = False
+    bench.emit(d, A)
+    line = json.loads(capsys.readouterr().out.strip())
+    assert line["roofline"]["traffic"] is None and "traffic_source" not in line["roofline"] and "layout" not in line["config"]
 
 
 def test_compact_line_sheds_sections_before_it_breaks_the_budget(bench, capsys, tmp_path, monkeypatch):

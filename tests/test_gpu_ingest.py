@@ -755,6 +755,9 @@ def test_device_buffer_cache_is_bounded_flushed_and_can_be_switched_off(ctx, bam
     h = tiddit_coverage.CoverageHistogram([("c", 1_000_000)], 50, ctx=ctx)        # (its accumulators come from tdt_dev_malloc)
     assert lib.tdt_device_cache_bytes(ctx.handle) == 0
     h.close()
+    lib.tdt_debug_fail_next_malloc(1)                              # ... and with nothing cached the refused allocation is still tried again:
+    h = tiddit_coverage.CoverageHistogram([("c", 1_000_000)], 50, ctx=ctx)        # the hook cannot turn an allocation into a failure
+    h.close()
     lib.tdt_debug_fail_next_malloc(0)
     code = ("import sys; sys.path.insert(0, %r); from tiddit_amd import _native, bamio\n"
             "c = _native.default_context()\n"
@@ -767,35 +770,68 @@ def test_device_buffer_cache_is_bounded_flushed_and_can_be_switched_off(ctx, bam
 
 
 @pytest.mark.parametrize("chunk", [300_000, 2_000_000])
-def test_inflate_ahead_gives_the_same_batches(ctx, bams, chunk):
-    """DeviceBamReader.ahead(): the first half of the next span's push (carried record, inflate + CRC) is enqueued behind the current batch's
-    consumers; the field arrays of every batch equal the plain reader's, the current batch's arrays stay readable after the call, its raw
-    bytes are given up, and a span can only be started once"""
+def test_inflate_ahead_gives_the_same_batches(ctx, bams, chunk, monkeypatch):
+    """Spans are inflated ahead of their turn (tdt_ingest_push_ahead: own stream, own output buffer, the carried record put in front
+    afterwards): the batches equal those of a reader that never starts a span early, the current batch — raw bytes included — stays
+    readable while the next span inflates, and ahead() starts a span once"""
+    monkeypatch.setenv("TIDDIT_INGEST_AHEAD", "0")
     want, _, _, nb, _ = _device_records(bams[1], ctx, chunk)
+    monkeypatch.delenv("TIDDIT_INGEST_AHEAD")
     r = bamio.DeviceBamReader(bams[1], ctx=ctx, chunk=chunk)
     cols = {k: [] for k in FIELDS}
-    started = 0
     for b in r.batches():
         first = b.pos[:4].copy()                                       # (a host copy made BEFORE the call)
-        ok = r.ahead()
-        started += bool(ok)
-        assert r.ahead() is False                                      # one span ahead at most
-        if ok:
-            with pytest.raises(RuntimeError, match="raw bytes were given up"):
-                b.raw
+        r.ahead()
+        assert r.ahead() is False                                      # one span beyond the current one
+        i = len(b) - 1                                                 # the raw bytes are still the batch's own
+        assert b.raw[int(b.rec_off[i]) + 4:int(b.rec_off[i]) + 8].view(np.int32)[0] == b.tid[i]
         for k in FIELDS:
             if k not in ("rec_off", "sa_off"):
                 cols[k].append(getattr(b, k))                          # ... the field arrays are copied AFTER it
         assert np.array_equal(first, cols["pos"][-1][:4])
-    assert r.spans_ahead == started and (started >= nb // 2 or nb <= 2)      # (the reader thread does not always have the next span yet)
+    assert r.spans_ahead >= nb // 2 or nb <= 2                         # (the reader thread does not always have the next span yet)
     r.close()
     for k in cols:
         if k not in ("rec_off", "sa_off"):                             # (batch-relative)
             assert np.array_equal(np.concatenate(cols[k]), want[k]), k
 
 
+@pytest.mark.parametrize("gap", ["0", "256", "65536"])
+def test_carried_record_longer_than_the_gap_is_relocated(ctx, bams, gap, monkeypatch):
+    """the span's output starts `gap` bytes into its buffer and the partial record of the batch before is copied in front of it; a record
+    longer than the gap (here: a gap of 0 / 256 bytes / 64 KB on ordinary records) takes the relocation path — same records either way"""
+    want, sa_w, _, _, _ = _device_records(bams[0], ctx, 1 << 28)
+    monkeypatch.setenv("TIDDIT_INGEST_GAP", gap)
+    got, sa_g, runs_ok, nb, hc = _device_records(bams[0], ctx, 150_000)
+    assert nb > 3 and runs_ok and hc == 0 and sa_g == sa_w
+    for k in FIELDS:
+        if k not in ("rec_off", "sa_off"):
+            assert np.array_equal(got[k], want[k]), k
+
+
+def test_retained_batches_survive_spans_inflating_ahead(ctx, bams):
+    """a retained batch owns its buffers: later spans — begun ahead or not — inflate elsewhere, and every retained batch still reads back
+    as it was when the reader has finished the file"""
+    want, _, _, _, _ = _device_records(bams[1], ctx, 1 << 28)
+    r = bamio.DeviceBamReader(bams[1], ctx=ctx, chunk=400_000)
+    r.retain = True
+    kept = []
+    for b in r.batches():
+        r.ahead()
+        kept.append(b)
+    assert len(kept) > 4 and r.spans_ahead > 0
+    pos = np.concatenate([b.pos for b in kept])
+    flag = np.concatenate([b.flag for b in kept])
+    for b in kept:
+        i = len(b) // 3
+        assert b.raw[int(b.rec_off[i]) + 4:int(b.rec_off[i]) + 8].view(np.int32)[0] == b.tid[i]
+        b.release()
+    r.close()
+    assert np.array_equal(pos, want["pos"]) and np.array_equal(flag, want["flag"])
+
+
 def test_inflate_ahead_misuse_is_refused(ctx, bams):
-    """a push for another span than the one started ahead, a second start, and retaining the batch under the inflate are errors"""
+    """a push for another span than the one begun first, and a third span begun beyond the current batch, are errors"""
     import ctypes
     lib = ctx.lib
     r = bamio.DeviceBamReader(bams[1], ctx=ctx, chunk=300_000)
@@ -803,15 +839,16 @@ def test_inflate_ahead_misuse_is_refused(ctx, bams):
     b = next(it)
     assert len(b) > 0
     for _ in range(200):                                               # until the reader thread has the next span
-        if r.ahead():
+        if r.spans_ahead or r.ahead():
             break
         import time
         time.sleep(0.01)
     assert r.spans_ahead == 1
-    rh = ctypes.c_void_p()
-    assert lib.tdt_ingest_retain(r._h, ctypes.byref(rh)) != 0 and b"inflating over this batch" in lib.tdt_last_error()
     buf = np.zeros(64, dtype=np.uint8)
     n = ctypes.c_size_t(0)
+    span = r._gen["pending"]
+    assert lib.tdt_ingest_push_ahead(r._h, _native.ptr(span[0]), span[1]) == 0          # a second span beyond the current batch: fine
+    assert lib.tdt_ingest_push_ahead(r._h, _native.ptr(span[0]), span[1]) != 0 and b"two spans are already" in lib.tdt_last_error()
     assert lib.tdt_ingest_push(r._h, _native.ptr(buf), 64, 0, ctypes.byref(n)) != 0
     assert b"another span was started" in lib.tdt_last_error()
     it.close()

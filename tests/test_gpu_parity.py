@@ -398,6 +398,31 @@ def test_sort_dbscan(ctx, nat):
         assert np.array_equal(lab[lo:hi], oracle.dbscan_main(d, 300, 3)), b
 
 
+@pytest.mark.parametrize("n,nb,span", [(1, 1, 100), (2, 1, 1), (63, 1, 1 << 30), (4095, 1, 1 << 20), (4096, 3, 1 << 31), (4097, 1, 37),
+                                       (12289, 300, 250_000_000), (200_001, 1, 1 << 31), (1_000_003, 300, 250_000_000), (1_500_000, 1, 5000),
+                                       (300_000, 2, 1 << 9), (70_000, 129, 1 << 24)])
+def test_sort_order_is_the_stable_order_at_every_size(ctx, nat, n, nb, span):
+    """a12 (tiddit_cluster.pyx:152): the one-sweep radix sort behind tdt_sort_dbscan — tile boundaries (4096 pairs), one and many
+    buckets (the bucket index shares a digit with the last position bits), position spans from one digit to 31 bits, heavy ties
+    (their order is the arrival order), a constant column"""
+    rng = np.random.default_rng(n * 31 + nb)
+    cuts = np.sort(rng.integers(0, n + 1, nb - 1)) if nb > 1 else np.zeros(0, dtype=np.int64)
+    off = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    xa = rng.integers(0, span, n).astype(np.int64)
+    if n > 1000:
+        xa[rng.integers(0, n, n // 3)] = xa[0]                           # a third of the column is one value
+    ya = rng.integers(0, 1 << 31, n).astype(np.int64)
+    perm = np.empty(n, dtype=np.uint32)
+    lab = np.empty(n, dtype=np.float64)
+    nat.check(ctx.lib.tdt_sort_dbscan(ctx.handle, nat.ptr(xa), nat.ptr(ya), n, nat.ptr(off), nb, 300.0, 3, nat.ptr(perm), nat.ptr(lab)))
+    ctx.sync()                                                           # (also: no look-back of the sort timed out)
+    want = np.empty(n, dtype=np.int64)
+    for b in range(nb):
+        lo, hi = int(off[b]), int(off[b + 1])
+        want[lo:hi] = lo + np.argsort(xa[lo:hi], kind="stable")
+    assert np.array_equal(perm, want)
+
+
 def test_cluster_columns_int32_signal_order(ctx, nat):
     """tdt_cluster_columns: int32 columns (pageable and pinned), labels in SIGNAL order, x-run counts and final ids per bucket — against
     stable argsort + the oracle per bucket; negative coordinates, a max_pos bound, one bucket and many, duplicates in posA"""

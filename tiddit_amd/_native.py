@@ -29,6 +29,7 @@ _PP = ctypes.POINTER(ctypes.c_void_p)
 SYMBOLS = {
     "tdt_version": (_i, []),
     "tdt_last_error": (ctypes.c_char_p, []),
+    "tdt_build_flags": (ctypes.c_char_p, []),
     "tdt_device_count": (_i, [ctypes.POINTER(_i)]),
     "tdt_ctx_create": (_i, [_i, _PP]),
     "tdt_ctx_destroy": (None, [_P]),
@@ -158,6 +159,10 @@ def load():
                 f = getattr(L, name)
                 f.restype = res
                 f.argtypes = args
+            # a measurement build (ablation / tunable macros, tools/build_variant.sh) is never what the product runs by accident
+            flags = L.tdt_build_flags().decode()
+            if flags and os.environ.get("TIDDIT_ALLOW_VARIANT") != "1":
+                raise ImportError("%s was built with measurement macros (%s); set TIDDIT_ALLOW_VARIANT=1 to load it anyway" % (SO_PATH, flags))
             _lib = L
     return _lib
 

@@ -385,8 +385,6 @@ class DeviceBatch:
             if not self._live:
                 raise RuntimeError("DeviceBatch used after the reader moved on to the next batch")
             if name == "raw":
-                if getattr(self, "_raw_gone", False):
-                    raise RuntimeError("the batch's raw bytes were given up (DeviceBamReader.ahead()): the next span inflates over them")
                 a = np.empty(self._raw_len, dtype=np.uint8)
             elif name == "packed":
                 a = np.empty(self._n, dtype=np.uint64)
@@ -703,26 +701,27 @@ class DeviceBamReader:
         finally:
             spans.close()
 
+    def _begin(self, st, item):
+        """first half of `item`'s push (tdt_ingest_push_ahead): its inflate + CRC kernels go to the reader's inflate streams now"""
+        _native.check(self.ctx.lib.tdt_ingest_push_ahead(self._h, _native.ptr(item[0]), item[1]))
+        self.spans_ahead += 1
+
     def ahead(self):
-        """Called by a consumer of ``batches()`` when it has LAUNCHED everything that reads the current batch's raw bytes on the device:
-        the next span — if the reader thread has it — is taken now and the first half of its push (carried record, inflate + CRC kernels)
-        is enqueued behind those launches (``tdt_ingest_push_ahead``), so that the device runs on into it while the host collects the
-        current batch's results.  From here on only what was enqueued before may read ``batch.dev["raw"]``; the field arrays stay valid
-        until the generator is advanced.  -> whether a span was started.  (Not with ``retain``: a kept batch owns its output buffer.)"""
+        """Start the NEXT span's inflate if the reader thread has the span and it was not started yet.  ``batches()`` does this by itself
+        before it parses the current span (the next span's inflate runs on the reader's own streams, into its own output buffer, and
+        depends on nothing the current batch's consumers do: ``tdt_ingest_push_ahead``); a consumer calls it once more after launching its
+        kernels in case the reader thread had not delivered the span then.  The current batch — field arrays AND raw bytes — stays valid
+        until the generator is advanced.  -> whether a span was started by this call."""
         st = self._gen
-        if st is None or self.retain or st["ahead"] or os.environ.get("TIDDIT_INGEST_AHEAD", "1") == "0":
+        if st is None or st["ahead"] or os.environ.get("TIDDIT_INGEST_AHEAD", "1") == "0":
             return False
         if st["pending"] is False:
             st["pending"] = st["spans"].poll()
         item = st["pending"]
         if item is False or item is None:
             return False
-        buf, consumed = item[0], item[1]
-        _native.check(self.ctx.lib.tdt_ingest_push_ahead(self._h, _native.ptr(buf), consumed))
+        self._begin(st, item)
         st["ahead"] = True
-        if st.get("batch") is not None and not getattr(st["batch"], "_retained", None):
-            st["batch"]._raw_gone = True                      # (a retained batch owns its buffers: nothing inflates over them)
-        self.spans_ahead += 1
         return True
 
     def _batches(self, spans, lib, ctx, nothing):
@@ -743,8 +742,15 @@ class DeviceBamReader:
             if cur is None:
                 break
             buf, consumed, abs0, read_ms = cur
-            st["ahead"] = False                                     # (a span started by ahead() is this one: its push finishes below)
+            begun, st["ahead"] = st["ahead"], False                 # (a span started by ahead() is this one: its push finishes below)
             st["pending"] = spans.poll()                            # span k+1 already read?  (its PCIe copy was started by the reader thread)
+            if os.environ.get("TIDDIT_INGEST_AHEAD", "1") != "0":
+                # span k+1 goes to the inflate streams BEFORE span k is parsed: the chip never leaves the inflate kernel while the record
+                # search, the field decode and the consumer's kernels of batch k run beside it (pushes must follow the order of the begins)
+                if not begun:
+                    self._begin(st, cur)
+                    self.spans_ahead -= 1                           # (not ahead of anything: counted are spans begun before their turn)
+                self.ahead()
             if prev is not None and not getattr(prev, "_retained", None):
                 prev._live = False
             n = ctypes.c_size_t(0)

@@ -89,4 +89,6 @@ int tdt_bz_hop(const uint8_t *p, size_t avail, size_t *bsize, size_t *pay_off, s
 int tdt_bz_block_table(const uint8_t *comp, size_t len, std::vector<BzDesc> &blocks, size_t *produced);
 int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out, bool check_crc,
                   unsigned *d_status, unsigned *d_summary);
+int tdt_bz_launch_on(tdt_ctx *ctx, hipStream_t st, int reserve, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks,
+                     unsigned char *d_out, bool check_crc, unsigned *d_status, unsigned *d_summary);
 const char *tdt_bz_err_name(unsigned e);

@@ -16,6 +16,71 @@
 //     anything outside the window (unsorted input, very long reads) straight to HBM atomics;
 //   * the window is spilled once with coalesced 64-bit global atomics, zero bins skipped.
 // A final elementwise pass turns int64 accumulators into the float64 bins.
+// ---- measurement builds declare themselves (tdt_build_flags): the macros this file was compiled with, before any default is set
+extern const char *const tdt_variant_coverage;
+const char *const tdt_variant_coverage = ""
+#ifdef COV_EXP_LOADONLY
+    " COV_EXP_LOADONLY"
+#endif
+#ifdef COV_EXP_NOATOMIC
+    " COV_EXP_NOATOMIC"
+#endif
+#ifdef COV_EXP_NOSCAN
+    " COV_EXP_NOSCAN"
+#endif
+#ifdef COV_M1X_NOK
+    " COV_M1X_NOK"
+#endif
+#ifdef COV_M1X_NOLAST
+    " COV_M1X_NOLAST"
+#endif
+#ifdef COV_M1X_NOSPILL
+    " COV_M1X_NOSPILL"
+#endif
+#ifdef COV_M1X_SPILLKIND
+    " COV_M1X_SPILLKIND"
+#endif
+#ifdef COV_M1_SCANK
+    " COV_M1_SCANK"
+#endif
+#ifdef COV_M1_SKIPZERO
+    " COV_M1_SKIPZERO"
+#endif
+#ifdef COV_M1_SPILL_R4
+    " COV_M1_SPILL_R4"
+#endif
+#ifdef COV_MIN_WAVES
+    " COV_MIN_WAVES"
+#endif
+#ifdef COV_MIN_WAVES1
+    " COV_MIN_WAVES1"
+#endif
+#ifdef COV_MIN_WAVES1_4
+    " COV_MIN_WAVES1_4"
+#endif
+#ifdef COV_MIN_WAVES4
+    " COV_MIN_WAVES4"
+#endif
+#ifdef COV_PF2
+    " COV_PF2"
+#endif
+#ifdef COV_RPL
+    " COV_RPL"
+#endif
+#ifdef COV_RPL1
+    " COV_RPL1"
+#endif
+#ifdef COV_SPARES1
+    " COV_SPARES1"
+#endif
+#ifdef COV_WIN
+    " COV_WIN"
+#endif
+#ifdef COV_WIN1
+    " COV_WIN1"
+#endif
+    ;
+
 #include "tdt_common.h"
 
 #include <algorithm>
@@ -91,26 +156,28 @@ __device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {  /
 // because the add is in place.  The three values are interleaved so that every DPP read of a VGPR
 // is >= 4 instructions behind the VALU write of that VGPR (the DPP read-after-write hazard needs 2
 // wait states, which inline asm does not get from the compiler).
+// The whole scan is ONE asm statement that opens with the wait states: the compiler can then place nothing (a v_mov that materialises an
+// operand, a v_cndmask of the caller) between the s_nop and the first DPP read, nor between two steps.
+#define COV_DPP_SHR1 "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define COV_DPP_SHR2 "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define COV_DPP_SHR4 "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define COV_DPP_SHR8 "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+#define COV_DPP_BC15 "row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define COV_DPP_BC31 "row_bcast:31 row_mask:0xc bank_mask:0xf"
+#define COV_SCAN_ALL(STEP) \
+    "s_nop 1\n\t" STEP(COV_DPP_SHR1) STEP(COV_DPP_SHR2) STEP(COV_DPP_SHR4) STEP(COV_DPP_SHR8) STEP(COV_DPP_BC15) STEP(COV_DPP_BC31) "s_nop 1"
 #define COV_SCAN_STEP(CTRL)                                                                     \
-    asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\t"                                \
-                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"                          \
-                 "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n\t"                                \
-                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL "\n\t"                          \
-                 "v_add_co_u32_dpp %4, vcc, %4, %4 " CTRL "\n\t"                                \
-                 "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " CTRL                                 \
-                 : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2)::"vcc")
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\t"                                             \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"                                       \
+    "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n\t"                                             \
+    "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL "\n\t"                                       \
+    "v_add_co_u32_dpp %4, vcc, %4, %4 " CTRL "\n\t"                                             \
+    "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " CTRL "\n\t"
 
 __device__ __forceinline__ void wave_scan3_u64(unsigned long long &a0, unsigned long long &a1, unsigned long long &a2) {
     unsigned l0 = (unsigned)a0, h0 = (unsigned)(a0 >> 32), l1 = (unsigned)a1, h1 = (unsigned)(a1 >> 32),
              l2 = (unsigned)a2, h2 = (unsigned)(a2 >> 32);
-    asm volatile("s_nop 1" ::: "memory");  // the values were just written by plain VALU
-    COV_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    COV_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
-    asm volatile("s_nop 1" ::: "memory");
+    asm volatile(COV_SCAN_ALL(COV_SCAN_STEP) : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1), "+v"(l2), "+v"(h2)::"vcc", "memory");   // (the values were just written by plain VALU)
     a0 = ((unsigned long long)h0 << 32) | l0;
     a1 = ((unsigned long long)h1 << 32) | l1;
     a2 = ((unsigned long long)h2 << 32) | l2;
@@ -142,43 +209,27 @@ __device__ __forceinline__ unsigned cov_select(unsigned long long m, unsigned if
 
 // the same for two values (each DPP read is still three instructions behind the write of its register)
 #define COV_SCAN2_STEP(CTRL)                                                                    \
-    asm volatile("v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\t"                                \
-                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"                          \
-                 "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n\t"                                \
-                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL                                 \
-                 : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1)::"vcc")
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\t"                                             \
+    "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"                                       \
+    "v_add_co_u32_dpp %2, vcc, %2, %2 " CTRL "\n\t"                                             \
+    "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " CTRL "\n\t"
 
 __device__ __forceinline__ void wave_scan2_u64(unsigned long long &a0, unsigned long long &a1) {
     unsigned l0 = (unsigned)a0, h0 = (unsigned)(a0 >> 32), l1 = (unsigned)a1, h1 = (unsigned)(a1 >> 32);
-    asm volatile("s_nop 1" ::: "memory");  // the values were just written by plain VALU
-    COV_SCAN2_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN2_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN2_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN2_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN2_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    COV_SCAN2_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
-    asm volatile("s_nop 1" ::: "memory");
+    asm volatile(COV_SCAN_ALL(COV_SCAN2_STEP) : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1)::"vcc", "memory");   // (the values were just written by plain VALU)
     a0 = ((unsigned long long)h0 << 32) | l0;
     a1 = ((unsigned long long)h1 << 32) | l1;
 }
 
 // four 32-bit values at once (each DPP read is three instructions behind the write of its register): the window resolve of MODE 1
 #define COV_SCAN4I_STEP(CTRL)                                                                   \
-    asm volatile("v_add_u32_dpp %0, %0, %0 " CTRL "\n\t"                                        \
-                 "v_add_u32_dpp %1, %1, %1 " CTRL "\n\t"                                        \
-                 "v_add_u32_dpp %2, %2, %2 " CTRL "\n\t"                                        \
-                 "v_add_u32_dpp %3, %3, %3 " CTRL                                                \
-                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3))
+    "v_add_u32_dpp %0, %0, %0 " CTRL "\n\t"                                                     \
+    "v_add_u32_dpp %1, %1, %1 " CTRL "\n\t"                                                     \
+    "v_add_u32_dpp %2, %2, %2 " CTRL "\n\t"                                                     \
+    "v_add_u32_dpp %3, %3, %3 " CTRL "\n\t"
 
 __device__ __forceinline__ void wave_scan4_i32(int &p0, int &p1, int &p2, int &p3) {
-    asm volatile("s_nop 1" ::: "memory");
-    COV_SCAN4I_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN4I_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN4I_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN4I_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0");
-    COV_SCAN4I_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    COV_SCAN4I_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
-    asm volatile("s_nop 1" ::: "memory");
+    asm volatile(COV_SCAN_ALL(COV_SCAN4I_STEP) : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)::"memory");
 }
 
 // 16 bytes at an LDS byte address held in a register (ds_read_b128, no generic-pointer arithmetic)

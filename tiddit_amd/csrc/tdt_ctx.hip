@@ -2,6 +2,7 @@
 #include "tdt_common.h"
 
 #include <atomic>
+#include <string>
 
 static thread_local char g_err[1024] = "";
 static std::atomic<int> live_contexts[64];
@@ -15,6 +16,20 @@ void tdt_set_error(const char *fmt, ...) {
 
 extern "C" const char *tdt_last_error(void) { return g_err; }
 extern "C" int tdt_version(void) { return 100; }
+
+// The measurement macros (ablations: COV_M1X_*, B2_EXP_*, DT_PERSIST ...; tunables given on the command line: COV_WIN, B2_OCC, RS_ROUNDS ...)
+// the library's translation units were compiled with — "" for the product build.  Two of the ablations produce wrong results by design;
+// the Python binding refuses a library that reports any unless TIDDIT_ALLOW_VARIANT=1 (tools/ab_*.sh set it).
+extern const char *const tdt_variant_coverage, *const tdt_variant_dbscan, *const tdt_variant_inflate, *const tdt_variant_inflate2,
+    *const tdt_variant_ingest, *const tdt_variant_sort;
+extern "C" const char *tdt_build_flags(void) {
+    static const std::string all = [] {
+        std::string s;
+        for (const char *p : {tdt_variant_coverage, tdt_variant_dbscan, tdt_variant_inflate, tdt_variant_inflate2, tdt_variant_ingest, tdt_variant_sort}) s += p;
+        return s.empty() ? s : s.substr(1);
+    }();
+    return all.c_str();
+}
 
 extern "C" int tdt_device_count(int *count) {
     if (!count) return TDT_E_ARG;
@@ -84,12 +99,13 @@ hipError_t tdt_dev_malloc(void **p, size_t bytes) {
     int pending = fail_next_malloc.load();
     while (pending > 0 && !fail_next_malloc.compare_exchange_weak(pending, pending - 1)) {
     }
-    if (pending <= 0) e = hipMalloc(p, bytes);
+    const bool injected = pending > 0;
+    if (!injected) e = hipMalloc(p, bytes);
     if (e == hipSuccess) return e;
     (void)hipGetLastError();
     int dev = -1;
     (void)hipGetDevice(&dev);
-    if (tdt_dev_cache_flush(dev) == 0) return e;        // nothing of ours was in the way
+    if (tdt_dev_cache_flush(dev) == 0 && !injected) return e;        // nothing of ours was in the way (an injected refusal is always tried again)
     e = hipMalloc(p, bytes);
     if (e != hipSuccess) (void)hipGetLastError();
     return e;

@@ -11,6 +11,32 @@
 //            s > 1 becomes (R-1) + #extra sub-runs of earlier x-clusters + (s-1).
 // All of it is integer compares, prefix sums and a segmented sort: HBM/latency-bound, no MFMA.
 // Several independent (chrA,chrB) buckets are processed by the same launches (ids restart per bucket).
+// ---- measurement builds declare themselves (tdt_build_flags): the macros this file was compiled with, before any default is set
+extern const char *const tdt_variant_dbscan;
+const char *const tdt_variant_dbscan = ""
+#ifdef DB_BUCKET_PERLANE
+    " DB_BUCKET_PERLANE"
+#endif
+#ifdef DT_PERSIST
+    " DT_PERSIST"
+#endif
+#ifdef DT_PROF
+    " DT_PROF"
+#endif
+#ifdef DT_FTPB
+    " DT_FTPB"
+#endif
+#ifdef DT_NW
+    " DT_NW"
+#endif
+#ifdef DT_THREADS
+    " DT_THREADS"
+#endif
+#ifdef DBF_THREADS
+    " DBF_THREADS"
+#endif
+    ;
+
 #include "tdt_common.h"
 #include <chrono>
 

@@ -15,6 +15,14 @@
 //     reads what earlier stores of the same wave wrote;
 //   * every loop is bounded by ISIZE / the compressed length, a malformed stream sets the block's status and stops.
 // A second kernel checks each block's CRC32 (lane-parallel table CRC + GF(2) combine).
+// ---- measurement builds declare themselves (tdt_build_flags): the macros this file was compiled with, before any default is set
+extern const char *const tdt_variant_inflate;
+const char *const tdt_variant_inflate = ""
+#ifdef BZ_STATS
+    " BZ_STATS"
+#endif
+    ;
+
 #include "tdt_common.h"
 
 #define BZ_TB_LL 10
@@ -607,18 +615,20 @@ const char *tdt_bz_err_name(unsigned e) {
 
 // Device-resident form: d_comp holds `comp_len` bytes of whole BGZF blocks followed by >= 1024 readable bytes of padding,
 // d_blocks the block table; inflates into d_out and verifies CRC32.  Leaves the per-block status in scratch.
-void tdt_bz_launch_lanes(hipStream_t st, int num_cu, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,
-                         unsigned *d_status, unsigned *d_next_block);   // tdt_inflate2.hip
+void tdt_bz_launch_lanes(hipStream_t st, int num_cu, int reserve, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks,
+                         unsigned char *d_out, unsigned *d_status, unsigned *d_next_block);   // tdt_inflate2.hip
 
-int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out, bool check_crc,
-                     unsigned *d_status, unsigned *d_summary) {
-    hipStream_t st = ctx->stream;
+// `st`: the stream the kernels go to; `reserve`: workgroups per CU the persistent inflate grid leaves free (0: the grid is what the chip
+// holds — right when nothing else has to run beside it; the ingest, whose record search / decode / consumer kernels run on another stream
+// while the next span inflates, keeps one)
+int tdt_bz_launch_on(tdt_ctx *ctx, hipStream_t st, int reserve, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks,
+                     unsigned char *d_out, bool check_crc, unsigned *d_status, unsigned *d_summary) {
     TDT_HIP(hipMemsetAsync(d_summary, 0xff, 4, st));
     TDT_HIP(hipMemsetAsync(d_summary + 1, 0, 8, st));            // (+ the lanes kernel's block counter, d_summary[2])
     const unsigned grid = (unsigned)((nblocks + BZ_WAVES - 1) / BZ_WAVES);
     const bool sequential = getenv("TIDDIT_INFLATE_SEQ") != nullptr;   // the one-symbol-at-a-time kernel of this file
     if (sequential) hipLaunchKernelGGL(bgzf_inflate, dim3(grid), dim3(64 * BZ_WAVES), 0, st, d_comp, d_blocks, (int)nblocks, d_out, d_status);
-    else tdt_bz_launch_lanes(st, ctx->num_cu, d_comp, d_blocks, nblocks, d_out, d_status, d_summary + 2);
+    else tdt_bz_launch_lanes(st, ctx->num_cu, reserve, d_comp, d_blocks, nblocks, d_out, d_status, d_summary + 2);
     TDT_CHECK_LAUNCH();
     if (check_crc) {
         hipLaunchKernelGGL(bgzf_crc32, dim3((unsigned)((nblocks + 3) / 4)), dim3(256), 0, st, d_blocks, (int)nblocks, d_out, d_status, crc_powers_1024());
@@ -627,6 +637,11 @@ int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blo
     hipLaunchKernelGGL(bgzf_status_reduce, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, d_status, (int)nblocks, d_summary);
     TDT_CHECK_LAUNCH();
     return TDT_OK;
+}
+
+int tdt_bz_launch(tdt_ctx *ctx, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out, bool check_crc,
+                     unsigned *d_status, unsigned *d_summary) {
+    return tdt_bz_launch_on(ctx, ctx->stream, 0, d_comp, d_blocks, nblocks, d_out, check_crc, d_status, d_summary);
 }
 
 

@@ -14,6 +14,47 @@
 //     (9 bits literal/length, 8 bits distance); a symbol whose code is longer than the LUT stops the chain and is decoded
 //     by the scalar canonical walk;
 //   * every loop is bounded by ISIZE / the compressed length; damage sets the block's status.
+// ---- measurement builds declare themselves (tdt_build_flags): the macros this file was compiled with, before any default is set
+extern const char *const tdt_variant_inflate2;
+const char *const tdt_variant_inflate2 = ""
+#ifdef B2_EARLYM
+    " B2_EARLYM"
+#endif
+#ifdef B2_EXP_NOLIT
+    " B2_EXP_NOLIT"
+#endif
+#ifdef B2_HOP2
+    " B2_HOP2"
+#endif
+#ifdef B2_NOPERSIST
+    " B2_NOPERSIST"
+#endif
+#ifdef B2_OCC
+    " B2_OCC"
+#endif
+#ifdef B2_PHASED
+    " B2_PHASED"
+#endif
+#ifdef B2_PIPE
+    " B2_PIPE"
+#endif
+#ifdef B2_PROF
+    " B2_PROF"
+#endif
+#ifdef B2_STATS
+    " B2_STATS"
+#endif
+#ifdef B2_TB_D
+    " B2_TB_D"
+#endif
+#ifdef B2_TB_LL
+    " B2_TB_LL"
+#endif
+#ifdef B2_WAVES
+    " B2_WAVES"
+#endif
+    ;
+
 #include "tdt_common.h"
 
 #include <algorithm>
@@ -817,12 +858,13 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
 #endif
 }
 
-void tdt_bz_launch_lanes(hipStream_t st, int num_cu, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks, unsigned char *d_out,
-                         unsigned *d_status, unsigned *d_next_block) {
+void tdt_bz_launch_lanes(hipStream_t st, int num_cu, int reserve, const unsigned char *d_comp, const BzDesc *d_blocks, size_t nblocks,
+                         unsigned char *d_out, unsigned *d_status, unsigned *d_next_block) {
 #ifdef B2_NOPERSIST
     const size_t resident = ~(size_t)0;
 #else
-    const size_t resident = (size_t)num_cu * (4 * B2_OCC / B2_WAVES);                  // workgroups the chip holds at 8 waves per SIMD
+    const int per_cu = 4 * B2_OCC / B2_WAVES;                                          // workgroups a CU holds at 8 waves per SIMD
+    const size_t resident = (size_t)num_cu * (size_t)(reserve > 0 && reserve < per_cu ? per_cu - reserve : per_cu);
 #endif
     const unsigned grid = (unsigned)std::min(resident, (nblocks + B2_WAVES - 1) / B2_WAVES);
     hipLaunchKernelGGL(bgzf_inflate_lanes, dim3(grid), dim3(64 * B2_WAVES), 0, st, d_comp, d_blocks, (int)nblocks, d_out, d_status, d_next_block);

@@ -15,6 +15,17 @@
 //   4. bam_decode_fields: one WAVE per accepted segment, one lane per record (its start comes from `rel`), writes the same
 //      thirteen arrays as tdt_bam_decode (bam_endpos for `end`, the SA:Z offset, first/last CIGAR op, ...); after a host
 //      chase bam_decode_fields_serial walks the records of a segment with one lane instead.
+// ---- measurement builds declare themselves (tdt_build_flags): the macros this file was compiled with, before any default is set
+extern const char *const tdt_variant_ingest;
+const char *const tdt_variant_ingest = ""
+#ifdef ING_GAP
+    " ING_GAP"
+#endif
+#ifdef ING_SEG
+    " ING_SEG"
+#endif
+    ;
+
 #include "tdt_common.h"
 #include <mutex>
 
@@ -294,12 +305,43 @@ __global__ void bam_tid_edges(const int32_t *__restrict__ tid, size_t n, unsigne
     }
 }
 
+#ifndef ING_GAP
+#define ING_GAP (1u << 20)
+#endif
+
 struct tdt_ingest {
     tdt_ctx *ctx = nullptr;
     int n_ref = 0;
-    tdt_buf comp, table, out, seg, soa;            // device buffers (grow only)
-    // compressed blocks of spans copied ahead by tdt_ingest_prefetch: two slots, so that the copy of span k+1 can be issued
-    // while span k (prefetched earlier) has not been pushed yet
+    tdt_buf seg, soa;                              // device buffers (grow only)
+    // A span's inflate no longer depends on the batch before it.  Span s lives in slot[s % NSLOT]: its compressed blocks, its block table
+    // and its OUTPUT, which the inflate kernel writes `gap` bytes into the buffer — the partial record the previous batch ended with (known
+    // only when that batch has been parsed) is copied in front of it afterwards, by the second half of the push.  Three slots: while batch k
+    // is being parsed and consumed on the launch stream, span k+1 inflates and the consumers of batch k-1 may still be running.
+    enum { NSLOT = 3 };
+    struct Slot {
+        tdt_buf out, comp, table;
+        void *h_table = nullptr;                   // pinned staging of the block table when the reader thread did not bring it along
+        size_t h_table_cap = 0;
+        unsigned *h_summary = nullptr;             // pinned: {first failed block, failed blocks} of the span
+        hipEvent_t inflated = nullptr;             // inflate stream: the span is inflated and checked, its status word is on the host
+        hipEvent_t released = nullptr;             // launch stream: everything that reads the batch that lived here was enqueued before it
+        bool released_set = false;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;   // inflate stream: around the span's copy (when the push makes it), behind inflate + CRC
+        hipEvent_t hit_t0 = nullptr, hit_t1 = nullptr;         // the prefetch slot's events around the copy it made
+        const uint8_t *host = nullptr;             // the span begun here and not pushed yet (null: none)
+        size_t len = 0, produced = 0, nb = 0;
+        unsigned *d_status = nullptr;
+        double table_ms = 0;
+        bool prefetched = false;
+    } slot[NSLOT];
+    unsigned long long seq_begun = 0, seq_pushed = 0;   // spans whose first half was enqueued / whose push has run
+    int cur = -1;                                  // slot of the current batch (-1: none yet)
+    size_t lead = 0;                               // the current batch starts at slot[cur].out + lead  (= gap - carried bytes)
+    size_t gap = ING_GAP;
+    tdt_buf carrybuf;                              // the partial record behind the current batch
+    hipStream_t inf_stream[2] = {nullptr, nullptr};     // spans alternate: the head of span k+1 fills the wave slots the tail of span k leaves
+    int reserve = 1;                               // workgroups per CU the inflate grid leaves to the launch stream's kernels
+    // compressed blocks of spans copied ahead by tdt_ingest_prefetch: the copy of span k+1 can be issued while span k has not been begun
     struct Prefetch {
         tdt_buf buf;
         const uint8_t *host = nullptr;             // what the slot holds: host pointer / length of the span (null = free)
@@ -308,12 +350,11 @@ struct tdt_ingest {
         hipEvent_t t0 = nullptr, t1 = nullptr;     // around the copy, for tdt_ingest_timing
         std::vector<BzDesc> blocks;                // the span's BGZF block table, built by the thread that read it ...
         size_t produced = 0;
-        tdt_buf table;                             // ... and already on the device (same layout as tdt_ingest::table)
-    } pf[3];                                       // spans the reader can be ahead by: queued, held back by the full queue, taken but not pushed yet
+        tdt_buf table;                             // ... and already on the device (same layout as Slot::table)
+    } pf[3];                                       // spans the reader can be ahead by: queued, held back by the full queue, taken but not begun yet
     std::mutex pf_mu;                              // the slots are filled by the reader thread (tdt_ingest_prefetch) and emptied by the pushing one
-    hipEvent_t hit_t0 = nullptr, hit_t1 = nullptr; // the timing events of the slot the last push consumed
     tdt_buf pin;                                   // pinned staging for the segment table / edges
-    size_t carry = 0, tail_off = 0;                // bytes of the partial record at out[tail_off..), moved to the front by the next push
+    size_t carry = 0;                              // bytes of the partial record in carrybuf
     size_t out_len = 0;                            // carry + inflated bytes of the current batch
     size_t n_records = 0, rec_cap = 0;
     IngestOut O{};
@@ -321,20 +362,10 @@ struct tdt_ingest {
     bool edges_overflow = false;
     bool failed = false;                           // a push returned an error: the stream position is undefined from then on
     size_t host_chases = 0;                        // batches whose record chain had to be chased on the host
-    // where the last push spent its time (tdt_ingest_timing): HIP events on the launch / copy stream + host clocks
-    hipEvent_t tev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // 0-1 h2d, 1-2 inflate+crc, 2-3 find, 4-5 decode, 6-7 prefetch copy
-    double t_table_ms = 0, t_chain_ms = 0, t_wall_ms = 0;
-    bool t_prefetched = false, t_have_decode = false;
-    // The first half of a push — the span's copy, its block table and the inflate + CRC kernels — can be ENQUEUED AHEAD
-    // (tdt_ingest_push_ahead) behind the kernels that still read the current batch; the push of exactly that span then starts at the wait
-    // for its status word.  What the second half needs from the first:
-    struct Begun {
-        bool valid = false;
-        const uint8_t *comp = nullptr;
-        size_t len = 0, produced = 0, carry = 0, T = 0, nb = 0;
-        unsigned *d_status = nullptr;
-    } begun;
-    unsigned *h_summary = nullptr;                 // pinned: {first failed block, failed blocks} of the batch being inflated
+    // where the last push spent its time (tdt_ingest_timing): the slot's events on the inflate stream, these on the launch stream, host clocks
+    hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};   // 0-1 record search, 2-3 field decode
+    double t_chain_ms = 0, t_wall_ms = 0;
+    bool t_have_decode = false, t_have_find = false;
 };
 
 static double ing_now_ms() {
@@ -499,6 +530,7 @@ extern "C" int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out) {
         tdt_set_error("tdt_ingest_create: bad argument");
         return TDT_E_ARG;
     }
+    TDT_HIP(hipSetDevice(ctx->device));
     tdt_ingest *g = new tdt_ingest();
     g->ctx = ctx;
     g->n_ref = n_ref;
@@ -507,10 +539,31 @@ extern "C" int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out) {
             (void)hipGetLastError();
             e = nullptr;
         }
-    if (hipHostMalloc((void **)&g->h_summary, 64, hipHostMallocDefault) != hipSuccess) {
+    if (const char *e = getenv("TIDDIT_INGEST_GAP")) {               // (tests: a gap smaller than a record exercises the relocation path)
+        const long long v = atoll(e);
+        if (v >= 0) g->gap = ((size_t)v + 255) & ~(size_t)255;
+    }
+    if (const char *e = getenv("TIDDIT_INFLATE_RESERVE")) g->reserve = atoi(e) < 0 ? 0 : atoi(e) > 7 ? 7 : atoi(e);
+    unsigned *h_sum = nullptr;
+    bool ok = hipHostMalloc((void **)&h_sum, 64 * tdt_ingest::NSLOT, hipHostMallocDefault) == hipSuccess;
+    // the inflate streams: lowest priority, so that the kernels of the launch stream (record search, field decode, the caller's coverage
+    // and signal kernels) get the wave slots that free up while a span inflates
+    int prio_lo = 0, prio_hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) (void)hipGetLastError(), prio_lo = 0;
+    for (auto &st : g->inf_stream) ok = ok && hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_lo) == hipSuccess;
+    for (int i = 0; i < tdt_ingest::NSLOT && ok; i++) {
+        auto &S = g->slot[i];
+        S.h_summary = h_sum + 16 * i;
+        ok = ok && hipEventCreateWithFlags(&S.inflated, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&S.released, hipEventDisableTiming) == hipSuccess;
+        for (hipEvent_t *e : {&S.e0, &S.e1, &S.e2})
+            if (hipEventCreate(e) != hipSuccess) (void)hipGetLastError(), *e = nullptr;
+    }
+    if (!ok) {
         (void)hipGetLastError();
-        delete g;
-        tdt_set_error("tdt_ingest_create: pinned allocation failed");
+        if (h_sum && !g->slot[0].h_summary) (void)hipHostFree(h_sum);
+        (void)tdt_ingest_destroy(g);
+        tdt_set_error("tdt_ingest_create: streams / events / pinned memory could not be created");
         return TDT_E_NOMEM;
     }
     *out = g;
@@ -520,6 +573,8 @@ extern "C" int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out) {
 extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
     if (!g) return TDT_OK;
     (void)hipSetDevice(g->ctx->device);
+    for (auto &st : g->inf_stream)
+        if (st) (void)hipStreamSynchronize(st);
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipStreamSynchronize(g->ctx->copy_stream);
     for (auto &p : g->pf) {
@@ -527,14 +582,20 @@ extern "C" int tdt_ingest_destroy(tdt_ingest *g) {
         if (p.t0) (void)hipEventDestroy(p.t0);
         if (p.t1) (void)hipEventDestroy(p.t1);
     }
-    if (g->hit_t0) (void)hipEventDestroy(g->hit_t0);
-    if (g->hit_t1) (void)hipEventDestroy(g->hit_t1);
     for (auto &e : g->tev)
         if (e) (void)hipEventDestroy(e);
-    for (tdt_buf *b : {&g->comp, &g->pf[0].buf, &g->pf[1].buf, &g->pf[2].buf, &g->pf[0].table, &g->pf[1].table, &g->pf[2].table, &g->table, &g->out, &g->seg, &g->soa})
-        ing_dev_free(g->ctx->device, b->p, b->cap);                  // (both streams are idle: synchronised above)
+    for (auto &S : g->slot) {
+        for (hipEvent_t e : {S.inflated, S.released, S.e0, S.e1, S.e2, S.hit_t0, S.hit_t1})
+            if (e) (void)hipEventDestroy(e);
+        for (tdt_buf *b : {&S.out, &S.comp, &S.table}) ing_dev_free(g->ctx->device, b->p, b->cap);     // (every stream is idle: synchronised above)
+        if (S.h_table) (void)hipHostFree(S.h_table);
+    }
+    for (tdt_buf *b : {&g->pf[0].buf, &g->pf[1].buf, &g->pf[2].buf, &g->pf[0].table, &g->pf[1].table, &g->pf[2].table, &g->seg, &g->soa, &g->carrybuf})
+        ing_dev_free(g->ctx->device, b->p, b->cap);
+    for (auto &st : g->inf_stream)
+        if (st) (void)hipStreamDestroy(st);
     if (g->pin.p) (void)hipHostFree(g->pin.p);
-    if (g->h_summary) (void)hipHostFree(g->h_summary);
+    if (g->slot[0].h_summary) (void)hipHostFree(g->slot[0].h_summary);
     delete g;
     return TDT_OK;
 }
@@ -644,18 +705,18 @@ extern "C" int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_
     return rc;
 }
 
-// First half of a push: the span's bytes and block table on the device (taken from the prefetch slot that holds them, or copied here),
-// the carried partial record at the front of the output, the inflate + CRC kernels and the copy of their status word — all ENQUEUED on the
-// launch stream, nothing waited for.  Leaves g->begun for ing_push.
+// First half of a push: the span's bytes and block table on the device (taken from the prefetch slot that holds them, or copied here), the
+// inflate + CRC kernels and the copy of their status word — all ENQUEUED on one of the reader's inflate streams, nothing waited for, and
+// nothing of it depends on the batch before: the output goes `gap` bytes into the slot's own buffer (ing_push puts the carried bytes in front).
 static int ing_push_begin(tdt_ingest *g, const uint8_t *comp, size_t len) {
     tdt_ctx *ctx = g->ctx;
     TDT_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    const unsigned long long seq = g->seq_begun;
+    tdt_ingest::Slot &S = g->slot[seq % tdt_ingest::NSLOT];
+    hipStream_t sb = g->inf_stream[seq & 1];
     std::vector<BzDesc> blocks;
     size_t produced = 0;
     const double t_begin = ing_now_ms();
-    g->t_have_decode = false;
-    g->t_prefetched = false;
     // a span the reader thread prefetched brings its block table along (host copy + device copy)
     tdt_ingest::Prefetch *hit = nullptr;
     bool table_on_device = false;
@@ -674,98 +735,103 @@ static int ing_push_begin(tdt_ingest *g, const uint8_t *comp, size_t len) {
         rc = tdt_bz_block_table(comp, len, blocks, &produced);
         if (rc) return rc;
     }
-    g->t_table_ms = ing_now_ms() - t_begin;
-    g->t_chain_ms = 0;
-    const size_t carry = g->carry;
-    const size_t T = carry + produced;
-    if (T >= 0xfffffff0ull) {
-        tdt_set_error("tdt_ingest_push: batch inflates to %zu bytes; feed at most 3 GiB of records per call", T);
+    S.table_ms = ing_now_ms() - t_begin;
+    S.prefetched = false;
+    if (g->gap + produced >= 0xfffffff0ull - (64u << 20)) {
+        tdt_set_error("tdt_ingest_push: batch inflates to %zu bytes; feed at most 3 GiB of records per call", produced);
         return TDT_E_RANGE;
     }
-    // (block offsets stay relative to the batch's own output: the kernels get the output base shifted by the carried bytes)
-    if (carry && g->tail_off) TDT_HIP(hipMemcpyAsync(g->out.p, (char *)g->out.p + g->tail_off, carry, hipMemcpyDeviceToDevice, st));
-    g->tail_off = 0;
-    rc = ing_grow(g, g->out, T + 256, true);                      // keeps the carried bytes at the front
+    // the batch that lived in this slot three spans ago: whatever reads it was enqueued on the launch stream before `released`
+    if (S.released_set) TDT_HIP(hipStreamWaitEvent(sb, S.released, 0));
+    S.released_set = false;
+    rc = ing_grow(g, S.out, g->gap + produced + 256);
     if (rc) return rc;
-    unsigned char *d_out = (unsigned char *)g->out.p;
     const size_t nb = blocks.size();
     unsigned *d_status = nullptr;
-    g->h_summary[0] = g->h_summary[1] = 0;
+    S.h_summary[0] = S.h_summary[1] = 0;
+    if (S.e0) (void)hipEventRecord(S.e0, sb);
     if (nb) {
         const size_t comp_pad = (len + 4096 + 255) & ~(size_t)255;
-        rc = ing_grow(g, g->comp, comp_pad);
+        rc = ing_grow(g, S.comp, comp_pad);
         if (rc) return rc;
         const size_t tab = (nb * sizeof(BzDesc) + 255) & ~(size_t)255, stb = (nb * 4 + 255) & ~(size_t)255;
-        rc = ing_grow(g, g->table, tab + stb + 256);
+        rc = ing_grow(g, S.table, tab + stb + 256);
         if (rc) return rc;
-        BzDesc *d_blocks = (BzDesc *)g->table.p;
-        d_status = (unsigned *)((char *)g->table.p + tab);
+        BzDesc *d_blocks = (BzDesc *)S.table.p;
+        d_status = (unsigned *)((char *)S.table.p + tab);
         unsigned *d_summary = (unsigned *)((char *)d_status + stb);
         if (table_on_device && hit && hit->table.cap < tab + stb + 256) table_on_device = false;       // (cannot happen: sized alike)
-        if (g->tev[0]) (void)hipEventRecord(g->tev[0], st);
         bool was_hit = false;
         {
             std::lock_guard<std::mutex> lock(g->pf_mu);
             if (hit && (hit->host != comp || hit->len != len || hit->buf.cap < comp_pad)) hit = nullptr;
             if (hit) {
-                std::swap(g->comp, hit->buf);                     // the span is already on the device (copy stream)
+                // (what goes back into the prefetch slot is free: the span that used these buffers, three spans ago, has been pushed)
+                std::swap(S.comp, hit->buf);                      // the span is already on the device (copy stream)
                 if (table_on_device) {
-                    std::swap(g->table, hit->table);              // ... and so is its block table
-                    d_blocks = (BzDesc *)g->table.p;
-                    d_status = (unsigned *)((char *)g->table.p + tab);
+                    std::swap(S.table, hit->table);               // ... and so is its block table
+                    d_blocks = (BzDesc *)S.table.p;
+                    d_status = (unsigned *)((char *)S.table.p + tab);
                     d_summary = (unsigned *)((char *)d_status + stb);
                 }
-                TDT_HIP(hipStreamWaitEvent(st, hit->done, 0));
-                std::swap(g->hit_t0, hit->t0);                    // (the slot gets the previous pair back: events are reused)
-                std::swap(g->hit_t1, hit->t1);
+                TDT_HIP(hipStreamWaitEvent(sb, hit->done, 0));
+                std::swap(S.hit_t0, hit->t0);                     // (the slot gets the previous pair back: events are reused)
+                std::swap(S.hit_t1, hit->t1);
                 if (!hit->t0) (void)hipEventCreate(&hit->t0);
                 if (!hit->t1) (void)hipEventCreate(&hit->t1);
                 hit->host = nullptr;
-                g->t_prefetched = true;
+                S.prefetched = true;
                 was_hit = true;
             }
         }
         if (!was_hit) {
-            TDT_HIP(hipMemcpyAsync(g->comp.p, comp, len, hipMemcpyHostToDevice, st));
-            TDT_HIP(hipMemsetAsync((char *)g->comp.p + len, 0, comp_pad - len, st));
+            TDT_HIP(hipMemcpyAsync(S.comp.p, comp, len, hipMemcpyHostToDevice, sb));
+            TDT_HIP(hipMemsetAsync((char *)S.comp.p + len, 0, comp_pad - len, sb));
         }
-        if (g->tev[1]) (void)hipEventRecord(g->tev[1], st);
-        unsigned char *d_comp = (unsigned char *)g->comp.p;
+        if (S.e1) (void)hipEventRecord(S.e1, sb);
+        unsigned char *d_comp = (unsigned char *)S.comp.p;
         if (!(was_hit && table_on_device)) {
-            // (the table's host copy must outlive the asynchronous transfer: it is staged through the launch stream's own pinned block)
-            void *h_tab = nullptr;
-            rc = tdt_pinned(ctx, 3, nb * sizeof(BzDesc), &h_tab);
-            if (rc) return rc;
-            memcpy(h_tab, blocks.data(), nb * sizeof(BzDesc));
-            TDT_HIP(hipMemcpyAsync(d_blocks, h_tab, nb * sizeof(BzDesc), hipMemcpyHostToDevice, st));
+            // (the table's host copy must outlive the asynchronous transfer: staged through the SLOT's pinned block — a context-wide one
+            // could be overwritten by another reader of the context before the copy has run)
+            if (S.h_table_cap < nb * sizeof(BzDesc)) {
+                if (S.h_table) (void)hipHostFree(S.h_table);
+                S.h_table = nullptr;
+                S.h_table_cap = 0;
+                const size_t cap = nb * sizeof(BzDesc) * 5 / 4 + 4096;
+                TDT_HIP(hipHostMalloc(&S.h_table, cap, hipHostMallocDefault));
+                S.h_table_cap = cap;
+            }
+            memcpy(S.h_table, blocks.data(), nb * sizeof(BzDesc));
+            TDT_HIP(hipMemcpyAsync(d_blocks, S.h_table, nb * sizeof(BzDesc), hipMemcpyHostToDevice, sb));
         }
-        rc = tdt_bz_launch(ctx, d_comp, d_blocks, nb, d_out + carry, true, d_status, d_summary);
+        rc = tdt_bz_launch_on(ctx, sb, g->reserve, d_comp, d_blocks, nb, (unsigned char *)S.out.p + g->gap, true, d_status, d_summary);
         if (rc) return rc;
-        if (g->tev[2]) (void)hipEventRecord(g->tev[2], st);
-        TDT_HIP(hipMemcpyAsync(g->h_summary, d_summary, 8, hipMemcpyDeviceToHost, st));
+        if (S.e2) (void)hipEventRecord(S.e2, sb);
+        TDT_HIP(hipMemcpyAsync(S.h_summary, d_summary, 8, hipMemcpyDeviceToHost, sb));
+    } else {
+        if (S.e1) (void)hipEventRecord(S.e1, sb);
+        if (S.e2) (void)hipEventRecord(S.e2, sb);
     }
-    g->begun.valid = true;
-    g->begun.comp = comp;
-    g->begun.len = len;
-    g->begun.produced = produced;
-    g->begun.carry = carry;
-    g->begun.T = T;
-    g->begun.nb = nb;
-    g->begun.d_status = d_status;
+    TDT_HIP(hipEventRecord(S.inflated, sb));
+    S.host = comp;
+    S.len = len;
+    S.produced = produced;
+    S.nb = nb;
+    S.d_status = d_status;
+    g->seq_begun = seq + 1;
     return TDT_OK;
 }
 
-// Enqueue the first half of the NEXT span's push behind whatever the launch stream holds — the caller has launched every kernel that
-// reads the current batch (its raw bytes are overwritten by this span's output: after this call only what was enqueued before it may
-// still read them) — so that the device goes from the current batch's consumers straight into the next span's inflate kernel while
-// the host collects results.  The following tdt_ingest_push / _bounded must be for exactly this (pointer, length).
+// Enqueue the first half of a coming span's push on the reader's inflate streams.  It depends on nothing the launch stream holds — the span
+// inflates into its own output buffer — so it may be called as soon as the span is in host memory: before the push of the span in front of it,
+// and while the current batch's consumers run.  At most two spans can be begun beyond the current batch; their pushes must come in the same order.
 extern "C" int tdt_ingest_push_ahead(tdt_ingest *g, const uint8_t *comp, size_t len) {
     if (!g || !comp || !len) {
         tdt_set_error("tdt_ingest_push_ahead: bad argument");
         return TDT_E_ARG;
     }
-    if (g->failed || g->begun.valid) {
-        tdt_set_error(g->failed ? "tdt_ingest_push_ahead: an earlier push on this stream failed" : "tdt_ingest_push_ahead: a span is already inflating ahead");
+    if (g->failed || g->seq_begun - g->seq_pushed >= 2) {
+        tdt_set_error(g->failed ? "tdt_ingest_push_ahead: an earlier push on this stream failed" : "tdt_ingest_push_ahead: two spans are already inflating ahead");
         return TDT_E_ARG;
     }
     const int rc = ing_push_begin(g, comp, len);
@@ -776,7 +842,7 @@ extern "C" int tdt_ingest_push_ahead(tdt_ingest *g, const uint8_t *comp, size_t 
 static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip, size_t own_bytes, size_t *n_records, size_t *first_off,
                     size_t *next_off) {
     const bool unknown_start = skip == (size_t)-1;
-    if (unknown_start && (g->carry || g->begun.valid)) {
+    if (unknown_start && (g->carry || g->seq_pushed)) {
         tdt_set_error("tdt_ingest_push_bounded: an unknown start is only possible on a fresh stream");
         return TDT_E_ARG;
     }
@@ -787,8 +853,9 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     TDT_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc = TDT_OK;
-    if (g->begun.valid) {
-        if (g->begun.comp != comp || g->begun.len != len) {
+    if (g->seq_begun > g->seq_pushed) {
+        const tdt_ingest::Slot &B = g->slot[g->seq_pushed % tdt_ingest::NSLOT];
+        if (B.host != comp || B.len != len) {
             tdt_set_error("tdt_ingest_push: another span was started with tdt_ingest_push_ahead");
             return TDT_E_ARG;
         }
@@ -796,22 +863,61 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         rc = ing_push_begin(g, comp, len);
         if (rc) return rc;
     }
-    g->begun.valid = false;
-    const size_t produced = g->begun.produced, carry = g->begun.carry, T = g->begun.T, nb = g->begun.nb;
-    unsigned char *d_out = (unsigned char *)g->out.p;
-    if (nb) {
-        TDT_HIP(hipStreamSynchronize(st));
-        if (g->h_summary[1]) {
-            unsigned code = 0;
-            TDT_HIP(hipMemcpy(&code, g->begun.d_status + g->h_summary[0], 4, hipMemcpyDeviceToHost));
-            tdt_set_error("tdt_ingest_push: %u of %zu BGZF blocks failed; first is block %u: %s", g->h_summary[1], nb, g->h_summary[0], tdt_bz_err_name(code));
-            return TDT_E_ARG;
-        }
+    const int si = (int)(g->seq_pushed % tdt_ingest::NSLOT);
+    tdt_ingest::Slot &S = g->slot[si];
+    // the batch in front of this one: everything that reads it has been enqueued (its slot is inflated into again three spans on)
+    if (g->cur >= 0) {
+        TDT_HIP(hipEventRecord(g->slot[g->cur].released, st));
+        g->slot[g->cur].released_set = true;
     }
+    g->seq_pushed++;
+    g->cur = si;
+    S.host = nullptr;
+    const size_t produced = S.produced, carry = g->carry, T = carry + produced, nb = S.nb;
+    TDT_HIP(hipEventSynchronize(S.inflated));
+    if (nb && S.h_summary[1]) {
+        unsigned code = 0;
+        TDT_HIP(hipMemcpy(&code, S.d_status + S.h_summary[0], 4, hipMemcpyDeviceToHost));
+        tdt_set_error("tdt_ingest_push: %u of %zu BGZF blocks failed; first is block %u: %s", S.h_summary[1], nb, S.h_summary[0], tdt_bz_err_name(code));
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipStreamWaitEvent(st, S.inflated, 0));
+    if (T >= 0xfffffff0ull) {
+        tdt_set_error("tdt_ingest_push: batch inflates to %zu bytes; feed at most 3 GiB of records per call", T);
+        return TDT_E_RANGE;
+    }
+    // ---- the carried partial record goes in front of the span's output
+    if (carry <= g->gap) {
+        g->lead = g->gap - carry;
+        if (carry) TDT_HIP(hipMemcpyAsync((char *)S.out.p + g->lead, g->carrybuf.p, carry, hipMemcpyDeviceToDevice, st));
+    } else {
+        // a record longer than the gap: the span's output moves behind it in a buffer of its own (one extra pass over the batch; the
+        // default gap is 1 MB, a record that long is a very long read)
+        tdt_buf moved;
+        moved.p = ing_dev_alloc(ctx->device, T + 256, &moved.cap);
+        if (!moved.p) {
+            tdt_set_error("tdt_ingest_push: device allocation of %zu bytes failed", T + 256);
+            return TDT_E_NOMEM;
+        }
+        hipError_t e = hipMemcpyAsync(moved.p, g->carrybuf.p, carry, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && produced) e = hipMemcpyAsync((char *)moved.p + carry, (char *)S.out.p + g->gap, produced, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            ing_dev_free(ctx->device, moved.p, moved.cap);
+            tdt_set_error("tdt_ingest_push: device copy failed: %s", hipGetErrorString(e));
+            return TDT_E_HIP;
+        }
+        ing_dev_free(ctx->device, S.out.p, S.out.cap);
+        S.out = moved;
+        g->lead = 0;
+    }
+    unsigned char *d_out = (unsigned char *)S.out.p + g->lead;
     g->out_len = T;
     g->n_records = 0;
     g->edges.clear();
     g->edges_overflow = false;
+    g->t_have_find = g->t_have_decode = false;
+    g->t_chain_ms = 0;
     *n_records = 0;
     if (skip > T) {
         tdt_set_error("tdt_ingest_push: skip (%zu) exceeds the inflated bytes (%zu)", skip, T);
@@ -819,7 +925,6 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     }
     if (T == skip) {
         g->carry = 0;
-        g->tail_off = 0;
         return TDT_OK;
     }
     const bool bounded = own_bytes != (size_t)-1;
@@ -845,13 +950,15 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     }
     unsigned *h_first = (unsigned *)g->pin.p, *h_exit = (unsigned *)((char *)g->pin.p + segb), *h_count = (unsigned *)((char *)g->pin.p + 2 * segb),
              *h_base = (unsigned *)((char *)g->pin.p + 3 * segb);
+    if (g->tev[0]) (void)hipEventRecord(g->tev[0], st);
     hipLaunchKernelGGL(bam_find_first, dim3((nseg + 3) / 4), dim3(256), 0, st, d_out, (long long)T, unknown_start ? -1ll : (long long)skip,
                        (long long)limit, g->n_ref, nseg, d_hint);
     TDT_CHECK_LAUNCH();
     hipLaunchKernelGGL(bam_find_records, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, unknown_start ? -1ll : (long long)skip,
                        (long long)limit, g->n_ref, nseg, d_first, d_exit, d_count, d_rel, d_hint);
     TDT_CHECK_LAUNCH();
-    if (g->tev[3]) (void)hipEventRecord(g->tev[3], st);
+    if (g->tev[1]) (void)hipEventRecord(g->tev[1], st);
+    g->t_have_find = g->tev[0] && g->tev[1];
     TDT_HIP(hipMemcpyAsync(h_first, d_first, 3 * segb, hipMemcpyDeviceToHost, st));
     TDT_HIP(hipStreamSynchronize(st));
     const double t_chain0 = ing_now_ms();
@@ -974,14 +1081,14 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
             TDT_HIP(hipMemcpyAsync(d_count, h_count, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
         }
         g->t_chain_ms = ing_now_ms() - t_chain0;
-        if (g->tev[4]) (void)hipEventRecord(g->tev[4], st);
+        if (g->tev[2]) (void)hipEventRecord(g->tev[2], st);
         if (table_dirty)
             hipLaunchKernelGGL(bam_decode_fields_serial, dim3((nseg + 63) / 64), dim3(64), 0, st, d_out, (long long)T, nseg, d_first, d_base, d_count, O);
         else
             hipLaunchKernelGGL(bam_decode_fields, dim3((nseg + 3) / 4), dim3(256), 0, st, d_out, (long long)T, nseg, d_base, d_count, d_rel, O);
         TDT_CHECK_LAUNCH();
-        if (g->tev[5]) (void)hipEventRecord(g->tev[5], st);
-        g->t_have_decode = g->tev[4] && g->tev[5];
+        if (g->tev[3]) (void)hipEventRecord(g->tev[3], st);
+        g->t_have_decode = g->tev[2] && g->tev[3];
         TDT_HIP(hipMemsetAsync(d_edges + 1023, 0, 4, st));
         hipLaunchKernelGGL(bam_tid_edges, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, O.tid, N, d_edges, 1023u, d_edges + 1023);
         TDT_CHECK_LAUNCH();
@@ -997,13 +1104,17 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     }
     g->n_records = n;
     *n_records = n;
-    // ---- the partial record stays where it is (the batch's raw bytes remain readable); the next push moves it to the front
+    // ---- the partial record behind the last complete one goes to the carry buffer (the batch's raw bytes stay readable where they are);
+    // the next push copies it in front of its span's output
     const size_t left = bounded ? 0 : T - tail;                   // a bounded push ends the shard: nothing is carried
-    if (left > tail && left) {
-        tdt_set_error("tdt_ingest_push: a single record (%zu bytes) is larger than the rest of the batch; feed more blocks per call", left);
-        return TDT_E_UNSUPPORTED;
+    if (left) {
+        if (g->carrybuf.cap < left) {
+            // (the old block may still be the source of the copy this push enqueued: it leaves behind the launch stream)
+            rc = ing_grow(g, g->carrybuf, left + (64u << 10));
+            if (rc) return rc;
+        }
+        TDT_HIP(hipMemcpyAsync(g->carrybuf.p, d_out + tail, left, hipMemcpyDeviceToDevice, st));
     }
-    g->tail_off = tail;
     g->carry = left;
     return TDT_OK;
 }
@@ -1016,7 +1127,7 @@ extern "C" int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_
     }
     const IngestOut &O = g->O;
     const void *p[14] = {O.tid, O.pos, O.end, O.mapq, O.flag, O.mate_tid, O.mate_pos, O.tlen, O.l_seq, O.cigar_first, O.cigar_last, O.rec_off,
-                         O.sa_off, g->out.p};
+                         O.sa_off, g->cur >= 0 && g->slot[g->cur].out.p ? (const char *)g->slot[g->cur].out.p + g->lead : nullptr};
     for (int i = 0; i < 14; i++) out14[i] = g->n_records || i == 13 ? p[i] : nullptr;
     if (raw_len) *raw_len = g->out_len;
     return TDT_OK;
@@ -1056,26 +1167,16 @@ extern "C" int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle) {
         return TDT_E_ARG;
     }
     *handle = nullptr;
-    if (g->failed || g->begun.valid) {
-        tdt_set_error(g->failed ? "tdt_ingest_retain: the stream is in an error state"
-                                : "tdt_ingest_retain: the next span is already inflating over this batch (tdt_ingest_push_ahead)");
+    if (g->failed) {
+        tdt_set_error("tdt_ingest_retain: the stream is in an error state");
         return TDT_E_ARG;
     }
-    TDT_HIP(hipSetDevice(g->ctx->device));
-    hipStream_t st = g->ctx->stream;
-    tdt_buf fresh;
-    if (g->out.cap) {
-        fresh.p = ing_dev_alloc(g->ctx->device, g->out.cap, &fresh.cap);
-        if (!fresh.p) {
-            tdt_set_error("tdt_ingest_retain: device allocation of %zu bytes failed", g->out.cap);
-            return TDT_E_NOMEM;
-        }
-        if (g->carry) TDT_HIP(hipMemcpyAsync(fresh.p, (char *)g->out.p + g->tail_off, g->carry, hipMemcpyDeviceToDevice, st));
-        TDT_HIP(hipStreamSynchronize(st));
-    }
-    tdt_retained *r = new tdt_retained{g->ctx, g->out.p, g->soa.p, g->out.cap, g->soa.cap};
-    g->out = fresh;
-    g->tail_off = 0;
+    // (nothing to copy or wait for: the partial record behind the batch is in the carry buffer, and spans inflating ahead have their own slots)
+    tdt_buf none;
+    tdt_buf &out = g->cur >= 0 ? g->slot[g->cur].out : none;
+    tdt_retained *r = new tdt_retained{g->ctx, out.p, g->soa.p, out.cap, g->soa.cap};
+    out = tdt_buf();                                 // the slot allocates afresh when a span is begun in it again
+    g->lead = 0;
     g->soa = tdt_buf();
     {
         IngestOut fresh_o{};
@@ -1100,37 +1201,35 @@ extern "C" int tdt_ingest_release(tdt_retained *r) {
 }
 
 // Where the last push spent its time, in milliseconds: out[0] block table (host), out[1] host-to-device copy of the compressed span
-// (on the launch stream; of the prefetch on the copy stream when out[6] = 1, then it ran behind the previous batch's kernels),
-// out[2] inflate + CRC kernels, out[3] record finding kernel, out[4] chain check on the host, out[5] field decode + contig edges
-// kernels, out[6] the span had been prefetched, out[7] wall time of the push call.  Waits for the decode kernel of that push.
+// (on the span's inflate stream; of the prefetch on the copy stream when out[6] = 1), out[2] inflate + CRC kernels of the span (elapsed on
+// its inflate stream: with spans begun ahead it overlaps the previous span's tail and the launch stream's kernels), out[3] record search
+// kernels, out[4] chain check on the host, out[5] field decode kernel, out[6] the span had been prefetched, out[7] wall time of the push
+// call itself (a span begun ahead has its first half outside it).  The events belong to the batch's slot and to the last push: spans
+// begun ahead since then do not disturb them.
 extern "C" int tdt_ingest_timing(tdt_ingest *g, double *out8) {
     if (!g || !out8) {
         tdt_set_error("tdt_ingest_timing: bad argument");
         return TDT_E_ARG;
     }
     for (int i = 0; i < 8; i++) out8[i] = 0;
-    auto span = [&](int a, int b) -> double {
+    if (g->cur < 0) return TDT_OK;
+    const tdt_ingest::Slot &S = g->slot[g->cur];
+    auto span = [&](hipEvent_t a, hipEvent_t b) -> double {
         float ms = 0;
-        if (!g->tev[a] || !g->tev[b]) return 0;
-        if (hipEventSynchronize(g->tev[b]) != hipSuccess || hipEventElapsedTime(&ms, g->tev[a], g->tev[b]) != hipSuccess) {
+        if (!a || !b) return 0;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
         }
         return ms;
     };
-    out8[0] = g->t_table_ms;
-    if (g->t_prefetched) {
-        float ms = 0;
-        if (g->hit_t0 && g->hit_t1 && hipEventSynchronize(g->hit_t1) == hipSuccess && hipEventElapsedTime(&ms, g->hit_t0, g->hit_t1) == hipSuccess) out8[1] = ms;
-        else (void)hipGetLastError();
-    } else {
-        out8[1] = span(0, 1);
-    }
-    out8[2] = span(1, 2);
-    out8[3] = span(2, 3);
+    out8[0] = S.table_ms;
+    out8[1] = S.prefetched ? span(S.hit_t0, S.hit_t1) : span(S.e0, S.e1);
+    out8[2] = span(S.e1, S.e2);
+    out8[3] = g->t_have_find ? span(g->tev[0], g->tev[1]) : 0;
     out8[4] = g->t_chain_ms;
-    out8[5] = g->t_have_decode ? span(4, 5) : 0;
-    out8[6] = g->t_prefetched ? 1 : 0;
+    out8[5] = g->t_have_decode ? span(g->tev[2], g->tev[3]) : 0;
+    out8[6] = S.prefetched ? 1 : 0;
     out8[7] = g->t_wall_ms;
     return TDT_OK;
 }

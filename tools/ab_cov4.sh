@@ -7,5 +7,5 @@ r,v,f=d['roofline'],d['coverage_sv']['roofline'],d['four_array_layout']
 print('packed %.3f | four arrays %.3f | z50 %.3f ms' % (r['avg_launch_ms'], f['avg_launch_ms'], v['avg_launch_ms']))"; }
 for rep in 1 2 3; do
   echo "in-tree: $(run)"
-  for v in "$@"; do echo "$v: $(TIDDIT_HIP_LIB=$PWD/variants/lib_$v.so run)"; done
+  for v in "$@"; do echo "$v: $(TIDDIT_ALLOW_VARIANT=1 TIDDIT_HIP_LIB=$PWD/variants/lib_$v.so run)"; done
 done

@@ -8,5 +8,5 @@ r,v=d['roofline'],d['coverage_sv']['roofline']
 print('z500 mean %.3f med %.3f min %.3f | z50 mean %.3f med %.3f min %.3f' % (r['avg_launch_ms'], r['median_launch_ms'], r['min_launch_ms'], v['avg_launch_ms'], v['median_launch_ms'], v['min_launch_ms']))"; }
 for rep in 1 2 3; do
   echo "in-tree: $(run)"
-  for v in "$@"; do echo "$v: $(TIDDIT_HIP_LIB=$PWD/variants/lib_$v.so run)"; done
+  for v in "$@"; do echo "$v: $(TIDDIT_ALLOW_VARIANT=1 TIDDIT_HIP_LIB=$PWD/variants/lib_$v.so run)"; done
 done

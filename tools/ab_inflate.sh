@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 one() {  # $1 = label, $2 = lib ("" = in-tree), $3.. = time_inflate_gpu.py args
   local label=$1 lib=$2; shift 2
-  if [ -n "$lib" ]; then export TIDDIT_HIP_LIB=$lib; else unset TIDDIT_HIP_LIB; fi
+  if [ -n "$lib" ]; then export TIDDIT_ALLOW_VARIANT=1 TIDDIT_HIP_LIB=$lib; else unset TIDDIT_HIP_LIB; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abi -o t -- python /root/repo/tools/time_inflate_gpu.py "$@" --check > /tmp/abi.log 2>&1
   echo "$label [$*]: $(grep -c '^match' /tmp/abi.log) match, lanes avg ns $(grep bgzf_inflate_lanes /tmp/abi/t_kernel_stats.csv | sed 's/.*)",//' | cut -d, -f3)"
 }

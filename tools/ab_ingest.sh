@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--no-gc --no-next --no-cov-sv --no-dbscan --no-sv-e2e --no-cpu-baseline --contigs 1"
 one() {
   local label=$1 lib=$2
-  if [ -n "$lib" ]; then export TIDDIT_HIP_LIB=$lib; else unset TIDDIT_HIP_LIB; fi
+  if [ -n "$lib" ]; then export TIDDIT_ALLOW_VARIANT=1 TIDDIT_HIP_LIB=$lib; else unset TIDDIT_HIP_LIB; fi
   python /root/repo/bench.py --full-line $ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())['ingest']

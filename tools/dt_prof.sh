@@ -2,7 +2,7 @@
 # per-phase shader-clock cycles of dbt_tile (variant built with -DDT_PROF: VARIANT_SRC=tdt_dbscan tools/build_variant.sh prof -Iinclude -DDT_PROF)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-TIDDIT_HIP_LIB=$R/variants/lib_${1:-prof}.so python - <<'PY'
+TIDDIT_ALLOW_VARIANT=1 TIDDIT_HIP_LIB=$R/variants/lib_${1:-prof}.so python - <<'PY'
 import sys, ctypes, atexit
 import torch  # before the library: one HIP runtime in the process
 sys.argv = ["bench.py", "--full-line", "--no-gc", "--no-ingest", "--no-next", "--no-cov-sv", "--no-sv-e2e", "--no-cpu-baseline", "--steps", "30", "--warmup", "5", "--contigs", "1"]

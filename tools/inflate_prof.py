@@ -4,6 +4,7 @@ build waits for the copies' memory operations where it charges them, so the kern
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ.setdefault("TIDDIT_ALLOW_VARIANT", "1")      # (a measurement build on purpose)
 from tiddit_amd import _native
 ctx = _native.default_context(); lib = ctx.lib
 comp = np.fromfile(sys.argv[1], dtype=np.uint8)

@@ -1,6 +1,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ.setdefault("TIDDIT_ALLOW_VARIANT", "1")      # (a measurement build on purpose)
 from tiddit_amd import _native
 ctx = _native.default_context(); lib = ctx.lib
 path = sys.argv[1]
