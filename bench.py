@@ -132,6 +132,7 @@ def parse():
 
 
 def main():
+    t_run0 = time.perf_counter()
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -731,6 +732,8 @@ def main():
 
         timing_on, batch_times = [False], []
         ingest_chunk = [448 << 20]                                # the reader's default span
+        span_count = [0]
+        ingest_split = [True]                                     # ... and its default for short files: four spans (here 4 x 65 MB)
 
         def ingest_pass():
             if use_dist:     # ONE file, byte-range shards, seam check, one exact all-reduce of the 500-bp bins (dist.coverage_sharded)
@@ -738,12 +741,14 @@ def main():
                 tk = torch.tensor([k], dtype=torch.int64, device=wire)
                 dist.all_reduce(tk)
                 return int(tk.item())
-            r = bamio.DeviceBamReader(path, ctx=ctx, chunk=ingest_chunk[0])
+            r = bamio.DeviceBamReader(path, ctx=ctx, chunk=ingest_chunk[0], split_small=ingest_split[0])
             r.collect_timing = timing_on[0]
-            k = 0
+            k = nb_ = 0
             for b in r.batches():
                 k += len(b)
+                nb_ += 1
             batch_times[:] = r.timings
+            span_count[0] = nb_
             r.close()
             return k
 
@@ -760,8 +765,8 @@ def main():
         t_in = rank_max(t_in)
         ires = {"metric": "BAM records decoded/sec (file -> packed arrays in HBM)", "value": nrec / t_in, "unit": "records/s",
                 "ms_per_step": 1e3 * t_in, "bam_MB_per_sec": fsize / t_in / 1e6,
-                "config": {"workload": "%d-record coordinate-sorted BAM (%.0f MB BGZF, zlib level 6, reads cut from a common reference), inflate + CRC32 + record decode on the device%s"
-                                       % (nrec, fsize / 1e6, "" if world == 1 else "; the ONE file read as %d byte-range shards, 500-bp coverage bins all-reduced (exact)" % world)}}
+                "config": {"workload": "%d-record coordinate-sorted BAM (%.0f MB BGZF, zlib level 6, reads cut from a common reference), inflate + CRC32 + record decode on the device, read as %d spans%s"
+                                       % (nrec, fsize / 1e6, span_count[0], "" if world == 1 else "; the ONE file read as %d byte-range shards, 500-bp coverage bins all-reduced (exact)" % world)}}
         if world == 1:
             # where a pass spends its time, batch by batch (one extra pass with the stage timers on: they wait for every batch's decode kernel)
             keys = ("read_ms", "wait_for_reader_ms", "block_table_ms", "h2d_ms", "inflate_crc_ms", "find_records_ms", "chain_check_ms", "decode_ms", "push_wall_ms")
@@ -770,6 +775,7 @@ def main():
                                          "stream behind the previous batch's kernels); inflate_crc / find_records / decode: kernels (HIP events); block_table / chain_check: host"}
             for label, chunk in (("span_448MB", 448 << 20), ("span_64MB", 64 << 20)):
                 ingest_chunk[0] = chunk
+                ingest_split[0] = False                           # (the file as ONE 448-MB span / as 64-MB spans, whatever the reader's default)
                 ingest_pass()                                     # buffers of this span size
                 t1 = time.perf_counter()
                 ingest_pass()
@@ -784,13 +790,14 @@ def main():
                                             "h2d_prefetched_batches": sum(1 for b in batch_times if b["h2d_prefetched"]),
                                             "rows": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in b.items()} for b in batch_times[:8]]}
             ingest_chunk[0] = 448 << 20
+            ingest_split[0] = True
             # what the BINNED coverage records cost where the pipeline pays for them: the record-decode kernel (bam_decode_fields) with the
             # reader bound to a 500-bp histogram (it then also computes first_bin, the bin shape and the two table indices of
             # tiddit_coverage.pyx:50-63 and writes the 8-byte record) against the same kernel unbound — the headline launch reads these records
             def decode_ms(bind):
                 best = None
                 for _ in range(4):
-                    r = bamio.DeviceBamReader(path, ctx=ctx, chunk=448 << 20)
+                    r = bamio.DeviceBamReader(path, ctx=ctx, chunk=448 << 20, split_small=False)
                     r.collect_timing = True
                     hh = None
                     if bind:
@@ -941,6 +948,10 @@ def main():
                                               "frac_of_stream_read": (f4["frac"] * HBM_PEAK_GBS / result["roofline"]["stream_read"]["GB_per_s"])
                                               if (result["roofline"].get("stream_read") or {}).get("GB_per_s") else None,
                                               "bins_per_sec": result["config"]["bins"] / (f4["avg_launch_ms"] * 1e-3)}
+        # how long the whole run took on this rank and what of it was input synthesis / CPU legs: at N > 1 no CPU leg runs (they are
+        # rank 0's at N = 1 only), and the driver's limit for a scaling run is 1 800 s
+        result["run_s"] = {"total": time.perf_counter() - t_run0, "sv_bam_generation": (result.get("sv_e2e") or {}).get("bam_generation_s"),
+                           "cpu_legs": "rank 0 at N = 1 only" if world > 1 or args.no_cpu_baseline else "included"}
         emit(result, args)
     if use_dist:
         dist.destroy_process_group()
@@ -1015,6 +1026,8 @@ def compact_line(result):
         line["cpu_baseline_all_cores"] = _pick(ca, ("value", "unit", "cores", "host_cores", "cpu_model"), 60)
     if "parity_checked" in result:
         line["parity_checked"] = _short(result["parity_checked"], 120)
+    if result.get("run_s"):
+        line["run_s"] = {k: _short(v) for k, v in result["run_s"].items() if v is not None}
 
     def section(name, keys, sub=()):
         s = result.get(name)

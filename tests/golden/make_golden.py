@@ -8,7 +8,7 @@ below, and only DATA (inputs + the reference's outputs) is written here.  tiddit
 pysam for FastaFile only; a tiny in-memory stand-in (oracle-side tooling, lives in /tmp) serves
 the sequences.  Nothing in tests/, bench.py or smoke() reads /root/reference at run time.
 
-usage: python tests/golden/make_golden.py [--slow | --large | --only-y-labels]
+usage: python tests/golden/make_golden.py [--slow | --large | --grch38 | --only-y-labels]
   --slow adds the 1M-point DBSCAN run (~6 min); --large makes ONLY sv_e2e_large.json (the 240-Mb file of bench.py's sv_e2e section, ~12 min)
 """
 import hashlib
@@ -455,7 +455,7 @@ def golden_sv_e2e(M, out, params=None, name="sv_e2e.json"):
     from tiddit_amd import synth_bam
     P = dict(E2E)
     P.update(params or {})
-    contigs = synth_bam.wgs_contigs(P["total_mb"])
+    contigs = synth_bam.contigs_for(P)
     with tempfile.TemporaryDirectory() as td:
         fa, bam, prefix = os.path.join(td, "ref.fa"), os.path.join(td, "WGS.bam"), os.path.join(td, "out")
         seqs = synth_bam.write_fasta(fa, contigs, seed=P["fasta_seed"])
@@ -487,7 +487,10 @@ def golden_sv_e2e(M, out, params=None, name="sv_e2e.json"):
            "epsilon": eps,
            "discordants_sha256": h(disc), "discordants_rows": disc.count("\n"), "splits_sha256": h(split), "splits_rows": split.count("\n"),
            "clips_sha256": h(clips), "clips_entries": clips.count(">"),
-           "coverage_sha256": {n: sha(cov[n].astype("<f8")) for n in cov}, "gc_sha256": {n: sha(gc[n]) for n in gc},
+           "coverage_sha256": {n: sha(cov[n].astype("<f8")) for n in cov},
+           # (a table of thousands of contigs: one checksum each for the contigs the job processes, ONE over all the others in header order)
+           "gc_sha256": {n: sha(gc[n]) for n, ln in contigs if len(contigs) <= 100 or ln >= P["min_contig"]},
+           "gc_sha256_rest": None if len(contigs) <= 100 else sha(np.concatenate([np.ascontiguousarray(gc[n]).view(np.uint8).ravel() for n, ln in contigs if ln < P["min_contig"]])),
            "ploidies_tab": ploidies, "library_after_ploidy": {k: float(v) for k, v in lib.items() if k.startswith(("avg_coverage", "contig_ploidy"))},
            "candidates_sha256": h(cluster_oracle.canonical(cand)), "candidates": cluster_oracle.summary(cand)}
     json.dump(res, open(os.path.join(out, name), "w"), indent=0)
@@ -500,6 +503,9 @@ def main():
     M = build_reference()
     if "--only-y-labels" in sys.argv:
         golden_dbscan_y_labels(M, HERE)
+        return
+    if "--grch38" in sys.argv:      # tests/golden/sv_e2e_grch38.json: a header shaped like the GRCh38 analysis set's (3 366 contigs), ~25 Mb
+        golden_sv_e2e(M, HERE, params={"total_mb": 24, "contig_table": "grch38", "seed": 38, "n_reads_stats": 400000}, name="sv_e2e_grch38.json")
         return
     if "--large" in sys.argv:       # tests/golden/sv_e2e_large.json: the 240-Mb file bench.py's sv_e2e section times (48 M records; ~12 min here)
         golden_sv_e2e(M, HERE, params={"total_mb": 240}, name="sv_e2e_large.json")

@@ -13,7 +13,7 @@ def materialise(fixture, directory, threads=8):
     """-> (bam path, fasta path, contigs)"""
     from tiddit_amd import synth_bam
     P = fixture["params"]
-    contigs = synth_bam.wgs_contigs(P["total_mb"])
+    contigs = synth_bam.contigs_for(P)
     fa, bam = os.path.join(directory, "ref.fa"), os.path.join(directory, "WGS.bam")
     seqs = synth_bam.write_fasta(fa, contigs, seed=P["fasta_seed"])
     info = synth_bam.write_wgs_sv_bam(bam, contigs, depth=P["depth"], read_len=P["read_len"], insert=P["insert"], insert_sd=P["insert_sd"],

@@ -481,10 +481,24 @@ def _a2a_worker(rank, world, port, q):
         def part(s, d):
             n = 0 if d == 0 or (s == d and s % 2) else (s + 1) * 1000 * d
             return np.full(n, 16 * s + d, dtype=np.uint8)
-        got = tdist.alltoall_bytes([part(rank, d) for d in range(world)])
-        assert len(got) == world
-        for s in range(world):
-            assert np.array_equal(np.asarray(got[s]), part(s, rank)), (rank, s)
+        for cap in (None, 777, 1):                               # one message per piece; pieces cut into several (TIDDIT_WIRE_MAX_BYTES)
+            if cap is None:
+                os.environ.pop("TIDDIT_WIRE_MAX_BYTES", None)
+            else:
+                os.environ["TIDDIT_WIRE_MAX_BYTES"] = str(cap)
+            scale = 1 if cap != 1 else 100                         # (byte-sized messages: smaller payloads)
+            got = tdist.alltoall_bytes([part(rank, d)[::scale] for d in range(world)])
+            assert len(got) == world
+            for s in range(world):
+                assert np.array_equal(np.asarray(got[s]), part(s, rank)[::scale]), (rank, s, cap)
+            # ragged byte strings to rank 1 (rank 2 sends nothing), and a pickled object from rank 2 to everybody
+            blobs = tdist.gather_bytes(bytes([65 + rank]) * (0 if rank == 2 else 1500 * (rank + 1) // scale), dst=1)
+            assert (blobs is None) == (rank != 1)
+            if rank == 1:
+                assert blobs == [bytes([65 + r]) * (0 if r == 2 else 1500 * (r + 1) // scale) for r in range(world)]
+            obj = tdist.broadcast_object({"rank": rank, "payload": list(range(400 // scale)), "none": None} if rank == 2 else None, src=2)
+            assert obj == {"rank": 2, "payload": list(range(400 // scale)), "none": None}
+        os.environ.pop("TIDDIT_WIRE_MAX_BYTES", None)
         sizes = tdist.allgather_i64([rank, 10 * rank, -rank])
         assert sizes.shape == (world, 3) and sizes[:, 1].tolist() == [10 * r for r in range(world)]
         q.put((rank, "ok"))

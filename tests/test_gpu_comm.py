@@ -108,3 +108,64 @@ def test_tdt_comm_with_n_ranks_on_one_gpu(standin, world):
     for p in procs:
         p.join(60)
     assert all(v == "ok" for v in res.values()), res
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from tiddit_amd import dist as tdist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and tdist._wire_device().type == "cuda"
+rng = np.random.default_rng(3)
+# alltoall_bytes (all_to_all_single on device tensors): empty, small, and a payload cut into many messages
+for cap, n in ((None, 0), (None, 1), (None, 3_000_001), (4096, 1_000_003), (1, 37)):
+    if cap is None:
+        os.environ.pop("TIDDIT_WIRE_MAX_BYTES", None)
+    else:
+        os.environ["TIDDIT_WIRE_MAX_BYTES"] = str(cap)
+    part = rng.integers(0, 256, n, dtype=np.uint8)
+    got = tdist.alltoall_bytes([part])
+    assert len(got) == 1 and np.array_equal(np.asarray(got[0]), part), (cap, n)
+    blobs = tdist.gather_bytes(part.tobytes(), dst=0)
+    assert blobs == [part.tobytes()]
+    obj = tdist.broadcast_object({"n": n, "part": part.tolist()[:1000], "nested": [None, 1.5, "x"]}, src=0)
+    assert obj["n"] == n and obj["nested"] == [None, 1.5, "x"]
+os.environ.pop("TIDDIT_WIRE_MAX_BYTES", None)
+assert tdist.allgather_i64([7, -1, 1 << 40]).tolist() == [[7, -1, 1 << 40]]
+# the seam table: one shard, a shard that starts at the header, an empty one
+assert tdist.check_seams(0, 0, False) == [[0, 0, 0]]
+assert tdist.check_seams(None, None, True) == [[-1, -1, 1]]
+# the all-reduce of the bins on a device tensor: exact (a sum over one rank), in place, 60 M bins = the 50-bp genome
+bins = torch.arange(60_000_000, dtype=torch.float64, device="cuda") * 0.25
+want = bins.clone()
+out = tdist.allreduce_bins(bins)
+assert out.data_ptr() == bins.data_ptr() and torch.equal(bins, want)
+# the variable-count all-gather of the cluster set
+t = torch.arange(12345, dtype=torch.int64, device="cuda")
+parts = tdist.allgatherv(t)
+assert len(parts) == 1 and torch.equal(parts[0], t)
+assert len(tdist.allgatherv(t[:0])) == 1
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+'''
+
+
+def test_dist_helpers_over_real_rccl_with_one_rank():
+    """The byte exchanges of the N-rank job — alltoall_bytes (one all_to_all_single per TIDDIT_WIRE_MAX_BYTES of the largest piece),
+    gather_bytes, broadcast_object, allgather_i64, check_seams, allreduce_bins, allgatherv — called DIRECTLY over backend nccl = RCCL
+    with device tensors (one rank: RCCL refuses two ranks on one device), incl. empty payloads and payloads cut into many messages.
+    The same functions run with 2 and 3 ranks over gloo in tests/test_dist_cpu.py; only the whole `--sv` job reached them over RCCL before."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK % {"repo": repo}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stderr[-3000:]

@@ -21,7 +21,9 @@ def h(t):
     return hashlib.sha256(t.encode()).hexdigest()
 
 
-@pytest.fixture(scope="module", params=["sv_e2e_small.json", "sv_e2e.json", "sv_e2e_large.json"])   # 3 Mb, 24 Mb, 240 Mb (the bench's file)
+# 3 Mb, 24 Mb, 240 Mb (the bench's file), and a 25-Mb genome under a header shaped like the GRCh38 analysis set's: 3 366 contigs (alt / decoy /
+# HLA names with `*` and `:`), a header of four BGZF blocks, 3 108 contigs below --min_contig, reads on 1 863 contigs, a tid = -1 tail
+@pytest.fixture(scope="module", params=["sv_e2e_small.json", "sv_e2e.json", "sv_e2e_large.json", "sv_e2e_grch38.json"])
 def run(request, golden_dir, tmp_path_factory):
     from tiddit_amd import __main__ as cli
     fx = load_fixture(golden_dir, request.param)
@@ -85,6 +87,9 @@ def test_coverage_gc_and_library(run):
     gc = tiddit_gc.main(fa, [n for n, _ in contigs], 1, 50, 0.5)
     for c, want in fx["gc_sha256"].items():
         assert hashlib.sha256(np.ascontiguousarray(gc[c]).tobytes()).hexdigest() == want, c
+    if fx.get("gc_sha256_rest"):                                 # thousands of contigs: one checksum over all those below --min_contig, header order
+        rest = np.concatenate([np.ascontiguousarray(gc[n]).view(np.uint8).ravel() for n, ln in contigs if ln < P["min_contig"]])
+        assert hashlib.sha256(rest.tobytes()).hexdigest() == fx["gc_sha256_rest"]
 
 
 def test_live_oracle_on_the_same_file(run, tmp_path):

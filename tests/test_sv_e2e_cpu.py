@@ -154,3 +154,72 @@ def test_statistics_prefix_restatement_is_pinned(small):
             assert a == {k: b[k] for k in a}, n
     finally:
         del os.environ["TIDDIT_HOST_INGEST"]
+
+
+# ---- a header shaped like the GRCh38 analysis set's (tests/golden/sv_e2e_grch38.json: 3 366 contigs)
+
+@pytest.fixture(scope="module")
+def grch38(golden_dir, tmp_path_factory):
+    fx = load_fixture(golden_dir, "sv_e2e_grch38.json")
+    d = str(tmp_path_factory.mktemp("sv_grch38"))
+    bam, fa, contigs = materialise(fx, d, threads=4)
+    return fx, bam, fa, contigs, d
+
+
+def test_grch38_shaped_header_host_side(grch38):
+    """The contig table the reference loops over on a human sample (tiddit_signal.pyx:246-259, tiddit_cluster.pyx:140-147,
+    tiddit_coverage.pyx:10-21): 3 366 @SQ lines with alt / decoy / HLA names (`*`, `:`), a header larger than three BGZF blocks,
+    3 108 contigs below --min_contig.  Host side: the header parse across blocks, the statistics of the reference's own
+    tiddit_stats.py (fixture), the per-contig coverage dictionary of create_coverage, and the contig-to-rank maps of the N-rank job."""
+    fx, bam, fa, contigs, d = grch38
+    from tiddit_amd import bamio, dist as tdist, tiddit_coverage
+    assert len(contigs) == 3366 and len({n for n, _ in contigs}) == 3366
+    assert sum(1 for n, _ in contigs if "*" in n and ":" in n) > 400 and min(l for _, l in contigs) == 970
+    r = bamio.BamReader(bam)
+    assert r.references == [n for n, _ in contigs] and r.lengths == [l for _, l in contigs]
+    assert r.header_bytes > 3 * 0xff00                           # the header alone spans four BGZF blocks
+    n, tail, tids = 0, 0, set()
+    for b in r.batches():
+        n += len(b)
+        tail += int((b.tid < 0).sum())
+        tids.update(np.unique(b.tid).tolist())
+    r.close()
+    assert n == fx["n_records"] and tail > 0 and len(tids) > 1500          # reads on 1 800 contigs, and the unplaced tail
+    P = fx["params"]
+    big = [n_ for n_, l in contigs if l >= P["min_contig"]]
+    assert list(fx["coverage_sha256"]) == big and 200 < len(big) < 300
+    assert any("*" in n_ for n_ in big)                          # HLA-DRB1 alleles above --min_contig: their names go into file names and rows
+    # create_coverage (tiddit_coverage.pyx:10-21): one array per contig, ceil(LN / bin) bins
+    header = {"SQ": [{"SN": n_, "LN": l} for n_, l in contigs]}
+    cov, lens = tiddit_coverage.create_coverage(header, 50)
+    assert list(cov) == [n_ for n_, _ in contigs] and all(len(cov[n_]) == -(-l // 50) for n_, l in contigs)
+    # the string order of the names (chrA < chrB, tiddit_signal.pyx:213) is not the header order
+    names = [n_ for n_, _ in contigs]
+    assert sorted(names) != names
+    lens = [l for _, l in contigs]
+    kept = [l >= P["min_contig"] for l in lens]
+    for world in (2, 3, 8):
+        owners = tdist.contig_owners(lens, kept, world)
+        assert len(owners) == len(names) and set(owners.tolist()) == set(range(world))
+        load = [sum(l for l, k, o in zip(lens, kept, owners) if k and o == r_) for r_ in range(world)]
+        assert max(load) < 1.5 * sum(load) / world               # 258 kept contigs packed evenly; the 3 108 others own nothing
+        parts = tdist.shard_contigs(lens, world)                 # the histogram path packs all 3 366
+        assert sorted(i for p_ in parts for i in p_) == list(range(len(lens)))
+
+
+def test_grch38_shaped_restatements_equal_the_reference(grch38, tmp_path):
+    """the restatements on this file == the fixture made by the compiled reference: signal tables (sha), candidates of
+    tiddit_cluster.main (whole dictionary), library statistics of tiddit_stats.py through the host decode"""
+    fx, bam, fa, contigs, d = grch38
+    P = fx["params"]
+    cov, disc, split, clips, each, n = signal_oracle.signal_main_file(bam, P["min_q"], fx["library"]["percentile_insert_size"], "WGS",
+                                                                      P["min_contig"], P["min_anchor_len"], P["min_clip_len"], want_clips=False)
+    assert h(disc) == fx["discordants_sha256"] and h(split) == fx["splits_sha256"] and n == fx["n_records"]
+    prefix = str(tmp_path / "o")
+    os.makedirs(prefix + "_tiddit")
+    open(prefix + "_tiddit/discordants_WGS.tab", "w").write(disc)
+    open(prefix + "_tiddit/splits_WGS.tab", "w").write(split)
+    names = [n_ for n_, _ in contigs]
+    cand = cluster_oracle.main(prefix, names, dict(contigs), ["WGS"], fx["library"]["mp"], fx["epsilon"], P["m"],
+                               fx["library"]["percentile_insert_size"], P["min_contig"], True, P["min_reads"])
+    assert cluster_oracle.summary(cand) == fx["candidates"] and h(cluster_oracle.canonical(cand)) == fx["candidates_sha256"]

@@ -489,6 +489,7 @@ def preingest(path, shard, bin_size, stop, max_batches=12, chunk=448 << 20, ctx=
     return len(kept)
 
 
+DEFAULT_RAMP_MB = 0              # first span of a reader in MB (0: every span is a full one), see DeviceBamReader._spans
 _SPAN_POOLS = []                 # free list of hostutil.PinnedPool objects, each holding a reader's four span buffers
 _SPAN_POOLS_LOCK = __import__("threading").Lock()
 
@@ -498,15 +499,16 @@ class DeviceBamReader:
     blocks are read into pinned host memory by a helper thread, pushed as they are, and come back as :class:`DeviceBatch`.
     Same ``header`` / ``references`` / ``lengths`` / ``batches()`` interface as :class:`BamReader`."""
 
-    def __init__(self, path, ctx=None, chunk=448 << 20, shard=None):
-        """shard = (rank, world): read only the BGZF blocks that start in this rank's byte range of the file; the records
+    def __init__(self, path, ctx=None, chunk=448 << 20, shard=None, split_small=True):
+        """split_small: a byte range shorter than four spans is read as four spans (see _spans); False = spans of `chunk` bytes whatever
+        the file's size.  shard = (rank, world): read only the BGZF blocks that start in this rank's byte range of the file; the records
         that start in them are this shard's.  After ``batches()`` is exhausted, ``first_off`` / ``next_off`` hold the seam
         offsets that neighbouring shards must agree on (``dist.check_seams``)."""
         host = BamReader(path, batch_bytes=1 << 20)                 # the header is parsed on the host
         self.header, self.references, self.lengths, self.text = host.header, host.references, host.lengths, host.text
         self._skip = host.header_bytes
         host.close()
-        self.path, self.chunk = path, chunk
+        self.path, self.chunk, self.split_small = path, chunk, split_small
         self.ctx = ctx or _native.default_context()
         self._f = open(path, "rb", buffering=0)
         h = ctypes.c_void_p()
@@ -557,6 +559,11 @@ class DeviceBamReader:
         lib = self.ctx.lib
         chunk = self.chunk
         b_lo, x_hi = self._b_lo, self._x_hi
+        # a byte range shorter than four spans is read as four (not below 32 MB each): a file that fits ONE span used to go through read ->
+        # copy -> inflate -> decode with nothing overlapping (bench.py's 259-MB file: 27.7 ms against 23.0 in 65-MB spans); short spans cost
+        # nothing any more since their inflate kernels overlap on the reader's two streams
+        if self.split_small:
+            chunk = min(chunk, max((x_hi - b_lo + 3) // 4, 32 << 20))
         chunk = max(1 << 16, min(chunk, x_hi - b_lo))
         # four pinned span buffers (in use, prefetched, queued, being read) from a process-wide free list: handed back in Spans.close(),
         # not whenever the collector gets to this closure — a reader opened right after another one used to find the previous
@@ -572,7 +579,12 @@ class DeviceBamReader:
         bufs = [span_pool.take("span0", chunk + (2 << 20), np.uint8), None, None, None]
         q = queue.Queue(maxsize=1)
         stop = self._stop
-        ramp = __import__("os").environ.get("TIDDIT_INGEST_RAMP", "0") == "1"      # measured: short first spans lose (0.14-0.16 s of statistics against 0.13)
+        # TIDDIT_INGEST_RAMP=<MB>: the first span is that short and the following ones double up to the full span, so that the device does
+        # not wait for 448 MB to be read and copied before its first kernel ("1" = 64; 0 = every span full).  Rounds 3-5 measured short
+        # first spans slower (a 64-MB span's 3 k blocks do not fill the chip); since round 6 the spans' inflate kernels overlap on two
+        # streams and a short span no longer leaves the chip part empty.
+        ramp = int(__import__("os").environ.get("TIDDIT_INGEST_RAMP", str(DEFAULT_RAMP_MB)) or 0)
+        ramp = 64 if ramp == 1 else max(0, ramp)
 
         def put(item):
             while not stop.is_set():
@@ -600,9 +612,7 @@ class DeviceBamReader:
                     have = len(carry)
                     buf[:have] = carry
                     if not eof:                                  # parallel positional reads into the pinned buffer
-                        # TIDDIT_INGEST_RAMP=1: short first spans (64, 128, 256 MB, then the full span) so that the device does not wait
-                        # for a whole first span — measured slower: a 64-MB span's 3 k blocks do not fill the chip
-                        ck = min(chunk, max(1 << 16, (64 << 20) << min(k, 3))) if ramp else chunk
+                        ck = min(chunk, max(1 << 16, (ramp << 20) << min(k, 8))) if ramp else chunk
                         want = fsize - fo if fsize - fo <= ck + (1 << 20) - have else max(ck - have, 1 << 16)   # the tail rides along
                         piece = 8 << 20
                         mv = memoryview(buf)

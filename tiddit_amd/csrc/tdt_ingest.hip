@@ -340,7 +340,9 @@ struct tdt_ingest {
     size_t gap = ING_GAP;
     tdt_buf carrybuf;                              // the partial record behind the current batch
     hipStream_t inf_stream[2] = {nullptr, nullptr};     // spans alternate: the head of span k+1 fills the wave slots the tail of span k leaves
-    int reserve = 1;                               // workgroups per CU the inflate grid leaves to the launch stream's kernels
+    int reserve = 0;                               // workgroups per CU the inflate grid leaves free (TIDDIT_INFLATE_RESERVE).  0: measured best —
+                                                   // the launch stream's kernels get the wave slots the previous span's tail frees, and a
+                                                   // grid one workgroup per CU short costs the inflate more than they gain (profiles/r06_sv_reserve_3000mb.txt)
     // compressed blocks of spans copied ahead by tdt_ingest_prefetch: the copy of span k+1 can be issued while span k has not been begun
     struct Prefetch {
         tdt_buf buf;

@@ -26,6 +26,9 @@ const char *const tdt_variant_sort = ""
 #ifdef RS_ROUNDS
     " RS_ROUNDS"
 #endif
+#ifdef RS_LOOK
+    " RS_LOOK"
+#endif
     ;
 
 #include "tdt_common.h"
@@ -39,6 +42,9 @@ const char *const tdt_variant_sort = ""
 #endif
 #define RS_TILE (RS_THREADS * RS_ROUNDS)  // 4096 pairs per workgroup
 #define RS_MAXPASS 8
+#ifndef RS_LOOK
+#define RS_LOOK 8                         // status words of the tiles in front fetched per round trip of the look-back
+#endif
 #define RS_FLAG_AGG 0x40000000u           // status word: the tile's own count of the digit
 #define RS_FLAG_PREFIX 0x80000000u        // ... the count of the digit in this tile and every tile in front of it
 #define RS_VALUE 0x3fffffffu
@@ -69,11 +75,20 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_all(const ull *__restrict_
     for (int p = 0; p < plan.np; p++) h[p][tid] = 0;
     __syncthreads();
     if (blockIdx.x == 0 && tid == 0) hdr[RS_MAXPASS * 256 + 8] = (unsigned)(keys[0] >> 32);
-    for (size_t i = (size_t)blockIdx.x * RS_THREADS + tid; i < (size_t)n; i += (size_t)gridDim.x * RS_THREADS) {
-        const ull k = keys[i];
+    // (16-byte loads: two keys per lane and trip; `keys` is 256-byte aligned scratch)
+    const size_t pairs = (size_t)n / 2;
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + tid; i < pairs; i += (size_t)gridDim.x * RS_THREADS) {
+        const ulonglong2 kk = reinterpret_cast<const ulonglong2 *>(keys)[i];
 #pragma unroll
         for (int p = 0; p < RS_MAXPASS; p++)
-            if (p < plan.np) atomicAdd(&h[p][rs_digit(k, plan.p[p])], 1u);
+            if (p < plan.np) {
+                atomicAdd(&h[p][rs_digit(kk.x, plan.p[p])], 1u);
+                atomicAdd(&h[p][rs_digit(kk.y, plan.p[p])], 1u);
+            }
+    }
+    if ((n & 1) && blockIdx.x == 0 && tid == 0) {
+        const ull k = keys[n - 1];
+        for (int p = 0; p < plan.np; p++) atomicAdd(&h[p][rs_digit(k, plan.p[p])], 1u);
     }
     __syncthreads();
     for (int p = 0; p < plan.np; p++) {
@@ -162,30 +177,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_onesweep(const KI *__restrict__
     __hip_atomic_store(my, (tile == 0 ? RS_FLAG_PREFIX : RS_FLAG_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned lbase = rs_block_excl(total, sscan, tid);           // where the digit's run starts in the reordered tile
     const unsigned gbase = rs_block_excl(ghist[tid], sscan, tid);      // ... and in the output: keys of smaller digits
-    // ---- look back over the tiles in front for the digit's prefix
-    unsigned excl = 0;
-    for (int t = tile - 1; t >= 0; t--) {
-        const unsigned *const sp = status + (size_t)t * 256 + tid;
-        unsigned s = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (!(s & ~RS_VALUE)) {                                     // the tile is running (it took its number before this one): wait for its count
-            __builtin_amdgcn_s_sleep(1);
-            s = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++spins > (1u << 24)) {                                // (cannot happen; a hang would cost the box — report instead)
-                *err = 7;                                              // (tdt_ctx_sync reports it)
-                break;
-            }
-        }
-        excl += s & RS_VALUE;
-        if (s & RS_FLAG_PREFIX) break;
-    }
-    if (tile) __hip_atomic_store(my, RS_FLAG_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gdst[tid] = (int)(gbase + excl) - (int)lbase;
     // the waves' first slots become tile slots
 #pragma unroll
     for (int w = 0; w < RS_WAVES; w++) wh[w][tid] += lbase;
     __syncthreads();
-    // ---- reorder by digit in LDS
+    // ---- reorder by digit in LDS (the tiles in front publish their counts meanwhile)
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int i = w0 + r * 64 + lane;
@@ -196,6 +192,35 @@ __global__ __launch_bounds__(RS_THREADS) void rs_onesweep(const KI *__restrict__
             sv[slot] = v[r];
         }
     }
+    // ---- look back over the tiles in front for the digit's prefix, RS_LOOK status words per round trip (one word at a time, a tile whose
+    // 500 predecessors were started together and hold only their own counts walked them one memory latency each)
+    unsigned excl = 0;
+    for (int t = tile - 1; t >= 0; t -= RS_LOOK) {
+        unsigned s[RS_LOOK];
+#pragma unroll
+        for (int j = 0; j < RS_LOOK; j++)
+            s[j] = t - j >= 0 ? __hip_atomic_load(status + (size_t)(t - j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_FLAG_PREFIX;
+        bool done = false;
+#pragma unroll
+        for (int j = 0; j < RS_LOOK; j++) {
+            if (done) continue;
+            unsigned sj = s[j];
+            unsigned spins = 0;
+            while (!(sj & ~RS_VALUE)) {                                // the tile is running (it took its number before this one): wait for its count
+                __builtin_amdgcn_s_sleep(1);
+                sj = __hip_atomic_load(status + (size_t)(t - j) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > (1u << 24)) {                            // (cannot happen; a hang would cost the box — report instead)
+                    *err = 7;                                          // (tdt_ctx_sync reports it)
+                    break;
+                }
+            }
+            excl += sj & RS_VALUE;
+            done = (sj & RS_FLAG_PREFIX) != 0;
+        }
+        if (done) break;
+    }
+    if (tile) __hip_atomic_store(my, RS_FLAG_PREFIX | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gdst[tid] = (int)(gbase + excl) - (int)lbase;
     __syncthreads();
     // ---- and out, in tile order: consecutive lanes write consecutive addresses of a digit's run
     const int cnt = n - t0 < RS_TILE ? n - t0 : RS_TILE;
@@ -265,7 +290,7 @@ int tdt_radix_sort_pairs(tdt_ctx *ctx, ull *keys, unsigned *vals, ull *keys_tmp,
     unsigned *hdr = (unsigned *)d_ws, *ctl = hdr + RS_MAXPASS * 256, *status = hdr + RS_HDR_WORDS;
     hipStream_t st = ctx->stream;
     TDT_HIP(hipMemsetAsync(d_ws, 0, words * 4, st));
-    const int hgrid = std::min(ntiles, 4 * ctx->num_cu);
+    const int hgrid = std::min(ntiles, 2 * ctx->num_cu);
     hipLaunchKernelGGL(rs_hist_all, dim3(hgrid), dim3(RS_THREADS), 0, st, (const ull *)keys, n, plan, hdr);
     TDT_CHECK_LAUNCH();
     const bool narrow = !(bitmask >> 32) && plan.np > 1;        // 32-bit keys between the first and the last digit

@@ -168,6 +168,13 @@ def _wire_device(group=None):
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
+def _wire_max():
+    """largest single message of the byte exchanges below (TIDDIT_WIRE_MAX_BYTES, default 1 GiB): longer payloads travel as several —
+    RCCL / gloo counts beyond 2^31 elements are where transports have failed before, and a 54-GB BAM's rows on few ranks get there"""
+    import os
+    return max(1, int(os.environ.get("TIDDIT_WIRE_MAX_BYTES", str(1 << 30))))
+
+
 def broadcast_object(obj, src=0, group=None):
     """pickle -> uint8 tensor -> broadcast (length first).  -> the object on every rank."""
     import pickle
@@ -182,8 +189,9 @@ def broadcast_object(obj, src=0, group=None):
     buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
     if me == src and len(blob):
         buf.copy_(torch.from_numpy(numpy.frombuffer(blob, dtype=numpy.uint8).copy()))
-    if buf.numel():
-        dist.broadcast(buf, src, group=group)
+    cap = _wire_max()
+    for o in range(0, buf.numel(), cap):
+        dist.broadcast(buf[o:o + cap], src, group=group)
     return obj if me == src else pickle.loads(buf.cpu().numpy().tobytes())
 
 
@@ -199,9 +207,12 @@ def gather_bytes(blob, dst=0, group=None):
     counts = torch.empty(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, cnt, group=group)
     counts = counts.cpu().tolist()
+    cap = _wire_max()
     if me != dst:
         if len(blob):
-            dist.send(torch.from_numpy(numpy.frombuffer(blob, dtype=numpy.uint8).copy()).to(dev), dst, group=group)
+            t = torch.from_numpy(numpy.frombuffer(blob, dtype=numpy.uint8).copy()).to(dev)
+            for o in range(0, t.numel(), cap):
+                dist.send(t[o:o + cap], dst, group=group)
         return None
     out = []
     for r in range(world):
@@ -209,8 +220,8 @@ def gather_bytes(blob, dst=0, group=None):
             out.append(bytes(blob))
             continue
         buf = torch.empty(counts[r], dtype=torch.uint8, device=dev)
-        if counts[r]:
-            dist.recv(buf, r, group=group)
+        for o in range(0, counts[r], cap):
+            dist.recv(buf[o:o + cap], r, group=group)
         out.append(buf.cpu().numpy().tobytes())
     return out
 
@@ -252,29 +263,38 @@ def alltoall_bytes(parts, group=None):
     parts = [numpy.ascontiguousarray(p, dtype=numpy.uint8) for p in parts]
     sizes = allgather_i64([len(p) for p in parts], group)            # sizes[src][dst]
     incoming = [int(sizes[r][me]) for r in range(world)]
+    cap = _wire_max()
+    rounds = -(-int(sizes.max()) // cap) if sizes.size and sizes.max() > 0 else 0      # (every rank holds the whole size table: same count everywhere)
     if dist.get_backend(group) == "nccl":
         dev = _wire_device(group)
-        send = torch.from_numpy(numpy.concatenate(parts) if sum(len(p) for p in parts) else numpy.zeros(0, dtype=numpy.uint8)).to(dev)
-        recv = torch.empty(sum(incoming), dtype=torch.uint8, device=dev)
-        dist.all_to_all_single(recv, send, output_split_sizes=incoming, input_split_sizes=[len(p) for p in parts], group=group)
-        flat = recv.cpu().numpy()
-        out, o = [], 0
-        for n in incoming:
-            out.append(flat[o:o + n])
-            o += n
-        return out
+        got = [numpy.empty(n, dtype=numpy.uint8) for n in incoming]
+        for k in range(rounds):                                  # one all_to_all_single per `cap` bytes of the largest (source, destination) piece
+            lo = k * cap
+            out_sizes = [len(p[lo:lo + cap]) for p in parts]
+            in_sizes = [max(0, min(cap, n - lo)) for n in incoming]
+            send = torch.from_numpy(numpy.concatenate([p[lo:lo + cap] for p in parts]) if sum(out_sizes) else numpy.zeros(0, dtype=numpy.uint8)).to(dev)
+            recv = torch.empty(sum(in_sizes), dtype=torch.uint8, device=dev)
+            dist.all_to_all_single(recv, send, output_split_sizes=in_sizes, input_split_sizes=out_sizes, group=group)
+            flat = recv.cpu().numpy()
+            o = 0
+            for r, n in enumerate(in_sizes):
+                got[r][lo:lo + n] = flat[o:o + n]
+                o += n
+        return got
     bufs, reqs = [], []
     for r in range(world):
         if r == me:
             bufs.append(parts[me])
             continue
         buf = torch.empty(incoming[r], dtype=torch.uint8)
-        if incoming[r]:
-            reqs.append(dist.irecv(buf, r, group=group))
+        for o in range(0, incoming[r], cap):
+            reqs.append(dist.irecv(buf[o:o + cap], r, group=group))
         bufs.append(buf.numpy())
     for r in range(world):
-        if r != me and len(parts[r]):
-            reqs.append(dist.isend(torch.from_numpy(parts[r]), r, group=group))
+        if r != me:
+            t = torch.from_numpy(parts[r])
+            for o in range(0, len(parts[r]), cap):
+                reqs.append(dist.isend(t[o:o + cap], r, group=group))
     for q in reqs:
         q.wait()
     return bufs

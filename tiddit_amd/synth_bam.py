@@ -265,6 +265,62 @@ def wgs_contigs(total_mb, decoys=True):
     return contigs
 
 
+def grch38_shaped_contigs(total_mb=24, seed=38):
+    """A contig table with the SHAPE of the GRCh38 analysis set's header (GRCh38_full_analysis_set_plus_decoy_hla: 3 366 @SQ lines),
+    scaled to about `total_mb` Mb: 24 chromosomes with GRCh38's relative lengths, chrM, 42 `*_random` and 127 `chrUn_*` scaffolds
+    (970 bp up), 261 `*_alt` contigs, chrEBV, 2 385 `chrUn_JTFH...v1_decoy` contigs of 1-8 kb and 525 HLA alleles whose names carry
+    `*` and `:` (`HLA-DRB1*15:03:01:02`; a few of them longer than tiddit's default --min_contig).  The names follow the real
+    header's patterns (the accessions are synthetic); everything derives from `seed`.  What it is for: the header alone is larger
+    than three BGZF blocks, thousands of contigs lie below --min_contig, hundreds of small contigs carry reads, the string order of
+    the names (chrA < chrB decisions, tiddit_signal.pyx:213) differs from the header order, and the file ends in a tid = -1 tail."""
+    rng = np.random.default_rng(seed)
+    small = 0.5 * total_mb * 1e6
+    prim_scale = (total_mb * 1e6 - small) / float(sum(HUMAN_MB))
+    chrom = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+    out = [(n, int(mb * prim_scale) // 1000 * 1000 + 137 + 11 * i) for i, (n, mb) in enumerate(zip(chrom, HUMAN_MB))]
+    out.append(("chrM", 16569))
+    host = [1, 1, 1, 2, 2, 3, 4, 5, 9, 9, 9, 9, 11, 14, 14, 14, 14, 14, 14, 14, 14, 15, 16, 17, 17, 17, 22, 22, 22, 22, 22, 22, 22, 22, 22]
+    for i in range(42):
+        c = "Y" if i >= 41 else str(host[i % len(host)])
+        out.append(("chr%s_KI270%03dv1_random" % (c, 706 + i), int(rng.integers(1200, 42000))))
+    for i in range(127):
+        ln = 970 if i == 0 else int(rng.integers(980, 1500)) if i < 12 else int(rng.integers(1500, 26000))
+        out.append((("chrUn_KI270%03dv1" % (302 + i)) if i < 100 else ("chrUn_GL000%03dv1" % (195 + i - 100)), ln))
+    for i in range(261):
+        c = chrom[int(rng.integers(0, 24))][3:]
+        out.append((("chr%s_KI270%03dv1_alt" % (c, 762 + i)) if i % 3 else ("chr%s_GL000%03dv2_alt" % (c, 250 + i // 3)), int(rng.integers(3000, 14000))))
+    out.append(("chrEBV", 17182))
+    for i in range(2385):
+        out.append(("chrUn_JTFH0100%04dv1_decoy" % (i + 1), int(rng.integers(1000, 3600 if i % 7 else 8000))))
+    genes = ["A", "B", "C", "DQA1", "DQB1", "DRB1"]
+    for i in range(525):
+        g = genes[i * len(genes) // 525]
+        name = "HLA-%s*%02d:%02d:%02d:%02d" % (g, 1 + i % 57, 1 + (i // 3) % 40, 1 + i % 4, 1 + i % 3)
+        if i % 11 == 0:
+            name = name.rsplit(":", 1)[0] + ("N" if i % 22 == 0 else "")            # three-field names and null alleles (`HLA-A*01:11N`-like)
+        ln = int(rng.integers(10500, 13900)) if g == "DRB1" and i % 4 == 0 else int(rng.integers(970, 5600))
+        out.append((name, ln))
+    seen = set()
+    uniq = []
+    for n, ln in out:                                           # (the generated allele names collide now and then: keep the header's names unique)
+        k = 2
+        base = n
+        while n in seen:
+            n = "%s:%02d" % (base, k)
+            k += 1
+        seen.add(n)
+        uniq.append((n, ln))
+    return uniq
+
+
+def contigs_for(params):
+    """the contig table of a synthetic WGS file from its parameter dictionary (tests/golden fixtures, bench.py): `contig_table` =
+    "grch38" selects :func:`grch38_shaped_contigs`, otherwise :func:`wgs_contigs`"""
+    if params.get("contig_table") == "grch38":
+        return grch38_shaped_contigs(params["total_mb"])
+    return wgs_contigs(params["total_mb"])
+
+
 def write_fasta(path, contigs, seed=100, width=60):
     """reference FASTA for `contigs` (synth.gen_sequence per contig) -> {name: uint8 sequence}"""
     from .synth import gen_sequence
