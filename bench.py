@@ -752,7 +752,8 @@ def main():
             r.close()
             return k
 
-        nrec = ingest_pass()                                       # warm-up (page cache, buffers)
+        nrec = ingest_pass()                                       # warm-up: page cache, device buffers ...
+        ingest_pass()                                              # ... and the reader's pinned ring: a process's SECOND pass still pays for it (38 ms against 22-23 from the third on, tools/time_ingest_passes.py)
         torch.cuda.synchronize()
         barrier()
         isteps = max(1, min(args.steps, 3))
@@ -963,7 +964,7 @@ def main():
 # `roofline` with every section's {ms, frac, traffic_ratio, frac_of_stream_read}, `cpu_baseline`, and per section the figures a
 # reader quotes); the detailed record of the same run goes to gpurun_out/bench_detail_n<N>.json (or $TIDDIT_BENCH_DETAIL) and to
 # stdout only with --full-line.
-LINE_BUDGET = 5000
+LINE_BUDGET = 7000        # (round 3's 16.8-KB line was parsed, round 4's 20-KB line was not; round 5 printed 4.7 KB)
 
 
 def _short(v, n=96):

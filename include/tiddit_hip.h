@@ -55,6 +55,9 @@ void *tdt_ctx_stream(tdt_ctx *ctx);
 /* Enqueue work on an externally owned hipStream_t (e.g. torch's current stream); 0 restores the
  * context's own stream. */
 int tdt_ctx_set_stream(tdt_ctx *ctx, void *hip_stream);
+/* Make the context's device the calling thread's current one: for a helper thread of the caller that pins host memory (tdt_host_alloc)
+ * before it has called anything else of the library (bamio's file-reading thread). */
+int tdt_ctx_bind_thread(tdt_ctx *ctx);
 
 /* ---- binned read-depth histogram ---------------------------------------------------------- *
  * Replaces tiddit_coverage.create_coverage (tiddit_coverage.pyx:10-21), the per-read
@@ -105,6 +108,9 @@ int tdt_cov_push_binned_device_multi(tdt_cov *cov, int n_items, const int *tids,
 int tdt_cov_total_bins(tdt_cov *cov, int64_t *total);
 int tdt_cov_offset(tdt_cov *cov, int tid, int64_t *off);
 int tdt_cov_finish_all_device(tdt_cov *cov, double *d_out);
+/* the same into HOST memory: out = float64[tdt_cov_total_bins], contig t at out + tdt_cov_offset(t) — one launch, one copy, one wait for
+ * a header of thousands of contigs (tiddit_coverage.pyx:10-21 creates one array per @SQ line) */
+int tdt_cov_finish_all(tdt_cov *c, double *out);
 /* Convert contig tid's accumulators to float64 bins (exact), copy to host / leave on device.
  * Returns TDT_E_RANGE / TDT_E_INEXACT if any pushed read / bin violated the domain. */
 int tdt_cov_finish(tdt_cov *cov, int tid, double *out_bins);
@@ -126,6 +132,12 @@ int tdt_gc_bins_fasta(tdt_ctx *ctx, const uint8_t *raw, int64_t nbytes, int64_t 
                       double n_cutoff, int8_t *out);
 int tdt_gc_bins_fasta_device(tdt_ctx *ctx, const uint8_t *d_raw, int64_t nbytes, int64_t len, int linebases, int linewidth, int bin_size,
                              double n_cutoff, int8_t *d_out);
+/* tiddit_gc.main's loop (tiddit_gc.pyx:35-42) over MANY contigs in one call: `raw` = the FASTA bytes of n contigs, contig i at raw_off[i]
+ * (a multiple of 16) for raw_len[i] bytes, len[i] bases at linebases[i] / linewidth[i] per line; its int8 bins are written to
+ * out + out_off[i].  One copy in, one launch per contig, one copy out, one wait (a GRCh38-shaped reference has 3 366 contigs). */
+int tdt_gc_bins_fasta_many(tdt_ctx *ctx, const uint8_t *raw, int64_t nbytes, int n, const int64_t *raw_off, const int64_t *raw_len,
+                           const int64_t *len, const int32_t *linebases, const int32_t *linewidth, int bin_size, double n_cutoff,
+                           int8_t *out, const int64_t *out_off, int64_t out_bytes);
 
 /* ---- signal clustering ("DBSCAN") ----------------------------------------------------------- *
  * Replaces DBSCAN.x_coordinate_clustering (DBSCAN.py:33-64), y_coordinate_clustering (:66-123) and
@@ -377,7 +389,7 @@ int tdt_bgzf_inflate_hbm(tdt_ctx *ctx, const uint8_t *comp, size_t len, uint8_t 
  * the stream position is undefined: further pushes on that object are refused.  tdt_ingest_arrays: device pointers, valid until the next push, in tdt_bam_decode's
  * output order (tid, pos, end, mapq, flag, mate_tid, mate_pos, tlen, l_seq, cigar_first, cigar_last, rec_off, sa_off)
  * followed by the batch's raw record bytes (rec_off / sa_off index into them).  tdt_ingest_edges: record indices
- * where the contig id changes (*n = (size_t)-1 when there are more than 1023, i.e. the input is not coordinate
+ * where the contig id changes (*n = (size_t)-1 when there are more than 8191, i.e. the input is not coordinate
  * sorted).  tdt_ingest_carry: bytes of the pending partial record (0 after a well-formed file). */
 typedef struct tdt_ingest tdt_ingest;
 int tdt_ingest_create(tdt_ctx *ctx, int n_ref, tdt_ingest **out);
@@ -396,24 +408,32 @@ int tdt_ingest_push_bounded(tdt_ingest *g, const uint8_t *comp, size_t len, size
 int tdt_ingest_prefetch(tdt_ingest *g, const uint8_t *comp, size_t len);
 int tdt_ingest_arrays(tdt_ingest *g, const void **out14, size_t *raw_len);
 int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size_t *n);
+/* the contig id of the run that starts at edges[k], for every k tdt_ingest_edges reported (up to 8191 runs per batch: a GRCh38-shaped
+ * file has ~1 900 contigs with reads) */
+int tdt_ingest_edge_tids(tdt_ingest *g, int32_t *tids, size_t cap);
 /* device pointer of the batch's PACKED coverage records (see tdt_cov_push_packed_device_multi), valid until the next push */
 int tdt_ingest_packed(tdt_ingest *g, const uint64_t **d_packed);
 /* From the next push on the reader writes BINNED records for `cov` (NULL: the generic packed records again) into the column
  * tdt_ingest_packed returns; *binned = 1 when it does (0: that histogram's bin size has no binned form, the column stays generic). */
 int tdt_ingest_bin_for(tdt_ingest *g, tdt_cov *cov, int *binned);
-/* Enqueue the FIRST HALF of the next span's push — its copy (or the prefetched one), the carried partial record, the inflate + CRC
- * kernels — on the context's stream, behind the kernels the caller has already launched on the current batch, without waiting for anything:
- * the device goes from the current batch's consumers straight into the next span's inflate while the host collects their results.  The
- * current batch's raw bytes are overwritten by it: after this call only work enqueued BEFORE it may still read them (the field arrays stay
- * valid until the push itself).  The next tdt_ingest_push / _push_bounded must be for exactly this (pointer, length); tdt_ingest_retain is
- * refused in between.  (htslib's reader threads decompress ahead of the consumer in the same way.) */
+/* Enqueue the FIRST HALF of a coming span's push — its copy (or the prefetched one), its block table, the inflate + CRC kernels and the
+ * copy of their status word — on the reader's own (low-priority) inflate streams, without waiting for anything.  A span inflates into an
+ * output buffer of its own, a fixed gap into it (1 MB; TIDDIT_INGEST_GAP), and the partial record the batch before it ends with is copied
+ * in front of the output by the push itself (a record longer than the gap moves the output once): so a span's inflate depends on NOTHING
+ * the launch stream holds and may be started as soon as the span is in host memory — before the push of the span in front of it, while
+ * the current batch's consumers run; the chip then never leaves the inflate kernel, and the record search, field decode and the caller's
+ * kernels of batch k run beside span k+1's inflate.  At most two spans may be begun beyond the current batch; their pushes must follow in
+ * the same order with exactly these (pointer, length) pairs.  The current batch (field arrays AND raw bytes) stays valid until the next
+ * push; tdt_ingest_retain may be called with spans begun ahead.  (htslib's reader threads decompress ahead of the consumer in the same way.) */
 int tdt_ingest_push_ahead(tdt_ingest *g, const uint8_t *comp, size_t len);
 /* Keep the current batch beyond the next push: its device buffers (everything tdt_ingest_arrays / tdt_ingest_packed returned) move into
  * *handle and stay valid until tdt_ingest_release; the reader continues with fresh buffers.  Used by `tiddit --sv` to scan the batches its
  * library statistics were sampled from without reading and inflating them a second time. */
 /* Where the last push spent its time (ms): [0] BGZF block table (host), [1] host-to-device copy of the span (the prefetch copy when
- * [6] = 1: it ran on the copy stream behind the previous batch's kernels), [2] inflate + CRC kernels, [3] record-finding kernel,
- * [4] chain check (host), [5] field decode + contig-edge kernels, [6] prefetched, [7] wall time of the push call. */
+ * [6] = 1: it ran on the copy stream behind the previous batch's kernels), [2] inflate + CRC kernels of the span (elapsed on its inflate
+ * stream: it overlaps the previous span's tail and the launch stream's kernels), [3] record-finding kernels, [4] chain check (host),
+ * [5] field decode kernel, [6] prefetched, [7] wall time of the push call itself (the first half of a span begun ahead lies outside
+ * it).  The figures are those of the CURRENT batch: spans begun ahead since its push do not disturb them. */
 int tdt_ingest_timing(tdt_ingest *g, double *out8);
 typedef struct tdt_retained tdt_retained;
 int tdt_ingest_retain(tdt_ingest *g, tdt_retained **handle);

@@ -675,6 +675,46 @@ def test_gc_from_fasta_layout_equals_stripped(tmp_path, width, eol):
     assert np.array_equal(g["a"], oracle.binned_gc(seqs["a"], 50, 0.5)) and np.array_equal(g["d"], oracle.binned_gc(seqs["d"], 50, 0.5))
 
 
+def test_gc_of_many_small_contigs_in_groups(tmp_path, monkeypatch):
+    """tiddit_gc.main (tiddit_gc.pyx:35-42) over a reference of many small contigs — the shape of GRCh38's alt / decoy / HLA contigs —
+    goes to the device in GROUPS (tdt_gc_bins_fasta_many: one copy in, one launch per contig, one wait): contigs wrapped at different
+    widths in one file, one-line and one-base contigs, an empty contig, a last contig without a final line end, groups of every size
+    (the batch limit forced down), contigs above the grouping limit in between — all equal to the oracle per contig, keys in call order"""
+    rng = np.random.default_rng(77)
+    path = str(tmp_path / "many.fa")
+    seqs, order = {}, []
+    with open(path, "wb") as f:
+        for i in range(420):
+            name = ["HLA-A*%02d:%02d:01" % (1 + i % 40, 1 + i // 40), "chrUn_JTFH0100%04dv1_decoy" % i, "chr%d_KI27%04dv1_alt" % (1 + i % 22, i)][i % 3]
+            ln = int(rng.choice([0, 1, 49, 50, 51, 60, 61, 970, 2274, int(rng.integers(100, 9000)), int(rng.integers(9000, 40000))])) if i else 33_000
+            if i == 7:
+                ln = 0
+            width = int(rng.choice([60, 70, 80, 61]))
+            s = synth.gen_sequence(max(ln, 1), seed=int(rng.integers(1, 1 << 30)))[:ln]
+            if ln > 200:
+                s[rng.integers(0, ln, ln // 40)] = ord("N")
+                s[50:50 + min(130, ln - 60)] = ord("n")
+            seqs[name] = s
+            order.append(name)
+            f.write((">%s\n" % name).encode())
+            b = s.tobytes()
+            last = i == 419
+            for o in range(0, ln, width):
+                f.write(b[o:o + width] + (b"" if last and o + width >= ln else b"\n"))
+    assert len(seqs) == 420
+    want = {n: oracle.binned_gc(seqs[n], 50, 0.5) if len(seqs[n]) else np.zeros(0, dtype=np.int8) for n in order}
+    for batch, one in ((96 << 20, 8 << 20), (30_000, 8 << 20), (1, 8 << 20), (96 << 20, 5_000)):
+        monkeypatch.setattr(tiddit_gc, "_MANY_MAX_BATCH", batch)
+        monkeypatch.setattr(tiddit_gc, "_MANY_MAX_CONTIG", one)
+        got = tiddit_gc.main(path, order[::-1], 1, 50, 0.5)
+        assert list(got) == order[::-1]
+        for n in order:
+            assert got[n].dtype == np.int8 and np.array_equal(got[n], want[n]), (n, batch, one)
+    got = tiddit_gc.main(path, order[:5], 1, 500, 0.5)             # another bin size through the same groups
+    for n in order[:5]:
+        assert np.array_equal(got[n], oracle.binned_gc(seqs[n], 500, 0.5) if len(seqs[n]) else np.zeros(0, dtype=np.int8))
+
+
 def test_comm_abi_single_rank_group(ctx):
     """tdt_comm_* (RCCL bound at run time): a one-rank communicator on this GPU — the variable-count all-gather and the float64
     sum all-reduce are the identity; (more ranks need more GPUs: the N-rank layout logic is covered by the gloo tests)"""

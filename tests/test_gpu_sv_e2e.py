@@ -286,3 +286,41 @@ def test_switches_off_leave_the_same_files(run, tmp_path, monkeypatch):
     for r in ["_tiddit/discordants_WGS.tab", "_tiddit/splits_WGS.tab", "_tiddit/clips_WGS.fa", ".ploidies.tab", ".candidates.tab"]:
         a, b = open(out + r, "rb").read(), open(out2 + r, "rb").read()
         assert a == b and a, r
+
+
+def test_cov_cli_on_a_header_of_thousands_of_contigs(run, tmp_path, monkeypatch):
+    """`tiddit --cov` on the GRCh38-shaped file: one row per bin of ALL 3 366 contigs (tiddit_coverage.pyx:10-21 creates an array per @SQ
+    line, print_coverage walks them in header order) — the bins come back in one piece (tdt_cov_finish_all); the device-ingest and the
+    host-ingest runs write the same bytes, and every contig's rows equal the oracle's update_coverage on the decoded reads"""
+    import oracle
+    from tiddit_amd import __main__ as cli, bamio
+    fx, bam, fa, contigs, out = run
+    if fx["params"].get("contig_table") != "grch38":
+        pytest.skip("the other fixtures have 27 contigs")
+    dev_out, host_out = str(tmp_path / "dev"), str(tmp_path / "host")
+    cli.main(["--cov", "--bam", bam, "-o", dev_out, "-z", "500"])
+    monkeypatch.setenv("TIDDIT_HOST_INGEST", "1")
+    cli.main(["--cov", "--bam", bam, "-o", host_out, "-z", "500"])
+    monkeypatch.delenv("TIDDIT_HOST_INGEST")
+    text = open(dev_out + ".bed", "rb").read()
+    assert text == open(host_out + ".bed", "rb").read()
+    rows = text.decode().splitlines()
+    assert len(rows) == 1 + sum(-(-l // 500) for _, l in contigs) and rows[0].startswith("#")
+    # the oracle on the decoded reads, contig by contig (placed reads that pass the --cov filter, __main__.py:231-240)
+    r = bamio.BamReader(bam)
+    cols = {k: [] for k in ("tid", "pos", "end", "mapq", "flag")}
+    for b in r.batches():
+        for k in cols:
+            cols[k].append(getattr(b, k))
+    r.close()
+    tid, pos, end, mapq, flag = (np.concatenate(cols[k]) for k in ("tid", "pos", "end", "mapq", "flag"))
+    order = np.argsort(tid, kind="stable")
+    cuts = np.searchsorted(tid[order], np.arange(len(contigs) + 1))
+    at = 1
+    for t, (name, ln) in enumerate(contigs):
+        nb = -(-ln // 500)
+        idx = order[cuts[t]:cuts[t + 1]]
+        want, _ = oracle.coverage_stream(pos[idx], end[idx], mapq[idx], flag[idx], ln, 500, 20)      # the --cov filter (a3) + update_coverage
+        got = np.array([float(x.split("\t")[3]) for x in rows[at:at + nb]])
+        assert rows[at].split("\t")[0] == name and np.array_equal(got, want), name
+        at += nb

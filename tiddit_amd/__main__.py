@@ -100,8 +100,14 @@ def run_cov(args):
                 if tid[lo] >= 0:
                     hist.push(int(tid[lo]), b.pos[lo:hi], b.end[lo:hi], b.mapq[lo:hi], b.flag[lo:hi], args.q)
         reader.close()
-        for contig in coverage_data:
-            coverage_data[contig] = hist.finish(contig)
+        if len(coverage_data) > 64:          # a header of thousands of contigs: every contig's bins in one launch + copy (tdt_cov_finish_all)
+            allbins = hist.finish_all()
+            for i, contig in enumerate(coverage_data):
+                o = hist.offset(i)
+                coverage_data[contig] = allbins[o:o + hist.nbins(i)[0]].copy()
+        else:
+            for contig in coverage_data:
+                coverage_data[contig] = hist.finish(contig)
         hist.close()
     if args.w:
         tiddit_coverage.print_coverage(coverage_data, bam_header, args.z, "wig", args.o + ".wig")
@@ -278,7 +284,7 @@ def run_sv(args, version):
             try:
                 ctx = _native.Context(_native.default_context().device)
                 fasta = FastaFile(args.ref)
-                gc_job["result"] = {c: tiddit_gc.binned_gc(fasta, c, 50, 0.5, ctx=ctx)[1] for c in gc_mine}
+                gc_job["result"] = tiddit_gc.gc_of_contigs(fasta, gc_mine, 50, 0.5, ctx=ctx)
             except BaseException as e:           # re-raised on the main thread
                 gc_job["error"] = e
             gc_job["seconds"] = time.time() - gc_job["t0"]

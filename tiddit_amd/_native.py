@@ -36,6 +36,7 @@ SYMBOLS = {
     "tdt_ctx_sync": (_i, [_P]),
     "tdt_ctx_stream": (_P, [_P]),
     "tdt_ctx_set_stream": (_i, [_P, _P]),
+    "tdt_ctx_bind_thread": (_i, [_P]),
     "tdt_cov_create": (_i, [_P, _P, _i, _i, _PP]),
     "tdt_cov_destroy": (None, [_P]),
     "tdt_cov_nbins": (_i, [_P, _i, ctypes.POINTER(_i64), ctypes.POINTER(_i)]),
@@ -51,6 +52,7 @@ SYMBOLS = {
     "tdt_cov_total_bins": (_i, [_P, ctypes.POINTER(_i64)]),
     "tdt_cov_offset": (_i, [_P, _i, ctypes.POINTER(_i64)]),
     "tdt_cov_finish_all_device": (_i, [_P, _P]),
+    "tdt_cov_finish_all": (_i, [_P, _P]),
     "tdt_cov_finish": (_i, [_P, _i, _P]),
     "tdt_cov_finish_device": (_i, [_P, _i, _P]),
     "tdt_cov_kept": (_i, [_P, ctypes.POINTER(_i64)]),
@@ -58,6 +60,7 @@ SYMBOLS = {
     "tdt_gc_bins_fasta": (_i, [_P, _P, _i64, _i64, _i, _i, _i, _dbl, _P]),
     "tdt_gc_bins_fasta_device": (_i, [_P, _P, _i64, _i64, _i, _i, _i, _dbl, _P]),
     "tdt_gc_bins_device": (_i, [_P, _P, _i64, _i, _dbl, _P]),
+    "tdt_gc_bins_fasta_many": (_i, [_P, _P, _i64, _i, _P, _P, _P, _P, _P, _i, _dbl, _P, _P, _i64]),
     "tdt_dbscan": (_i, [_P, _P, _sz, _sz, _dbl, _i, _i, _P, ctypes.POINTER(_i64)]),
     "tdt_dbscan_y": (_i, [_P, _P, _sz, _sz, _dbl, _i, _i64, _P, ctypes.POINTER(_i64)]),
     "tdt_dbscan_y_segments": (_i, [_P, _P, _P, _P, _sz, _i, _dbl, _i, _i64, _P, ctypes.POINTER(_i64)]),
@@ -121,6 +124,7 @@ SYMBOLS = {
     "tdt_calib_stream_read": (_i, [_P, _P, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _P, _P]),
     "tdt_ingest_timing": (_i, [_P, _P]),
     "tdt_ingest_retain": (_i, [_P, _PP]),
+    "tdt_ingest_edge_tids": (_i, [_P, _P, _sz]),
     "tdt_ingest_release": (_i, [_P]),
     "tdt_ingest_edges": (_i, [_P, _P, _sz, ctypes.POINTER(_sz)]),
     "tdt_ingest_carry": (_i, [_P, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),

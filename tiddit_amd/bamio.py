@@ -565,114 +565,188 @@ class DeviceBamReader:
         if self.split_small:
             chunk = min(chunk, max((x_hi - b_lo + 3) // 4, 32 << 20))
         chunk = max(1 << 16, min(chunk, x_hi - b_lo))
-        # four pinned span buffers (in use, prefetched, queued, being read) from a process-wide free list: handed back in Spans.close(),
-        # not whenever the collector gets to this closure — a reader opened right after another one used to find the previous
-        # reader's pinned blocks still alive and paid 5-55 ms for new ones (the spread of the bench's ingest line)
+        # pinned span buffers from a process-wide free list: handed back in Spans.close(), not whenever the collector gets to this
+        # closure — a reader opened right after another one used to find the previous reader's pinned blocks still alive and paid
+        # 5-55 ms for new ones (the spread of the bench's ingest line)
         with _SPAN_POOLS_LOCK:
             span_pool = _SPAN_POOLS.pop() if _SPAN_POOLS else None
         if span_pool is None:
             from .hostutil import PinnedPool
             span_pool = PinnedPool()
-        # four rotating pinned span buffers; the first is pinned here, the others by the reader thread when it first needs them (after its
-        # first tdt_ingest_prefetch, which binds the thread to the context's device): pinning all four up front (1.8 GB) was 0.2-0.3 s
-        # in front of a process's first span, and the device had nothing to do meanwhile
-        bufs = [span_pool.take("span0", chunk + (2 << 20), np.uint8), None, None, None]
-        q = queue.Queue(maxsize=1)
+        # TWO helper threads (round 6): one READS the file into the next free pinned buffer, the other hops over the BGZF block headers
+        # of what was read (tdt_bgzf_scan: a serial chase, ~4 ms per 448 MB), starts the span's PCIe copy and uploads its block table
+        # (tdt_ingest_prefetch).  As one thread — read, then scan, then the next read — they took 13.7 ms per 448-MB span at 3 Gb, as
+        # long as the span's inflate kernel: with the inflate running back to back the reader had become the other limit of the scan.
+        # Five buffers: being read, being scanned, queued, and the consumer's two (the span it pushes and the one begun ahead).  The first
+        # is pinned here, the others by the reading thread when it first needs them: pinning all of them up front was 0.2-0.3 s in
+        # front of a process's first span, and the device had nothing to do meanwhile.
+        NBUF, GAP = 5, 1 << 20            # GAP: data is read this far into a buffer; the partial block carried from the span before goes in front
+        cap = chunk + GAP + (2 << 20)
+        bufs = [span_pool.take("span0", cap, np.uint8)] + [None] * (NBUF - 1)
+        q1 = queue.Queue(maxsize=1)       # read -> scan
+        q = queue.Queue(maxsize=1)        # scan -> consumer
+        free_q = queue.Queue()
+        for i in range(NBUF):
+            free_q.put(i)
+        refs_lock = threading.Lock()
+        refs = [0] * NBUF                 # spans of a buffer the consumer has not finished with
+        closed = [False] * NBUF           # ... and whether the scanning thread is done with it
         stop = self._stop
         # TIDDIT_INGEST_RAMP=<MB>: the first span is that short and the following ones double up to the full span, so that the device does
-        # not wait for 448 MB to be read and copied before its first kernel ("1" = 64; 0 = every span full).  Rounds 3-5 measured short
-        # first spans slower (a 64-MB span's 3 k blocks do not fill the chip); since round 6 the spans' inflate kernels overlap on two
-        # streams and a short span no longer leaves the chip part empty.
-        ramp = int(__import__("os").environ.get("TIDDIT_INGEST_RAMP", str(DEFAULT_RAMP_MB)) or 0)
+        # not wait for 448 MB to be read and copied before its first kernel ("1" = 64; 0 = every span full).  Measured in rounds 3-5 and
+        # again in round 6 (inflate kernels overlapping on two streams): no gain (profiles/r06_sv_ramp_240mb.txt)
+        ramp = int(os.environ.get("TIDDIT_INGEST_RAMP", str(DEFAULT_RAMP_MB)) or 0)
         ramp = 64 if ramp == 1 else max(0, ramp)
+        RS = self.reader_seconds                                   # where the helper threads' time goes, summed over the spans
 
-        def put(item):
+        def put(qq, item):
             while not stop.is_set():
                 try:
-                    q.put(item, timeout=0.05)
+                    qq.put(item, timeout=0.05)
                     return True
                 except queue.Full:
                     pass
             return False
 
-        def produce():
-            import os
+        def get(qq):
+            while not stop.is_set():
+                try:
+                    return qq.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            return None
+
+        def release_buffer(idx):
+            """the consumer is done with one span of buffer idx"""
+            with refs_lock:
+                refs[idx] -= 1
+                done = refs[idx] == 0 and closed[idx]
+                if done:
+                    closed[idx] = False
+            if done:
+                free_q.put(idx)
+
+        def read_loop():
             from concurrent.futures import ThreadPoolExecutor
             fd, fsize, fo = self._f.fileno(), x_hi, b_lo           # this reader's byte range of the file
             pool = ThreadPoolExecutor(int(os.environ.get("TIDDIT_READ_THREADS", "16")))       # (8 threads: 9.2 GB/s of BGZF from the page cache, 16: 10.5)
             try:
-                k, carry = 0, np.zeros(0, dtype=np.uint8)
-                eof = False
-                read_ms, got = 0.0, 0
-                RS = self.reader_seconds                           # where the reader thread's time goes, summed over the spans
-                while True:
-                    if bufs[k % 4] is None:
-                        bufs[k % 4] = span_pool.take("span%d" % (k % 4), chunk + (2 << 20), np.uint8)
-                    buf = bufs[k % 4]
-                    have = len(carry)
-                    buf[:have] = carry
-                    if not eof:                                  # parallel positional reads into the pinned buffer
-                        ck = min(chunk, max(1 << 16, (ramp << 20) << min(k, 8))) if ramp else chunk
-                        want = fsize - fo if fsize - fo <= ck + (1 << 20) - have else max(ck - have, 1 << 16)   # the tail rides along
-                        piece = 8 << 20
-                        mv = memoryview(buf)
-
-                        def rd(o):
-                            n, end = 0, min(want, o + piece)
-                            while o + n < end:
-                                g = os.preadv(fd, [mv[have + o + n:have + end]], fo + o + n)
-                                if g <= 0:
-                                    raise ValueError("short read")
-                                n += g
-                            return n
-                        t_rd = time.perf_counter()
-                        got = sum(pool.map(rd, range(0, want, piece)))
-                        read_ms = 1e3 * (time.perf_counter() - t_rd)
-                        RS["read"] += read_ms * 1e-3
-                        fo += got
-                        have += got
-                        eof = fo >= fsize
-                    if have == 0:
-                        break
-                    t_sc = time.perf_counter()
-                    nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
-                    _native.check(lib.tdt_bgzf_scan(_native.ptr(buf), have, 3 << 30, ctypes.byref(nb), ctypes.byref(consumed), ctypes.byref(produced)))
-                    if nb.value == 0:
-                        raise ValueError("truncated BGZF block at end of file" if eof else "BGZF block larger than the read window")
-                    carry = buf[consumed.value:have].copy()
-                    t_pf = time.perf_counter()
-                    RS["block scan"] += t_pf - t_sc
-                    # the PCIe copy of this span starts now, on the copy stream, behind whatever the device is doing for the span before it
-                    # (the push of exactly this (pointer, length) then finds it on the device)
-                    _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(buf), consumed.value))
-                    t_put = time.perf_counter()
-                    RS["block table + copy issue"] += t_put - t_pf
-                    ok_put = put((buf, consumed.value, fo - have, read_ms if not eof or got else 0.0))
-                    RS["waited for the consumer"] += time.perf_counter() - t_put
-                    RS["spans"] += 1
-                    if not ok_put:
+                lib.tdt_ctx_bind_thread(self.ctx.handle)           # (this thread pins buffers: on the context's device)
+                k = 0
+                while fo < fsize:
+                    t_w = time.perf_counter()
+                    idx = get(free_q)
+                    RS["reader waited for a buffer"] = RS.get("reader waited for a buffer", 0.0) + time.perf_counter() - t_w
+                    if idx is None:
                         return
+                    if bufs[idx] is None:
+                        bufs[idx] = span_pool.take("span%d" % idx, cap, np.uint8)
+                    buf = bufs[idx]
+                    ck = min(chunk, max(1 << 16, (ramp << 20) << min(k, 8))) if ramp else chunk
+                    want = fsize - fo if fsize - fo <= ck + (1 << 20) else ck         # the tail rides along
+                    piece = 8 << 20
+                    mv = memoryview(buf)
+
+                    def rd(o):                                   # parallel positional reads into the pinned buffer
+                        n, end = 0, min(want, o + piece)
+                        while o + n < end:
+                            g = os.preadv(fd, [mv[GAP + o + n:GAP + end]], fo + o + n)
+                            if g <= 0:
+                                raise ValueError("short read")
+                            n += g
+                        return n
+                    t_rd = time.perf_counter()
+                    got = sum(pool.map(rd, range(0, want, piece)))
+                    read_ms = 1e3 * (time.perf_counter() - t_rd)
+                    RS["read"] += read_ms * 1e-3
+                    if not put(q1, (idx, got, fo, read_ms, fo + got >= fsize)):
+                        return
+                    fo += got
                     k += 1
-                put(None)
+                put(q1, None)
             except BaseException as e:
-                put(e)
+                put(q1, e)
             finally:
                 pool.shutdown(wait=False)
 
-        th = threading.Thread(target=produce, daemon=True)
+        def scan_loop():
+            try:
+                carry = np.zeros(0, dtype=np.uint8)
+                while True:
+                    item = get(q1)
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    idx, got, fo0, read_ms, eof = item
+                    buf = bufs[idx]
+                    if len(carry) > GAP:
+                        raise ValueError("BGZF block larger than the read window")
+                    pos = GAP - len(carry)
+                    buf[pos:GAP] = carry
+                    end = GAP + got
+                    emitted = 0
+                    # (one scan covers the buffer unless its blocks inflate to more than a push takes — 3 GiB: highly compressible data —,
+                    # then the rest of the same buffer goes out as further spans)
+                    while pos < end:
+                        t_sc = time.perf_counter()
+                        nb, consumed, produced = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+                        view = buf[pos:end]
+                        _native.check(lib.tdt_bgzf_scan(_native.ptr(view), end - pos, 3 << 30, ctypes.byref(nb), ctypes.byref(consumed), ctypes.byref(produced)))
+                        t_pf = time.perf_counter()
+                        RS["block scan"] += t_pf - t_sc
+                        if nb.value == 0:
+                            break
+                        # the PCIe copy of this span starts now, on the copy stream, behind whatever the device is doing for the span before it
+                        # (the push of exactly this (pointer, length) then finds it on the device)
+                        _native.check(lib.tdt_ingest_prefetch(self._h, _native.ptr(view), consumed.value))
+                        t_put = time.perf_counter()
+                        RS["block table + copy issue"] += t_put - t_pf
+                        with refs_lock:
+                            refs[idx] += 1
+                        ok_put = put(q, (view, consumed.value, fo0 - (GAP - pos), read_ms if not emitted else 0.0, idx))
+                        RS["waited for the consumer"] += time.perf_counter() - t_put
+                        RS["spans"] += 1
+                        if not ok_put:
+                            return
+                        emitted += 1
+                        pos += consumed.value
+                    carry = buf[pos:end].copy()
+                    with refs_lock:
+                        closed[idx] = True
+                        idle = refs[idx] == 0
+                        if idle:
+                            closed[idx] = False
+                    if idle:
+                        free_q.put(idx)
+                    if len(carry) and eof:
+                        raise ValueError("truncated BGZF block at end of file")
+                    if len(carry) > 1 << 16 and not emitted:
+                        raise ValueError("BGZF block larger than the read window")
+                put(q, None)
+            except BaseException as e:
+                put(q, e)
+
+        th = threading.Thread(target=scan_loop, daemon=True)
+        th_read = threading.Thread(target=read_loop, daemon=True)
+        th_read.start()
         th.start()
-        self._span_thread = th                                    # close() joins it before the ingest handle goes (the thread prefetches through it)
+        self._span_thread = th                                    # close() joins both before the ingest handle goes (the scanning thread prefetches through it)
+        self._read_thread = th_read
 
         class Spans:
             """blocking ``next()`` and non-blocking ``poll()`` over the reader thread's queue; None = end of range"""
             done = False
             returned = False
 
+            release = staticmethod(release_buffer)
+
             def _take(self, item):
                 if item is None:
                     self.done = True
                     stop.set()
                     th.join()
+                    th_read.join()
                     return None
                 if isinstance(item, BaseException):
                     self.done = True
@@ -692,8 +766,9 @@ class DeviceBamReader:
                     return False                                  # nothing read yet
 
             def close(self):
-                stop.set()                                        # a consumer that stops early releases the reader thread
+                stop.set()                                        # a consumer that stops early releases the helper threads
                 th.join()
+                th_read.join()
                 if not self.returned:
                     self.returned = True
                     with _SPAN_POOLS_LOCK:
@@ -751,7 +826,7 @@ class DeviceBamReader:
             self.reader_seconds["consumer waited for a span"] += wait_ms * 1e-3
             if cur is None:
                 break
-            buf, consumed, abs0, read_ms = cur
+            buf, consumed, abs0, read_ms, buf_idx = cur
             begun, st["ahead"] = st["ahead"], False                 # (a span started by ahead() is this one: its push finishes below)
             st["pending"] = spans.poll()                            # span k+1 already read?  (its PCIe copy was started by the reader thread)
             if os.environ.get("TIDDIT_INGEST_AHEAD", "1") != "0":
@@ -787,6 +862,7 @@ class DeviceBamReader:
             else:
                 _native.check(lib.tdt_ingest_push(self._h, _native.ptr(buf), consumed, skip, ctypes.byref(n)))
             first = False
+            spans.release(buf_idx)                                 # (the push has waited for the span's inflate: its host bytes are not needed again)
             if self.collect_timing:
                 tm = (ctypes.c_double * 8)()
                 _native.check(lib.tdt_ingest_timing(self._h, tm))
@@ -798,9 +874,9 @@ class DeviceBamReader:
             ptrs = (ctypes.c_void_p * 14)()
             raw_len = ctypes.c_size_t(0)
             _native.check(lib.tdt_ingest_arrays(self._h, ptrs, ctypes.byref(raw_len)))
-            edges = np.empty(1024, dtype=np.uint32)
+            edges = np.empty(8192, dtype=np.uint32)
             ne = ctypes.c_size_t(0)
-            _native.check(lib.tdt_ingest_edges(self._h, _native.ptr(edges), 1024, ctypes.byref(ne)))
+            _native.check(lib.tdt_ingest_edges(self._h, _native.ptr(edges), 8192, ctypes.byref(ne)))
             b = DeviceBatch(self, n.value, ptrs, raw_len.value, None)
             pk = ctypes.c_void_p()
             _native.check(lib.tdt_ingest_packed(self._h, ctypes.byref(pk)))
@@ -809,14 +885,13 @@ class DeviceBamReader:
             if ne.value == ctypes.c_size_t(-1).value:                   # not coordinate sorted: runs from the tid column
                 tid = b.tid
                 lo = np.concatenate([[0], np.flatnonzero(np.diff(tid)) + 1])
+                tids = tid[lo]
             else:
                 lo = edges[:ne.value].astype(np.int64)
+                tids = np.empty(max(1, ne.value), dtype=np.int32)    # the contig of every run came back with the edges
+                _native.check(lib.tdt_ingest_edge_tids(self._h, _native.ptr(tids), ne.value))
+                tids = tids[:ne.value]
             hi = np.concatenate([lo[1:], [n.value]])
-            tids = np.empty(len(lo), dtype=np.int32)
-            for j, l in enumerate(lo):                                   # one 4-byte read per run
-                t = np.empty(1, dtype=np.int32)
-                _native.check(lib.tdt_copy_to_host(ctx.handle, _native.ptr(t), b.dev["tid"] + 4 * int(l), 4))
-                tids[j] = t[0]
             b.runs = [(int(t), int(l), int(h)) for t, l, h in zip(tids, lo, hi)]
             if self.retain:
                 rh = ctypes.c_void_p()
@@ -836,10 +911,11 @@ class DeviceBamReader:
         """safe whatever the lifetime of a ``batches()`` generator: the reader thread (which calls tdt_ingest_prefetch on the handle and
         reads the file) is stopped and joined before the handle is destroyed and the file closed"""
         self._stop.set()
-        th = getattr(self, "_span_thread", None)
-        if th is not None and th.is_alive() and th is not __import__("threading").current_thread():
-            th.join()
-        self._span_thread = None
+        for attr in ("_span_thread", "_read_thread"):
+            th = getattr(self, attr, None)
+            if th is not None and th.is_alive() and th is not __import__("threading").current_thread():
+                th.join()
+            setattr(self, attr, None)
         if self._h:
             self.ctx.lib.tdt_ingest_destroy(self._h)
             self._h = None

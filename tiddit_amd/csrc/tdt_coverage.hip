@@ -1679,6 +1679,25 @@ extern "C" int tdt_cov_finish(tdt_cov *c, int tid, double *out) {
     return cov_status(c);
 }
 
+// every contig's bins at once, contig t at out + tdt_cov_offset(t): one finalize launch, one copy, one wait — a header with thousands
+// of contigs (GRCh38 with its alt / decoy / HLA contigs) paid a launch + copy + wait per contig through tdt_cov_finish
+extern "C" int tdt_cov_finish_all(tdt_cov *c, double *out) {
+    if (!c || (!out && c->total_bins)) {
+        tdt_set_error("tdt_cov_finish_all: bad argument");
+        return TDT_E_ARG;
+    }
+    TDT_HIP(hipSetDevice(c->ctx->device));
+    const size_t nb = (size_t)c->total_bins;
+    if (!nb) return cov_status(c);
+    void *d_out = nullptr;
+    int rc = tdt_scratch(c->ctx, 0, nb * 8, &d_out);
+    if (rc) return rc;
+    rc = tdt_cov_finish_all_device(c, (double *)d_out);
+    if (rc) return rc;
+    TDT_HIP(hipMemcpyAsync(out, d_out, nb * 8, hipMemcpyDeviceToHost, c->ctx->stream));
+    return cov_status(c);
+}
+
 extern "C" int tdt_cov_kept(tdt_cov *c, int64_t *kept) {
     if (!c || !kept) return TDT_E_ARG;
     TDT_HIP(hipSetDevice(c->ctx->device));

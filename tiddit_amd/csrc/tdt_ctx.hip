@@ -126,6 +126,14 @@ extern "C" int tdt_ctx_sync(tdt_ctx *c) {
     return TDT_OK;
 }
 
+// A helper thread of the caller that pins host memory (tdt_host_alloc) or only ever hands pointers to the library makes the
+// context's device its current one first (pinned allocations belong to the calling thread's current device).
+extern "C" int tdt_ctx_bind_thread(tdt_ctx *c) {
+    if (!c) return TDT_E_ARG;
+    TDT_HIP(hipSetDevice(c->device));
+    return TDT_OK;
+}
+
 extern "C" void *tdt_ctx_stream(tdt_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 extern "C" int tdt_ctx_set_stream(tdt_ctx *c, void *s) {

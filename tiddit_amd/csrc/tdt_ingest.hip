@@ -35,6 +35,7 @@ const char *const tdt_variant_ingest = ""
 #define ING_SEG 16384
 #endif
 #define ING_NONE 0xffffffffu
+#define ING_EDGES 8191                       // contig runs of one batch the device reports (more: the caller derives them from the tid column)
 #define ING_MAXREC ((ING_SEG + 35) / 36)      // a record is at least 4 + 32 bytes long
 
 __device__ __forceinline__ unsigned ld_u32(const unsigned char *p) {
@@ -296,12 +297,18 @@ __global__ __launch_bounds__(64) void bam_decode_fields_serial(const unsigned ch
 }
 
 // positions where tid changes (i = 0 included): the per-contig runs of a coordinate-sorted batch
+// (the contig id at every edge rides along: a human reference with its alt / decoy / HLA contigs has thousands of runs per batch, and a
+// 4-byte copy per run to learn its tid was 40 ms of a 25-Mb job)
 __global__ void bam_tid_edges(const int32_t *__restrict__ tid, size_t n, unsigned *__restrict__ edges, unsigned cap, unsigned *__restrict__ n_edges) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (i == 0 || tid[i] != tid[i - 1]) {
+    const int32_t t = tid[i];
+    if (i == 0 || t != tid[i - 1]) {
         const unsigned k = atomicAdd(n_edges, 1u);
-        if (k < cap) edges[k] = (unsigned)i;
+        if (k < cap) {
+            edges[k] = (unsigned)i;
+            edges[cap + 1 + k] = (unsigned)t;
+        }
     }
 }
 
@@ -361,6 +368,7 @@ struct tdt_ingest {
     size_t n_records = 0, rec_cap = 0;
     IngestOut O{};
     std::vector<unsigned> edges;
+    std::vector<int32_t> edge_tids;              // the contig id of the run that starts at edges[k]
     bool edges_overflow = false;
     bool failed = false;                           // a push returned an error: the stream position is undefined from then on
     size_t host_chases = 0;                        // batches whose record chain had to be chased on the host
@@ -917,6 +925,7 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     g->out_len = T;
     g->n_records = 0;
     g->edges.clear();
+    g->edge_tids.clear();
     g->edges_overflow = false;
     g->t_have_find = g->t_have_decode = false;
     g->t_chain_ms = 0;
@@ -945,9 +954,9 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     unsigned *d_hint = (unsigned *)((char *)g->seg.p + 4 * segb + relb);
     unsigned *d_first = (unsigned *)g->seg.p, *d_exit = (unsigned *)((char *)g->seg.p + segb), *d_count = (unsigned *)((char *)g->seg.p + 2 * segb),
              *d_base = (unsigned *)((char *)g->seg.p + 3 * segb);
-    if (g->pin.cap < 4 * segb + 65536) {
+    if (g->pin.cap < 4 * segb + 8 * (ING_EDGES + 1)) {
         if (g->pin.p) (void)hipHostFree(g->pin.p);
-        g->pin.cap = 4 * segb + 65536 + segb;
+        g->pin.cap = 4 * segb + 8 * (ING_EDGES + 1) + segb;
         TDT_HIP(hipHostMalloc(&g->pin.p, g->pin.cap));
     }
     unsigned *h_first = (unsigned *)g->pin.p, *h_exit = (unsigned *)((char *)g->pin.p + segb), *h_count = (unsigned *)((char *)g->pin.p + 2 * segb),
@@ -1058,7 +1067,7 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
     if (n) {
         const size_t N = n;
         const size_t a4 = (N * 4 + 255) & ~(size_t)255, a2 = (N * 2 + 255) & ~(size_t)255, a1 = (N + 255) & ~(size_t)255, a8 = (N * 8 + 255) & ~(size_t)255;
-        rc = ing_grow(g, g->soa, 9 * a4 + a2 + a1 + 3 * a8 + 4096);
+        rc = ing_grow(g, g->soa, 9 * a4 + a2 + a1 + 3 * a8 + 8 * (ING_EDGES + 1) + 256);
         if (rc) return rc;
         char *p = (char *)g->soa.p;
         IngestOut &O = g->O;
@@ -1076,7 +1085,7 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         O.cigar_last = (uint32_t *)p; p += a4;
         O.flag = (uint16_t *)p; p += a2;
         O.mapq = (uint8_t *)p; p += a1;
-        unsigned *d_edges = (unsigned *)p;                         // 1023 edges + counter
+        unsigned *d_edges = (unsigned *)p;                         // ING_EDGES edges, the counter, ING_EDGES contig ids
         TDT_HIP(hipMemcpyAsync(d_base, h_base, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
         if (table_dirty) {
             TDT_HIP(hipMemcpyAsync(d_first, h_first, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
@@ -1091,17 +1100,27 @@ static int ing_push(tdt_ingest *g, const uint8_t *comp, size_t len, size_t skip,
         TDT_CHECK_LAUNCH();
         if (g->tev[3]) (void)hipEventRecord(g->tev[3], st);
         g->t_have_decode = g->tev[2] && g->tev[3];
-        TDT_HIP(hipMemsetAsync(d_edges + 1023, 0, 4, st));
-        hipLaunchKernelGGL(bam_tid_edges, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, O.tid, N, d_edges, 1023u, d_edges + 1023);
+        TDT_HIP(hipMemsetAsync(d_edges + ING_EDGES, 0, 4, st));
+        hipLaunchKernelGGL(bam_tid_edges, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, O.tid, N, d_edges, (unsigned)ING_EDGES, d_edges + ING_EDGES);
         TDT_CHECK_LAUNCH();
         unsigned *h_edges = (unsigned *)((char *)g->pin.p + 4 * segb);
-        TDT_HIP(hipMemcpyAsync(h_edges, d_edges, 4096, hipMemcpyDeviceToHost, st));
+        // (the counter first: a sorted file has a handful of runs per batch, and only that many entries of either half are copied... the
+        // count is not known before the copy, so both halves travel whole: 64 KB)
+        TDT_HIP(hipMemcpyAsync(h_edges, d_edges, 8 * (ING_EDGES + 1) - 4, hipMemcpyDeviceToHost, st));
         TDT_HIP(hipStreamSynchronize(st));
-        const unsigned ne = h_edges[1023];
-        g->edges_overflow = ne > 1023;                              // not coordinate sorted: the caller derives runs from tid itself
+        const unsigned ne = h_edges[ING_EDGES];
+        g->edges_overflow = ne > ING_EDGES;                         // not coordinate sorted: the caller derives runs from tid itself
+        g->edge_tids.clear();
         if (!g->edges_overflow) {
-            g->edges.assign(h_edges, h_edges + ne);
-            std::sort(g->edges.begin(), g->edges.end());
+            std::vector<std::pair<unsigned, int32_t>> ev(ne);       // (the kernel's slots are in arrival order)
+            for (unsigned k = 0; k < ne; k++) ev[k] = {h_edges[k], (int32_t)h_edges[ING_EDGES + 1 + k]};
+            std::sort(ev.begin(), ev.end());
+            g->edges.resize(ne);
+            g->edge_tids.resize(ne);
+            for (unsigned k = 0; k < ne; k++) {
+                g->edges[k] = ev[k].first;
+                g->edge_tids[k] = ev[k].second;
+            }
         }
     }
     g->n_records = n;
@@ -1254,6 +1273,16 @@ extern "C" int tdt_ingest_edges(tdt_ingest *g, uint32_t *edges, size_t cap, size
     }
     *n = g->edges_overflow ? (size_t)-1 : g->edges.size();
     for (size_t i = 0; i < g->edges.size() && i < cap; i++) edges[i] = g->edges[i];
+    return TDT_OK;
+}
+
+// the contig id of every run of tdt_ingest_edges (same order); nothing when that call reported (size_t)-1
+extern "C" int tdt_ingest_edge_tids(tdt_ingest *g, int32_t *tids, size_t cap) {
+    if (!g || (cap && !tids)) {
+        tdt_set_error("tdt_ingest_edge_tids: bad argument");
+        return TDT_E_ARG;
+    }
+    for (size_t i = 0; i < g->edge_tids.size() && i < cap; i++) tids[i] = g->edge_tids[i];
     return TDT_OK;
 }
 

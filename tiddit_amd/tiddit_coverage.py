@@ -185,6 +185,12 @@ class CoverageHistogram:
         """float64[total_bins()] on the device; contig c occupies [offset(c), offset(c)+nbins(c))."""
         _native.check(self.lib.tdt_cov_finish_all_device(self.handle, d_out))
 
+    def finish_all(self):
+        """float64[total_bins()] on the host; contig c occupies [offset(c), offset(c) + nbins(c))"""
+        out = numpy.empty(max(1, self.total_bins()), dtype=numpy.float64)
+        _native.check(self.lib.tdt_cov_finish_all(self.handle, _native.ptr(out)))
+        return out[:self.total_bins()]
+
     def finish(self, contig):
         nb, _ = self.nbins(contig)
         out = numpy.empty(nb, dtype=numpy.float64)

@@ -452,10 +452,11 @@ def _scan(bam_file_name, min_q, max_ins, min_contig, min_anchor_len, min_clip_le
             READER_SECONDS["pushes"] = len(reader.timings)
     reader.close()
     chromosomes = [n for n, ok in zip(names, big) if ok]
-    if reduce_bins is None:
+    if reduce_bins is None and len(chromosomes) <= 64:
         coverage = {n: hist.finish(n) for n in chromosomes}
     else:
-        allbins = reduce_bins(hist)
+        # (a header of hundreds of kept contigs — GRCh38's alt contigs — or the N-rank job's reduced bins: every contig's bins in one piece)
+        allbins = reduce_bins(hist) if reduce_bins is not None else hist.finish_all()
         coverage = {}
         for i, n in enumerate(names):
             if big[i]:
