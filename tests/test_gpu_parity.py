@@ -680,6 +680,7 @@ def test_gc_of_many_small_contigs_in_groups(tmp_path, monkeypatch):
     goes to the device in GROUPS (tdt_gc_bins_fasta_many: one copy in, one launch per contig, one wait): contigs wrapped at different
     widths in one file, one-line and one-base contigs, an empty contig, a last contig without a final line end, groups of every size
     (the batch limit forced down), contigs above the grouping limit in between — all equal to the oracle per contig, keys in call order"""
+    from tiddit_amd import tiddit_gc
     rng = np.random.default_rng(77)
     path = str(tmp_path / "many.fa")
     seqs, order = {}, []
