@@ -23,6 +23,12 @@ const char *const tdt_variant_inflate2 = ""
 #ifdef B2_EXP_NOLIT
     " B2_EXP_NOLIT"
 #endif
+#ifdef B2_EXP_NOOWN
+    " B2_EXP_NOOWN"
+#endif
+#ifdef B2_EXP_NOREPLAY
+    " B2_EXP_NOREPLAY"
+#endif
 #ifdef B2_HOP2
     " B2_HOP2"
 #endif
@@ -53,6 +59,12 @@ const char *const tdt_variant_inflate2 = ""
 #ifdef B2_WAVES
     " B2_WAVES"
 #endif
+#ifdef B2_WBITS
+    " B2_WBITS"
+#endif
+#ifdef B2_W2
+    " B2_W2"
+#endif
     ;
 
 #include "tdt_common.h"
@@ -76,6 +88,12 @@ const char *const tdt_variant_inflate2 = ""
 #define B2_PARMAX 16                       // longest match a lane copies by itself (bytes); 32 with two loads was measured: slower
 #ifndef B2_HOP2
 #define B2_HOP2 1
+#endif
+#ifndef B2_W2
+#define B2_W2 0                            // 1: TWO windows (128 bit offsets) per trip of the symbol loop — see the B2_W2 loop below
+#endif
+#ifndef B2_WBITS
+#define B2_WBITS 64                        // bit offsets a window's chain walk accepts (measurement builds: 32 / 16 — what a window costs apart from its symbols)
 #endif
 #ifndef B2_PHASED
 #define B2_PHASED 0                        // 1: all loads of the window's independent copies first, one wait, then all their stores (measured in round 4:
@@ -289,6 +307,105 @@ __device__ __forceinline__ unsigned b2_scan(unsigned v) {
                  "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
                  : "+v"(v));
     return v;
+}
+
+// two independent inclusive prefix sums over the 64 lanes, their DPP steps interleaved: a step's result is read two instructions
+// later (the other value's step + one wait state), so the pair costs little more than one scan
+__device__ __forceinline__ void b2_scan2(unsigned &a, unsigned &b) {
+#define B2_S2(CTRL) "v_add_u32_dpp %0, %0, %0 " CTRL "\n\tv_add_u32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+    asm volatile("s_nop 1\n\t"
+                 B2_S2("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 B2_S2("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 B2_S2("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 B2_S2("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+                 B2_S2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 B2_S2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b));
+#undef B2_S2
+}
+
+// B2_W2: what the symbol starting `q` bits into the stream would be, for the lane's own q.  -> pk = the chain walk's packed word (bits 7:0 the
+// lane one symbol ahead, 64 when that hop leaves the window; from bit 8 where the walk stands after two symbols), sy = what the symbol
+// writes in ONE word: bits 8:0 the number of output bytes (0 end of block, 1 literal, 3..258 match), from bit 9 the literal byte or the
+// match's distance - 1
+__device__ __forceinline__ void b2_spec(const unsigned *win, const unsigned *lut_ll, const unsigned *lut_d, unsigned q, int lane, unsigned &pk, unsigned &sy) {
+    const unsigned qd = (q >> 5) & 127, qs = q & 31;
+    const unsigned wa = win[qd], wb = win[qd + 1], wc = win[qd + 2];
+    const unsigned lo = __builtin_amdgcn_alignbit(wb, wa, qs), hi = __builtin_amdgcn_alignbit(wc, wb, qs);
+    const unsigned e1 = lut_ll[lo & ((1u << B2_TB_LL) - 1)];
+    const unsigned step1 = B2_STEP(e1);
+    const unsigned e2 = lut_d[__builtin_amdgcn_ubfe(lo, step1, B2_TB_D)];
+    const bool is_len = e1 & B2_F_LEN;
+    const unsigned nxt = (unsigned)lane + step1 + (is_len ? B2_STEP(e2) : 0u);
+    const unsigned m1 = nxt < 64u ? nxt : 64u;
+    const unsigned n2r = (unsigned)__builtin_amdgcn_ds_bpermute((int)(m1 << 2), (int)nxt);
+    pk = m1 | ((nxt < 64u ? n2r : nxt) << 8);
+    const unsigned l1 = e1 & 15, eb1 = (e1 >> 4) & 15, litv = (e1 >> 8) & 0x1ff;
+    const unsigned mlen = litv + __builtin_amdgcn_ubfe(lo >> l1, 0u, eb1);
+    const unsigned l2 = e2 & 15, eb2 = (e2 >> 4) & 15, base2 = (e2 >> 8) & 0x7fff;
+    const unsigned dist = base2 + __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(hi, lo, (step1 + l2) & 31), 0u, eb2);
+    sy = is_len ? (mlen | ((dist - 1u) << 9)) : ((e1 & B2_F_EOB) ? 0u : (1u | (litv << 9)));
+}
+
+// B2_W2: the chain of true symbol starts through one set of 64 bit offsets, from lane `cur` (scalar; two symbols per hop).  Codes longer
+// than the LUTs are resolved on the way and their lane's `sy` patched (as in the one-window loop).  -> chain = the lanes on it, cur = where
+// the walk left the set (64 .. 111: that many bits behind the set's first; the bits past an end of block when stop == 2)
+__device__ __forceinline__ void b2_walk(const unsigned *win, const unsigned *lut_ll, const unsigned *lut_d, const unsigned short *sorted_ll,
+                                        const unsigned short *meta_ll, const unsigned short *sorted_d, const unsigned short *meta_d, unsigned qbase,
+                                        int lane, unsigned pk, unsigned &sy, u64 &chain, unsigned &cur, unsigned &stop, unsigned &err) {
+    const unsigned start = cur;
+    for (;;) {
+        while (cur < 64u) {
+            const unsigned p2 = b2_rl(pk, cur);
+            asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(cur));
+            asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p2));       // (bits 5:0 = the next symbol's lane, or lane 0 when that hop leaves the set: undone below)
+            cur = p2 >> 8;
+        }
+        if (cur >= 256u) {
+            stop = 2;
+            cur -= 256u;
+            break;
+        }
+        if (cur < 128u) break;
+        const unsigned at = 63u - (unsigned)__builtin_clzll(chain);      // the chain's last member is the symbol the LUTs did not resolve
+        const unsigned qq = qbase + at, d = (qq >> 5) & 127, sh = qq & 31;
+        const unsigned w0 = b2_rfl(win[d]), w1 = b2_rfl(win[d + 1]), w2 = b2_rfl(win[d + 2]);
+        u64 v = ((u64)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+        unsigned e = b2_rfl(lut_ll[(unsigned)v & ((1u << B2_TB_LL) - 1)]);
+        if (e == B2_ESC) e = b2_long_code((unsigned)v, B2_TB_LL, B2_MODE_LL, sorted_ll, meta_ll, lane);
+        if (e == B2_ESC) {
+            err = B2_E_SYMBOL;
+            break;
+        }
+        unsigned used = e & 15;
+        v >>= used;
+        unsigned s_sy = 1u | (((e >> 8) & 0xff) << 9);
+        if (e & B2_F_EOB) {
+            s_sy = 0;
+            stop = 2;
+        } else if (e & B2_F_LEN) {
+            unsigned eb = (e >> 4) & 15;
+            const unsigned s_len = ((e >> 8) & 0x1ff) + ((unsigned)v & ((1u << eb) - 1));
+            v >>= eb;
+            used += eb;
+            unsigned ed = b2_rfl(lut_d[(unsigned)v & ((1u << B2_TB_D) - 1)]);
+            if (ed == B2_ESC) ed = b2_long_code((unsigned)v, B2_TB_D, B2_MODE_DIST, sorted_d, meta_d, lane);
+            if (ed == B2_ESC) {
+                err = B2_E_DIST;
+                break;
+            }
+            v >>= ed & 15;
+            eb = (ed >> 4) & 15;
+            const unsigned s_dist = ((ed >> 8) & 0x7fff) + ((unsigned)v & ((1u << eb) - 1));
+            used += (ed & 15) + eb;
+            s_sy = s_len | ((s_dist - 1u) << 9);
+        }
+        b2_wl(sy, s_sy, at);
+        cur = at + used;
+        if (stop == 2) break;
+    }
+    if (start != 0) chain &= ~1ull;                                 // (a walk that starts behind lane 0 never has lane 0 on its chain)
 }
 
 // 64 stream bits starting `q` bits into the stream, gathered from the LDS ring (any lane, any q inside the staged windows)
@@ -547,6 +664,110 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
         }
         // ---- the symbols of this block, a window of 64 bit offsets at a time
         B2_MARK(11);                                                  // (block header + code lengths + the two table builds)
+#if B2_W2
+        // ---- TWO windows per trip: the lanes decode the symbols that would start at bp + lane AND at bp + 64 + lane, the chain is walked
+        // through the first set and on through the second, and what a trip pays once whatever it decodes — the ring gather and the LUT round
+        // trips, the prefix sum, the memory round trip of the own-lane copies, the cursor and the ring refill — is paid once per ~11 symbols
+        // instead of once per 5.4 (a -DB2_WBITS=32 / 16 build prices that part at half of a 64-bit window's time: profiles/r06_ab_inflate_w2.txt).
+        // A symbol's output size, literal byte and distance travel in one register (b2_spec), so the second set costs two live registers
+        // across the first one's walk.
+        for (;;) {
+            unsigned pk0, sy0, pk1, sy1;
+            b2_spec(win, lut_ll, lut_d, bp + (unsigned)lane, lane, pk0, sy0);
+            b2_spec(win, lut_ll, lut_d, bp + 64u + (unsigned)lane, lane, pk1, sy1);
+            u64 chain0 = 0, chain1 = 0;
+            unsigned stop = 0, cur = 0, adv = 0;
+            b2_walk(win, lut_ll, lut_d, sorted_ll, meta_ll, sorted_d, meta_d, bp, lane, pk0, sy0, chain0, cur, stop, err);
+            if (err != B2_OK) break;
+            if (stop != 2) {
+                cur -= 64u;                                             // (64 .. 111 behind the first set's first bit)
+                adv = 64u;
+                b2_walk(win, lut_ll, lut_d, sorted_ll, meta_ll, sorted_d, meta_d, bp + 64u, lane, pk1, sy1, chain1, cur, stop, err);
+                if (err != B2_OK) break;
+            }
+            adv += cur;
+            unsigned ol0 = b2_sel(chain0, sy0 & 0x1ffu, 0u), ol1 = b2_sel(chain1, sy1 & 0x1ffu, 0u);
+            unsigned incl0 = ol0, incl1 = ol1;
+            b2_scan2(incl0, incl1);
+            const unsigned tot0 = b2_rl(incl0, 63), tot = tot0 + b2_rl(incl1, 63);
+            const unsigned pos0 = op + incl0 - ol0, pos1 = op + tot0 + incl1 - ol1;
+            const bool copy0 = ol0 >= 3, copy1 = ol1 >= 3;
+            const unsigned x0 = sy0 >> 9, x1 = sy1 >> 9;                // literal byte / distance - 1
+            if (op + tot > isize || __ballot((copy0 && x0 >= pos0) || (copy1 && x1 >= pos1))) {
+                err = op + tot > isize ? B2_E_OVERRUN : B2_E_DIST;
+                break;
+            }
+            if (ol0 == 1) dst[pos0] = (unsigned char)x0;
+            if (ol1 == 1) dst[pos1] = (unsigned char)x1;
+            const unsigned srco0 = pos0 - x0 - 1u, srco1 = pos1 - x1 - 1u;
+            // own-lane copies of BOTH sets: sources wholly before this trip's output (op) and at most B2_PARMAX bytes.  ALL their loads, ONE
+            // wait, all their stores: a trip pays one memory round trip for them.  (The loaded words are deliberately not initialised and the
+            // wait is unconditional: a zeroed register that a masked load may still be writing, or a wait the compiler can only see on one side
+            // of an exec branch, makes its wait-count pass drain the queue — the previous trip's stores included — BEFORE the loads go out.)
+            const bool wide0 = copy0 && srco0 + ol0 <= op && ol0 <= B2_PARMAX && ol0 >= 4 && srco0 + 16 <= isize;
+            const bool wide1 = copy1 && srco1 + ol1 <= op && ol1 <= B2_PARMAX && ol1 >= 4 && srco1 + 16 <= isize;
+            const bool tri0 = copy0 && ol0 == 3 && srco0 + 3 <= op, tri1 = copy1 && ol1 == 3 && srco1 + 3 <= op;   // (the dword read ends at srco + 4 <= pos + 1 <= isize)
+            // The lanes on a chain are few (5.4 of a set's 64), so the two sets' own-lane copies share ONE set of copy instructions: a lane
+            // copies the first set's match if it has one, else the second set's; a lane with one in both (one trip in eight) leaves its
+            // second to the replay loop.
+            const bool par0 = wide0 || tri0, par1 = (wide1 || tri1) && !par0;
+            const bool wide = par0 ? wide0 : (wide1 && par1), tri = par0 ? tri0 : (tri1 && par1);
+            const unsigned olm = par0 ? ol0 : ol1, posm = par0 ? pos0 : pos1, srcom = par0 ? srco0 : srco1;
+            unsigned w3, tw;
+            B2U128 vv;
+            asm volatile("" : "=v"(w3), "=v"(tw), "=v"(vv.w[0]), "=v"(vv.w[1]), "=v"(vv.w[2]), "=v"(vv.w[3]));
+            if (tri) w3 = reinterpret_cast<const B2U32 *>(dst + srcom)->v;
+            if (wide) {
+                vv = *reinterpret_cast<const B2U128 *>(dst + srcom);
+                tw = reinterpret_cast<const B2U32 *>(dst + (srcom + olm - 4u))->v;
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0), nothing else
+            if (tri) {
+                reinterpret_cast<B2U16 *>(dst + posm)->v = (unsigned short)w3;
+                dst[posm + 2] = (unsigned char)(w3 >> 16);
+            }
+            if (wide) {
+                const bool g8 = olm >= 8, g12 = olm >= 12, g16 = olm >= 16;
+                reinterpret_cast<B2U32 *>(dst + posm)->v = vv.w[0];
+                reinterpret_cast<B2U32 *>(dst + (posm + (g8 ? 4u : 0u)))->v = g8 ? vv.w[1] : vv.w[0];
+                reinterpret_cast<B2U32 *>(dst + (posm + (g12 ? 8u : 0u)))->v = g12 ? vv.w[2] : vv.w[0];
+                reinterpret_cast<B2U32 *>(dst + (posm + (g16 ? 12u : 0u)))->v = g16 ? vv.w[3] : vv.w[0];
+                reinterpret_cast<B2U32 *>(dst + (posm + olm - 4u))->v = tw;
+            }
+            // the others in stream order (they may read each other's output, and the second set's may read the first set's)
+#define B2_REPLAY(copy_, par_, ol_, x_, pos_, srco_)                                                                   \
+            do {                                                                                                       \
+                u64 mm = __ballot(copy_ && !par_);                                                                     \
+                while (mm) {                                                                                           \
+                    const unsigned l = (unsigned)__builtin_ctzll(mm);                                                  \
+                    mm &= ~(1ull << l);                                                                                \
+                    const unsigned len = b2_rl(ol_, l), dd = b2_rl(x_, l) + 1u, p = b2_rl(pos_, l), so = b2_rl(srco_, l); \
+                    if (dd >= len) {                                                                                   \
+                        for (unsigned i = (unsigned)lane; i < len; i += 64) dst[p + i] = dst[so + i];                  \
+                    } else {                                                                                           \
+                        unsigned j = (unsigned)lane % dd;                                                              \
+                        const unsigned step = 64u % dd;                                                                \
+                        for (unsigned i = (unsigned)lane; i < len; i += 64) {                                          \
+                            dst[p + i] = dst[so + j];                                                                  \
+                            j += step;                                                                                 \
+                            j -= j >= dd ? dd : 0u;                                                                    \
+                        }                                                                                              \
+                    }                                                                                                  \
+                }                                                                                                      \
+            } while (0)
+            B2_REPLAY(copy0, par0, ol0, x0, pos0, srco0);
+            B2_REPLAY(copy1, par1, ol1, x1, pos1, srco1);
+#undef B2_REPLAY
+            op += tot;
+            bp += adv;
+            if (bp > end_bit) {                                     // a valid block ends (EOB included) inside the payload
+                err = B2_E_INPUT;
+                break;
+            }
+            B2_ENSURE();
+            if (err != B2_OK || stop == 2) break;
+        }
+#else
         for (;;) {
             // every lane: the symbol that would start at bit bp + lane
             // (three dwords from the ring; every field but the distance's extra bits lies in the first 32 stream bits:
@@ -567,9 +788,9 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             // lane i reads next[next[i]]), and the walk reads both with one v_readlane — the scalar / vector hand-over, half of a hop's
             // ≈ 185 cycles, is paid once per two symbols.  m1 = the lane one symbol ahead, 64 when that hop leaves the window;
             // n2 = where the walk stands after two symbols (the exit value of whichever hop leaves the window first).
-            const unsigned m1 = nxt < 64u ? nxt : 64u;
+            const unsigned m1 = nxt < (unsigned)B2_WBITS ? nxt : 64u;
             const unsigned n2r = (unsigned)__builtin_amdgcn_ds_bpermute((int)(m1 << 2), (int)nxt);   // (m1 = 64 reads lane 0: not used)
-            const unsigned pack2 = m1 | ((nxt < 64u ? n2r : nxt) << 8);
+            const unsigned pack2 = m1 | ((nxt < (unsigned)B2_WBITS ? n2r : nxt) << 8);
 #endif
 #ifdef B2_PROF
             asm volatile("" :: "v"(nxt));
@@ -595,7 +816,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             u64 chain = 0;
             unsigned stop = 0;                                      // 2 = end of block
             for (;;) {
-                while (cur < 64) {
+                while (cur < (unsigned)B2_WBITS) {
 #if B2_HOP2
                     const unsigned p2 = b2_rl(pack2, cur);
                     asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(cur));
@@ -674,7 +895,11 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             const unsigned srco = pos - dist;                       // first source byte of this lane's match
             // Matches whose source lies wholly before this window's output cannot depend on anything decoded in it: each of
             // those is copied by its own lane, all at once (3 bytes unconditionally — the minimum match — then the rest).
+#ifdef B2_EXP_NOOWN    // ablation (output wrong): what the own-lane copies cost
+            const bool par = false;
+#else
             const bool par = copy && srco + mlen <= op && mlen <= B2_PARMAX;
+#endif
             const bool wide = par && mlen >= 4 && srco + 16 <= isize;   // the 16-byte read stays inside this block's output
 #if B2_PIPE
             // (measurement variant) The copies are PIPELINED over two windows: this window was decoded while the previous window's loads
@@ -801,6 +1026,9 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
 #endif
 #if !B2_PIPE
             u64 mm = __ballot(copy && !par);
+#ifdef B2_EXP_NOREPLAY  // ablation (output wrong): what the replayed matches cost
+            mm = 0;
+#endif
 #if B2_PHASED
             if (e_len) mm &= ~(1ull << e_lane);
 #endif
@@ -837,6 +1065,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             B2_MARK(6);
             if (err != B2_OK || stop == 2) break;
         }
+#endif
 #if B2_PIPE
         if (err == B2_OK) B2_FLUSH();                              // the last window's copies, before the next DEFLATE block writes behind them
 #endif
