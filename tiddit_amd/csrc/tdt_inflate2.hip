@@ -65,6 +65,9 @@ const char *const tdt_variant_inflate2 = ""
 #ifdef B2_W2
     " B2_W2"
 #endif
+#ifdef B2_W2_EARLY
+    " B2_W2_EARLY"
+#endif
     ;
 
 #include "tdt_common.h"
@@ -91,6 +94,11 @@ const char *const tdt_variant_inflate2 = ""
 #endif
 #ifndef B2_W2
 #define B2_W2 0                            // 1: TWO windows (128 bit offsets) per trip of the symbol loop — see the B2_W2 loop below
+#endif
+#ifndef B2_W2_EARLY
+#define B2_W2_EARLY 0                      // B2_W2: 1 = each set's first long match that reads only earlier trips' output is copied by all lanes in the own-lane
+                                           // phases (measured: +4.5 % / +7 % SLOWER than B2_W2 without it — the instructions it adds to every trip cost more
+                                           // than the replay round trips it saves, as B2_EARLYM in the one-window loop)
 #endif
 #ifndef B2_WBITS
 #define B2_WBITS 64                        // bit offsets a window's chain walk accepts (measurement builds: 32 / 16 — what a window costs apart from its symbols)
@@ -716,12 +724,44 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
             unsigned w3, tw;
             B2U128 vv;
             asm volatile("" : "=v"(w3), "=v"(tw), "=v"(vv.w[0]), "=v"(vv.w[1]), "=v"(vv.w[2]), "=v"(vv.w[3]));
+#if B2_W2_EARLY
+            // Each set's FIRST match that its lane cannot copy (longer than B2_PARMAX, or the lane's second) but that reads only what earlier
+            // trips wrote is independent of everything this trip writes: ALL lanes copy it — lane k the k-th dword, the lane behind them the
+            // last four bytes — with one load in the load phase and one store in the store phase, instead of a round trip of its own in
+            // the replay loop (three replayed matches in four are of this kind: profiles/r04_inflate_windows.txt).
+            const u64 ml0 = __ballot(copy0 && !par0 && srco0 + ol0 <= op && ol0 - 4u <= 252u);
+            const u64 ml1 = __ballot(copy1 && !par1 && srco1 + ol1 <= op && ol1 - 4u <= 252u);
+            unsigned e_len0 = 0, e_p0 = 0, e_so0 = 0, e_len1 = 0, e_p1 = 0, e_so1 = 0;
+            u64 e_bit0 = 0, e_bit1 = 0;
+            if (ml0) {
+                const unsigned l = (unsigned)__builtin_ctzll(ml0);
+                e_bit0 = 1ull << l;
+                e_len0 = b2_rl(ol0, l), e_p0 = b2_rl(pos0, l), e_so0 = b2_rl(srco0, l);
+            }
+            if (ml1) {
+                const unsigned l = (unsigned)__builtin_ctzll(ml1);
+                e_bit1 = 1ull << l;
+                e_len1 = b2_rl(ol1, l), e_p1 = b2_rl(pos1, l), e_so1 = b2_rl(srco1, l);
+            }
+            const unsigned nd0 = e_len0 >> 2, nd1 = e_len1 >> 2;
+            const bool ea0 = (unsigned)lane < nd0 || ((unsigned)lane == nd0 && (e_len0 & 3u));
+            const bool ea1 = (unsigned)lane < nd1 || ((unsigned)lane == nd1 && (e_len1 & 3u));
+            const unsigned eo0 = (unsigned)lane < nd0 ? 4u * (unsigned)lane : e_len0 - 4u, eo1 = (unsigned)lane < nd1 ? 4u * (unsigned)lane : e_len1 - 4u;
+            unsigned ev0, ev1;
+            asm volatile("" : "=v"(ev0), "=v"(ev1));
+            if (ea0) ev0 = reinterpret_cast<const B2U32 *>(dst + (e_so0 + eo0))->v;
+            if (ea1) ev1 = reinterpret_cast<const B2U32 *>(dst + (e_so1 + eo1))->v;
+#endif
             if (tri) w3 = reinterpret_cast<const B2U32 *>(dst + srcom)->v;
             if (wide) {
                 vv = *reinterpret_cast<const B2U128 *>(dst + srcom);
                 tw = reinterpret_cast<const B2U32 *>(dst + (srcom + olm - 4u))->v;
             }
             __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0), nothing else
+#if B2_W2_EARLY
+            if (ea0) reinterpret_cast<B2U32 *>(dst + (e_p0 + eo0))->v = ev0;
+            if (ea1) reinterpret_cast<B2U32 *>(dst + (e_p1 + eo1))->v = ev1;
+#endif
             if (tri) {
                 reinterpret_cast<B2U16 *>(dst + posm)->v = (unsigned short)w3;
                 dst[posm + 2] = (unsigned char)(w3 >> 16);
@@ -735,9 +775,9 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 reinterpret_cast<B2U32 *>(dst + (posm + olm - 4u))->v = tw;
             }
             // the others in stream order (they may read each other's output, and the second set's may read the first set's)
-#define B2_REPLAY(copy_, par_, ol_, x_, pos_, srco_)                                                                   \
+#define B2_REPLAY(copy_, par_, ol_, x_, pos_, srco_, done_)                                                            \
             do {                                                                                                       \
-                u64 mm = __ballot(copy_ && !par_);                                                                     \
+                u64 mm = __ballot(copy_ && !par_) & ~(done_);                                                          \
                 while (mm) {                                                                                           \
                     const unsigned l = (unsigned)__builtin_ctzll(mm);                                                  \
                     mm &= ~(1ull << l);                                                                                \
@@ -755,8 +795,13 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                     }                                                                                                  \
                 }                                                                                                      \
             } while (0)
-            B2_REPLAY(copy0, par0, ol0, x0, pos0, srco0);
-            B2_REPLAY(copy1, par1, ol1, x1, pos1, srco1);
+#if B2_W2_EARLY
+            B2_REPLAY(copy0, par0, ol0, x0, pos0, srco0, e_bit0);
+            B2_REPLAY(copy1, par1, ol1, x1, pos1, srco1, e_bit1);
+#else
+            B2_REPLAY(copy0, par0, ol0, x0, pos0, srco0, 0ull);
+            B2_REPLAY(copy1, par1, ol1, x1, pos1, srco1, 0ull);
+#endif
 #undef B2_REPLAY
             op += tot;
             bp += adv;
