@@ -393,3 +393,78 @@ def test_random_rows_through_the_blob_equal_the_literal_merge(tmp_path):
             clipped = sum(1 for x in pos for y in pos[x] for v, ln in zip(pos[x][y][0::3], [dict(CONTIGS)[x]] * len(pos[x][y][0::3])) if int(v) == ln)
         assert clipped > 0
         t.close()
+
+
+def test_candidate_dictionaries_built_with_the_cpython_api_equal_the_python_loop():
+    """tiddit_amd/_pycand (csrc/tdt_pycand.c) against the Python loop of tiddit_cluster._native_candidates on random member arrays: equal
+    dictionaries, the same key order at every level, the same value types, empty candidates, names with non-ASCII characters — and the
+    argument checks (a row that points outside the arrays is refused, not read)"""
+    from tiddit_amd import _pycand
+    rng = np.random.default_rng(20260930)
+    nc = 400
+    nd, ns = rng.integers(0, 9, nc), rng.integers(0, 5, nc)
+    m = int((nd + ns).sum())
+    cand = np.stack([rng.integers(0, 7, nc), rng.permutation(nc) + 3, nd, ns], 1).astype(np.int32)
+    cols = [rng.integers(-5, 2 ** 31 - 1, m).astype(np.int32) for _ in range(6)]
+    ori = [rng.integers(0, 2, m).astype(np.uint8) for _ in range(2)]
+    frag = ["frag:%d/é%d" % (i % 97, i) for i in range(m)]          # (repeated prefixes; multi-byte characters)
+    names = "\n".join(frag).encode()
+    sample = "WGS"
+    W = ("False", "True")
+    sA, eA, sB, eB, pA, pB = (c.tolist() for c in cols)
+    oA, oB = [W[x] for x in ori[0].tolist()], [W[x] for x in ori[1].tolist()]
+    want = [{} for _ in range(7)]
+    lo = 0
+    for bkt, cid, a, b in cand.tolist():
+        mid, hi = lo + a, lo + a + b
+        c = tiddit_cluster._new_candidate()
+        c["samples"].add(sample)
+        c["sample_discordants"][sample], c["sample_splits"][sample], c["sample_contigs"][sample] = set(frag[lo:mid]), set(frag[mid:hi]), set()
+        c["discordants"], c["splits"] = set(frag[lo:mid]), set(frag[mid:hi])
+        for side, pos, o, s, e in (("positions_A", pA, oA, sA, eA), ("positions_B", pB, oB, sB, eB)):
+            c[side]["splits"], c[side]["discordants"] = pos[mid:hi], pos[lo:mid]
+            c[side]["orientation_splits"], c[side]["orientation_discordants"] = o[mid:hi], o[lo:mid]
+            c[side]["start"], c[side]["end"] = s[lo:hi], e[lo:hi]
+        want[bkt][cid] = c
+        lo = hi
+    got = [{} for _ in range(7)]
+    assert _pycand.build(got, cand, names, *cols, *ori, sample) == nc
+    assert got == want
+    for g, w in zip(got, want):
+        assert list(g) == list(w)
+        for cid in g:
+            assert list(g[cid]) == list(w[cid]) == list(tiddit_cluster._new_candidate())
+            for side in ("positions_A", "positions_B"):
+                assert list(g[cid][side]) == list(w[cid][side])
+                for k, v in g[cid][side].items():
+                    assert [type(x) for x in v] == [type(x) for x in w[cid][side][k]]
+            assert g[cid]["discordants"] is not g[cid]["sample_discordants"][sample] and type(cid) is int
+    # ... and with is_mp / min_reads given, what tiddit_cluster._finish_candidates adds, for both library kinds: counts of DISTINCT names,
+    # the mode with CPython's first-inserted tie rule, the orientation vote, the extreme positions, the four region keys in their order.
+    # (Positions from a small range, so that modes have ties and repeats; candidates need a member.)
+    keep = (nd + ns) > 0
+    small = [rng.integers(0, 6, m).astype(np.int32) for _ in range(6)]
+    frag2 = ["f%d" % (i % 11) for i in range(m)]                 # repeated names inside a candidate: N_* < members
+    names2 = "\n".join(frag2).encode()
+    for is_mp in (False, True):
+        for min_reads in (1, 3):
+            ref = [{} for _ in range(7)]
+            _pycand.build(ref, cand[keep], names2, *small, *ori, sample)
+            wrapped = {"a": {str(k): ref[k] for k in range(7)}}
+            tiddit_cluster._finish_candidates(wrapped, is_mp, min_reads)
+            fin = [{} for _ in range(7)]
+            _pycand.build(fin, cand[keep], names2, *small, *ori, sample, is_mp, min_reads)
+            assert fin == ref
+            for g, w in zip(fin, ref):
+                for cid in g:
+                    assert list(g[cid]) == list(w[cid]) and all(type(g[cid][k]) is type(w[cid][k]) for k in g[cid])
+    with pytest.raises(ValueError):                              # a candidate without members cannot be finished (min() of nothing in the Python)
+        _pycand.build([{} for _ in range(7)], np.array([[0, 1, 0, 0]], dtype=np.int32), b"", *[c[:0] for c in cols], *[o[:0] for o in ori], sample, False, 1)
+    bad = cand.copy()
+    bad[-1, 2] += 1                                              # one member more than the arrays hold
+    with pytest.raises(ValueError):
+        _pycand.build([{} for _ in range(7)], bad, names, *cols, *ori, sample)
+    with pytest.raises(ValueError):
+        _pycand.build([{} for _ in range(3)], cand, names, *cols, *ori, sample)         # a bucket index beyond the slots
+    with pytest.raises(ValueError):
+        _pycand.build([{} for _ in range(7)], cand, names, cols[0][:-1], *cols[1:], *ori, sample)

@@ -38,7 +38,29 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_pycand(force=force, verbose=verbose)
     return SO
+
+
+def pycand_path():
+    import sysconfig
+    return os.path.join(HERE, "_pycand" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_pycand(force=False, verbose=False):
+    """the CPython extension that builds the candidate dictionaries of tiddit_cluster.main (csrc/tdt_pycand.c; gcc, host only).  Optional:
+    without the interpreter's headers tiddit_cluster keeps its Python loop."""
+    import sysconfig
+    src, out = os.path.join(CSRC, "tdt_pycand.c"), pycand_path()
+    inc = sysconfig.get_paths().get("include") or ""
+    if not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    if force or _newer(src, out):
+        cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-Wall", "-I" + inc, src, "-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

@@ -14,10 +14,17 @@ elsewhere are parsed as text by the literal loops below.  Reference quirks repro
 """
 from collections import Counter  # noqa: F401  (kept: callers of the reference module may import it from here)
 
+import os
+
 import numpy
 
 from .hostutil import quiet_gc
 from . import _native
+
+try:                                  # the CPython extension that builds the candidate dictionaries (csrc/tdt_pycand.c, built by tiddit_amd.build);
+    from . import _pycand             # without it — no interpreter headers where the package was built — the Python loop below does the same
+except ImportError:
+    _pycand = None
 
 # (orientation of read A, orientation of read B) -> which of (start, end) is the breakpoint side,
 # indexes into the 9-column discordants_*.tab row: 3=startA 4=endA 6=startB 7=endB   (:7-37)
@@ -345,7 +352,7 @@ def cluster_columns_device(posA, posB, off, epsilon, m, lab32, ctx=None):
                                               hi if lo >= 0 else 0, _native.ptr(lab32), None, None))
 
 
-def _native_candidates(tables, sample, is_mp, epsilon, m, min_contig, T):
+def _native_candidates(tables, sample, is_mp, epsilon, m, min_contig, T, min_reads=None):
     """tiddit_cluster.main (:47-254) from the native signal tables of this process: the signal table is written into pinned int32
     columns by the library, clustered on the device, and the members of every candidate come back as flat arrays in the reference's
     order — the Python below runs once per CANDIDATE.  -> candidates[chrA][chrB][cluster id] for the (chrA, *) pairs the tables hold."""
@@ -369,6 +376,14 @@ def _native_candidates(tables, sample, is_mp, epsilon, m, min_contig, T):
     slots = []                                              # per bucket: candidates[chrA][chrB]
     for a, b in zip(ba.tolist(), bb.tolist()):              # header order of (chrA, chrB): the loops of :140-147
         slots.append(candidates.setdefault(names[a], {}).setdefault(names[b], {}))
+    if _pycand is not None and os.environ.get("TIDDIT_PY_CANDIDATES") != "1":
+        # the same dictionaries built with the CPython API (csrc/tdt_pycand.c): 15 µs of bytecode per candidate become ~3 µs
+        # (with min_reads given also what _finish_candidates adds — counts, breakpoints, regions — straight from the member columns)
+        extra = () if min_reads is None else (bool(is_mp), int(min_reads))
+        _pycand.build(slots, g["cand"], g["names"], g["startA"], g["endA"], g["startB"], g["endB"], g["posA"], g["posB"], g["oriA"], g["oriB"], sample, *extra)
+        T["regroup + breakpoints"] = time.time() - t0
+        T["finished"] = min_reads is not None
+        return candidates
     W = ("False", "True")
     frag = g["names"].decode().split("\n")
     sA, eA, sB, eB, pA, pB = (g[k].tolist() for k in ("startA", "endA", "startB", "endB", "posA", "posB"))
@@ -446,10 +461,11 @@ def _main(prefix, chromosomes, contig_length, samples, is_mp, epsilon, m, max_in
         if ts is not None:
             ts.finish_writes()
     if native:
-        candidates = _native_candidates(tables, samples[0], is_mp, epsilon, m, min_contig, STAGE_SECONDS)
-        t0 = time.time()
-        _finish_candidates(candidates, is_mp, min_reads)
-        STAGE_SECONDS["regroup + breakpoints"] += time.time() - t0
+        candidates = _native_candidates(tables, samples[0], is_mp, epsilon, m, min_contig, STAGE_SECONDS, min_reads=min_reads)
+        if not STAGE_SECONDS.pop("finished", False):          # (the Python loop built them: counts, breakpoints and regions follow)
+            t0 = time.time()
+            _finish_candidates(candidates, is_mp, min_reads)
+            STAGE_SECONDS["regroup + breakpoints"] += time.time() - t0
         if sharded:
             # every rank holds the candidates of the chrA it owns: rank 0 puts them together in header order (the order of :140-147)
             import pickle
