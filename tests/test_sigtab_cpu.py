@@ -399,7 +399,7 @@ def test_candidate_dictionaries_built_with_the_cpython_api_equal_the_python_loop
     """tiddit_amd/_pycand (csrc/tdt_pycand.c) against the Python loop of tiddit_cluster._native_candidates on random member arrays: equal
     dictionaries, the same key order at every level, the same value types, empty candidates, names with non-ASCII characters — and the
     argument checks (a row that points outside the arrays is refused, not read)"""
-    from tiddit_amd import _pycand
+    _pycand = pytest.importorskip("tiddit_amd._pycand")          # (built by tiddit_amd.build when the interpreter's headers are there)
     rng = np.random.default_rng(20260930)
     nc = 400
     nd, ns = rng.integers(0, 9, nc), rng.integers(0, 5, nc)
