@@ -101,12 +101,17 @@ def test_tables_reproduce_the_fixture_and_the_literal_merge(small, tmp_path):
     tiddit_signal._forget_tables()
 
 
+@pytest.mark.parametrize("builder", ["cpython-api", "python-loop"])
 @pytest.mark.parametrize("is_mp", [False, True])
-def test_candidates_from_the_tables_equal_the_text_path_and_the_reference(small, tmp_path, monkeypatch, is_mp):
+def test_candidates_from_the_tables_equal_the_text_path_and_the_reference(small, tmp_path, monkeypatch, is_mp, builder):
     """tiddit_cluster.main twice on the same files — taking the native tables over, and parsing the text — with the device call
     replaced by the oracle's DBSCAN: the same nested dictionary, insertion order included; for the library's own orientation it is the
     compiled reference's (fixture), for the other one the restatement's"""
     fx, bam, contigs, rd, batches, d = small
+    if builder == "python-loop":                            # the dictionaries by tiddit_cluster's own loop instead of tiddit_amd/_pycand
+        monkeypatch.setenv("TIDDIT_PY_CANDIDATES", "1")
+    elif tiddit_cluster._pycand is None:
+        pytest.skip("tiddit_amd/_pycand was not built")
     P = fx["params"]
     min_q, max_ins, anchor, clip = scan_args(fx)
     big = [ln >= P["min_contig"] for ln in rd.lengths]
