@@ -47,9 +47,6 @@ const char *const tdt_variant_inflate2 = ""
 #ifdef B2_PROF
     " B2_PROF"
 #endif
-#ifdef B2_ROT
-    " B2_ROT"
-#endif
 #ifdef B2_STATS
     " B2_STATS"
 #endif
@@ -94,9 +91,6 @@ const char *const tdt_variant_inflate2 = ""
 #define B2_PARMAX 16                       // longest match a lane copies by itself (bytes); 32 with two loads was measured: slower
 #ifndef B2_HOP2
 #define B2_HOP2 1
-#endif
-#ifndef B2_ROT
-#define B2_ROT 0                           // 1: the symbol loop ROTATED — loads of window k's copies, decode of window k+1, stores of window k (see the B2_ROT loop)
 #endif
 #ifndef B2_W2
 #define B2_W2 0                            // 1: TWO windows (128 bit offsets) per trip of the symbol loop — see the B2_W2 loop below
@@ -678,102 +672,7 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
         }
         // ---- the symbols of this block, a window of 64 bit offsets at a time
         B2_MARK(11);                                                  // (block header + code lengths + the two table builds)
-#if B2_ROT
-        // ---- the symbol loop rotated by half a trip: [loads of window k's own-lane copies] [decode of window k+1] [stores + replays of window k].
-        // The loads' memory round trip (0.5 us, a quarter of a window) passes while the next window is decoded; nothing that is loaded is
-        // carried around the loop (round 4's B2_PIPE carried the loaded words into the next trip, and the compiler, which has to copy a
-        // conditionally loaded loop-carried value, waited for them right behind the load).  What IS carried is the pending window in three
-        // registers: ol (output bytes per lane: 0 / 1 literal / 3..258 match), x (literal byte or distance - 1), pos.
-        {
-            unsigned p_ol = 0, p_x = 0, p_pos = 0, p_op = op;       // the pending window (p_op: the output position it started at)
-            bool pending = false, finished = false;
-            unsigned stop = 0;
-            for (;;) {
-                // A: the pending window's literal stores and the LOADS of its own-lane copies
-                const bool copy = p_ol >= 3;
-                const unsigned srco = p_pos - p_x - 1u;
-                const bool wide = copy && srco + p_ol <= p_op && p_ol <= B2_PARMAX && p_ol >= 4 && srco + 16 <= isize;
-                const bool tri = copy && p_ol == 3 && srco + 3 <= p_op;
-                unsigned w3, tw;
-                B2U128 vv;
-                asm volatile("" : "=v"(w3), "=v"(tw), "=v"(vv.w[0]), "=v"(vv.w[1]), "=v"(vv.w[2]), "=v"(vv.w[3]));
-                if (pending) {
-                    if (p_ol == 1) dst[p_pos] = (unsigned char)p_x;
-                    if (tri) w3 = reinterpret_cast<const B2U32 *>(dst + srco)->v;
-                    if (wide) {
-                        vv = *reinterpret_cast<const B2U128 *>(dst + srco);
-                        tw = reinterpret_cast<const B2U32 *>(dst + (srco + p_ol - 4u))->v;
-                    }
-                }
-                // B: decode the next window
-                unsigned n_ol = 0, n_x = 0, n_pos = 0, n_op = op;
-                bool have_next = false;
-                if (!finished) {
-                    unsigned pk, sy;
-                    b2_spec(win, lut_ll, lut_d, bp + (unsigned)lane, lane, pk, sy);
-                    u64 chain = 0;
-                    unsigned cur = 0;
-                    b2_walk(win, lut_ll, lut_d, sorted_ll, meta_ll, sorted_d, meta_d, bp, lane, pk, sy, chain, cur, stop, err);
-                    if (err != B2_OK) break;
-                    n_ol = b2_sel(chain, sy & 0x1ffu, 0u);
-                    const unsigned incl = b2_scan(n_ol);
-                    const unsigned tot = b2_rl(incl, 63);
-                    n_pos = op + incl - n_ol;
-                    n_x = sy >> 9;
-                    if (op + tot > isize || __ballot(n_ol >= 3 && n_x >= n_pos)) {
-                        err = op + tot > isize ? B2_E_OVERRUN : B2_E_DIST;
-                        break;
-                    }
-                    op += tot;
-                    bp += cur;
-                    if (bp > end_bit) {
-                        err = B2_E_INPUT;
-                        break;
-                    }
-                    have_next = true;
-                    finished = stop == 2;
-                }
-                // C: the pending window's stores, then its replayed matches (stream order)
-                __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0), nothing else
-                if (pending) {
-                    if (tri) {
-                        reinterpret_cast<B2U16 *>(dst + p_pos)->v = (unsigned short)w3;
-                        dst[p_pos + 2] = (unsigned char)(w3 >> 16);
-                    }
-                    if (wide) {
-                        const bool g8 = p_ol >= 8, g12 = p_ol >= 12, g16 = p_ol >= 16;
-                        reinterpret_cast<B2U32 *>(dst + p_pos)->v = vv.w[0];
-                        reinterpret_cast<B2U32 *>(dst + (p_pos + (g8 ? 4u : 0u)))->v = g8 ? vv.w[1] : vv.w[0];
-                        reinterpret_cast<B2U32 *>(dst + (p_pos + (g12 ? 8u : 0u)))->v = g12 ? vv.w[2] : vv.w[0];
-                        reinterpret_cast<B2U32 *>(dst + (p_pos + (g16 ? 12u : 0u)))->v = g16 ? vv.w[3] : vv.w[0];
-                        reinterpret_cast<B2U32 *>(dst + (p_pos + p_ol - 4u))->v = tw;
-                    }
-                    u64 mm = __ballot(copy && !(wide || tri));
-                    while (mm) {
-                        const unsigned l = (unsigned)__builtin_ctzll(mm);
-                        mm &= ~(1ull << l);
-                        const unsigned len = b2_rl(p_ol, l), dd = b2_rl(p_x, l) + 1u, p = b2_rl(p_pos, l), so = p - dd;
-                        if (dd >= len) {
-                            for (unsigned i = (unsigned)lane; i < len; i += 64) dst[p + i] = dst[so + i];
-                        } else {
-                            unsigned j = (unsigned)lane % dd;
-                            const unsigned step = 64u % dd;
-                            for (unsigned i = (unsigned)lane; i < len; i += 64) {
-                                dst[p + i] = dst[so + j];
-                                j += step;
-                                j -= j >= dd ? dd : 0u;
-                            }
-                        }
-                    }
-                }
-                if (!have_next) break;
-                B2_ENSURE();                                        // (the ring refill's wait drains the queue: behind the pending window's stores, not in front)
-                if (err != B2_OK) break;
-                p_ol = n_ol, p_x = n_x, p_pos = n_pos, p_op = n_op;
-                pending = true;
-            }
-        }
-#elif B2_W2
+#if B2_W2
         // ---- TWO windows per trip: the lanes decode the symbols that would start at bp + lane AND at bp + 64 + lane, the chain is walked
         // through the first set and on through the second, and what a trip pays once whatever it decodes — the ring gather and the LUT round
         // trips, the prefix sum, the memory round trip of the own-lane copies, the cursor and the ring refill — is paid once per ~11 symbols
