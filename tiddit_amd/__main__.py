@@ -222,10 +222,52 @@ def run_sv(args, version):
     T.clear()
     STAGE_NOTES.clear()
     from .trace import stage
+    # The GC / N-mask bins depend on the reference FASTA alone (the reference computes them after the signals, __main__.py:166): a
+    # second host thread with its own library context (own streams and scratch) reads the FASTA and runs the GC kernel BESIDE the BAM
+    # scan — the scan waits inside the library (inflate-kernel bound; its row path holds no Python since round 4), so the thread's
+    # short Python moments cost it nothing, and 3 GB more over a link that carries 54 GB in 2.2 s are noise.  (While the rows were
+    # Python objects the thread started behind the scan, tiddit_signal.AFTER_SCAN, because the two fought over the GIL: that left
+    # 0.42 s of a 3-Gb job waiting for it.)  On N ranks every rank computes the bins of ITS contigs (dist.shard_contigs) and rank 0
+    # receives them.  TIDDIT_GC_OVERLAP=0: in sequence on rank 0's main thread; =after: the thread starts when the scan is over.
+    gc_job = None
+    gc_mode = os.environ.get("TIDDIT_GC_OVERLAP", "1")
+    if gc_mode != "0":
+        import threading
+        from . import _native
+        gc_job = {}
+        gc_mine = list(chromosomes)
+        if multi:
+            owned = tdist.shard_contigs([contig_length[c] for c in chromosomes], world)[rank]
+            gc_mine = [chromosomes[i] for i in owned]
+
+        def gc_thread():
+            try:
+                ctx = _native.Context(_native.default_context().device)
+                fasta = FastaFile(args.ref)
+                gc_job["result"] = tiddit_gc.gc_of_contigs(fasta, gc_mine, 50, 0.5, ctx=ctx)
+            except BaseException as e:           # re-raised on the main thread
+                gc_job["error"] = e
+            gc_job["seconds"] = time.time() - gc_job["t0"]
+
+        def start_gc():
+            if "thread" not in gc_job:
+                gc_job["t0"] = time.time()
+                gc_job["thread"] = threading.Thread(target=gc_thread, name="tiddit-gc")
+                gc_job["thread"].start()
+        if gc_mode == "after":
+            tiddit_signal.AFTER_SCAN.append(start_gc)
+        elif not multi and gc_mode != "scan":
+            start_gc()          # one process: now, beside the statistics pass too (started behind it, a 240-Mb job — 0.06 s of scan for 0.055 s of GC
+                                # thread — waited 3-24 ms for the thread at its end; TIDDIT_GC_OVERLAP=scan starts it behind the statistics as before)
     t = time.time()
     with stage("tiddit: library statistics"):
         if not multi:
-            library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=True)
+            try:
+                library = tiddit_stats.statistics(args.bam, args.ref, min_mapq, max_ins_len, args.s, carry=True)
+            except BaseException:
+                if gc_job is not None and "thread" in gc_job:
+                    gc_job["thread"].join()                  # (no helper thread outlives the error)
+                raise
         else:
             # The sample is the head of the file = the head of rank 0's byte range: rank 0 samples it through its own share's reader and
             # keeps the batches for its scan.  Nothing in inflate / record decode / the coverage records depends on the statistics, so the
@@ -261,43 +303,9 @@ def run_sv(args, version):
                 STAGE_NOTES["batches ingested beside rank 0's statistics"] = held
     max_ins_len = args.i if args.i else library["percentile_insert_size"]
     T["library statistics"] = time.time() - t
+    if gc_job is not None and gc_mode != "after":
+        start_gc()              # (the N-rank job and TIDDIT_GC_OVERLAP=scan: beside the scan only)
 
-    # The GC / N-mask bins depend on the reference FASTA alone (the reference computes them after the signals, __main__.py:166): a
-    # second host thread with its own library context (own streams and scratch) reads the FASTA and runs the GC kernel BESIDE the BAM
-    # scan — the scan waits inside the library (inflate-kernel bound; its row path holds no Python since round 4), so the thread's
-    # short Python moments cost it nothing, and 3 GB more over a link that carries 54 GB in 2.2 s are noise.  (While the rows were
-    # Python objects the thread started behind the scan, tiddit_signal.AFTER_SCAN, because the two fought over the GIL: that left
-    # 0.42 s of a 3-Gb job waiting for it.)  On N ranks every rank computes the bins of ITS contigs (dist.shard_contigs) and rank 0
-    # receives them.  TIDDIT_GC_OVERLAP=0: in sequence on rank 0's main thread; =after: the thread starts when the scan is over.
-    gc_job = None
-    gc_mode = os.environ.get("TIDDIT_GC_OVERLAP", "1")
-    if gc_mode != "0":
-        import threading
-        from . import _native
-        gc_job = {}
-        gc_mine = list(chromosomes)
-        if multi:
-            owned = tdist.shard_contigs([contig_length[c] for c in chromosomes], world)[rank]
-            gc_mine = [chromosomes[i] for i in owned]
-
-        def gc_thread():
-            try:
-                ctx = _native.Context(_native.default_context().device)
-                fasta = FastaFile(args.ref)
-                gc_job["result"] = tiddit_gc.gc_of_contigs(fasta, gc_mine, 50, 0.5, ctx=ctx)
-            except BaseException as e:           # re-raised on the main thread
-                gc_job["error"] = e
-            gc_job["seconds"] = time.time() - gc_job["t0"]
-
-        def start_gc():
-            if "thread" not in gc_job:
-                gc_job["t0"] = time.time()
-                gc_job["thread"] = threading.Thread(target=gc_thread, name="tiddit-gc")
-                gc_job["thread"].start()
-        if gc_mode == "after":
-            tiddit_signal.AFTER_SCAN.append(start_gc)
-        else:
-            start_gc()
     t = time.time()
     # one process: the blocks of discordants / splits / clips are placed by a thread while the job goes on (tiddit_cluster takes the tables
     # over, not the files); finish_writes() below waits for it.  TIDDIT_BACKGROUND_WRITES=0: written before tiddit_signal.main returns.
