@@ -370,12 +370,12 @@ __device__ __forceinline__ void b2_walk(const unsigned *win, const unsigned *lut
             asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p2));       // (bits 5:0 = the next symbol's lane, or lane 0 when that hop leaves the set: undone below)
             cur = p2 >> 8;
         }
+        if (__builtin_expect(cur < 128u, 1)) break;                      // (the common exit first, as in the one-window loop)
         if (cur >= 256u) {
             stop = 2;
             cur -= 256u;
             break;
         }
-        if (cur < 128u) break;
         const unsigned at = 63u - (unsigned)__builtin_clzll(chain);      // the chain's last member is the symbol the LUTs did not resolve
         const unsigned qq = qbase + at, d = (qq >> 5) & 127, sh = qq & 31;
         const unsigned w0 = b2_rfl(win[d]), w1 = b2_rfl(win[d + 1]), w2 = b2_rfl(win[d + 2]);
@@ -876,12 +876,14 @@ __global__ __launch_bounds__(64 * B2_WAVES) __attribute__((amdgpu_waves_per_eu(B
                 B2_MARK(9);                                         // (the hops alone; what is left under mark 2 is the long-code path)
                 if (cur >= 128 && cur < 256) pf[10]++;
 #endif
+                // (the common exit first — the walk left the window, 64 <= cur < 128: one compare and one branch on the path every window takes;
+                //  tested behind the end-of-block case it cost 1.5 % of the launch, profiles/r06_ab_inflate_w2.txt (10))
+                if (__builtin_expect(cur < 128, 1)) break;
                 if (cur >= 256) {
                     stop = 2;
                     cur -= 256;
                     break;
                 }
-                if (cur < 128) break;
                 const unsigned at = 63u - (unsigned)__builtin_clzll(chain);      // the chain's last member is the symbol the LUTs did not resolve
                 const unsigned qq = bp + at, d = (qq >> 5) & 127, sh = qq & 31;
                 const unsigned w0 = b2_rfl(win[d]), w1 = b2_rfl(win[d + 1]), w2 = b2_rfl(win[d + 2]);
